@@ -1,0 +1,243 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (``/root/reference`` is mounted there and does
+not exist on the GPU box):
+
+    OMP_NUM_THREADS=1 python tests/golden/make_golden.py
+
+It imports johannesulf/nautilus v1.0.6 from /root/reference, drives the
+functions on the hot path with fixed seeds and writes
+inputs + the reference's outputs as small ``.npz`` files.  Only data is
+stored; no reference source travels.  The oracle (``oracle/``) is pinned
+against these files by ``tests/test_oracle_golden.py``.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+import nautilus  # noqa: E402
+from nautilus import bounds  # noqa: E402
+from nautilus.bounds.basic import minimum_volume_enclosing_ellipsoid  # noqa
+from nautilus.neural import NeuralNetworkEmulator  # noqa: E402
+
+assert nautilus.__version__ == '1.0.6'
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def correlated_cloud(n, d, seed, scale=0.08):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(d, d)) / np.sqrt(d)
+    return 0.5 + scale * rng.normal(size=(n, d)) @ (np.eye(d) + 0.5 * a)
+
+
+def ellipsoid_case(d, n):
+    pts = correlated_cloud(n, d, 100 + d)
+    ell = bounds.Ellipsoid.compute(pts, enlarge_per_dim=1.1,
+                                   rng=np.random.default_rng(0))
+    drawn = ell.sample(512)
+    test = np.random.default_rng(1).random((512, d))
+    # half of the probe points are pulled towards the centre so that the
+    # mask has both values
+    test[::2] = ell.c + 0.35 * (test[::2] - 0.5)
+    y = ell.transform(test)
+    save('ellipsoid_D%d' % d, points=pts, enlarge=1.1, c=ell.c, A=ell.A,
+         B=ell.B, B_inv=ell.B_inv, log_v=ell.log_v, sample=drawn, test=test,
+         transform=y, r2=np.sum(y**2, axis=-1), contains=ell.contains(test))
+
+
+def mvee_sphere():
+    d = 10
+    pts = np.zeros((2 * d, d)) + 0.5
+    for i in range(2 * d):
+        pts[i, i // 2] += 1 if i % 2 else -1
+    pts = np.vstack([pts, np.zeros(d) + 0.5])
+    c, a, a_inv = minimum_volume_enclosing_ellipsoid(pts)
+    save('mvee_sphere_D10', points=pts, c=c, A=a, A_inv=a_inv)
+
+
+def mixture_case():
+    rng = np.random.default_rng(5)
+    d = 6
+    pts = rng.random((400, d))
+    pts[:, :3] = 0.5 + 0.03 * rng.normal(size=(400, 3)) @ np.array(
+        [[1, 0.5, 0], [0, 1, 0.3], [0, 0, 1]])
+    mix = bounds.UnitCubeEllipsoidMixture.compute(
+        pts, enlarge_per_dim=1.1, rng=np.random.default_rng(0))
+    drawn = mix.sample(512)
+    test = np.random.default_rng(6).random((512, d))
+    test[::2, :3] = 0.5 + 0.1 * (test[::2, :3] - 0.5)
+    test[5] = -0.01
+    save('mixture_D6', points=pts, dim_cube=mix.dim_cube, c=mix.ellipsoid.c,
+         B=mix.ellipsoid.B, B_inv=mix.ellipsoid.B_inv, A=mix.ellipsoid.A,
+         log_v=mix.log_v, sample=drawn, test=test,
+         contains=mix.contains(test), transform=mix.transform(test))
+
+
+def member_arrays(union):
+    out = {}
+    for i, b in enumerate(union.bounds):
+        if hasattr(b, 'dim_cube'):
+            out['dim_cube_%d' % i] = b.dim_cube
+            b = b.ellipsoid
+            if b is None:
+                continue
+        out['c_%d' % i] = b.c
+        out['B_%d' % i] = b.B
+        out['B_inv_%d' % i] = b.B_inv
+        out['A_%d' % i] = b.A
+    return out
+
+
+def union_case(name, pts, member_cls, n_split, unit, d):
+    union = bounds.Union.compute(pts, enlarge_per_dim=1.1, unit=unit,
+                                 bound_class=member_cls,
+                                 rng=np.random.default_rng(0))
+    for _ in range(n_split):
+        union.split()
+    k = len(union.bounds)
+    union.reset(np.random.default_rng(7))
+    drawn = union.sample(1500)
+    lo, hi = pts.min(0) - 0.05, pts.max(0) + 0.05
+    test = lo + (hi - lo) * np.random.default_rng(8).random((1024, d))
+    counts = np.sum([b.contains(test) for b in union.bounds], axis=0)
+    save(name, points=pts, K=k, unit=unit, log_v_all=union.log_v_all,
+         sample=drawn, n_sample=union.n_sample, n_reject=union.n_reject,
+         log_v=union.log_v, fifo=union.points, test=test, counts=counts,
+         contains=union.contains(test), **member_arrays(union))
+
+
+def union_cases():
+    rng = np.random.default_rng(11)
+    # two overlapping blobs in 3-D, ellipsoid members, no cube clip
+    pts = np.vstack([0.4 + 0.05 * rng.normal(size=(300, 3)),
+                     0.55 + 0.05 * rng.normal(size=(300, 3))])
+    union_case('union_K2_D3', pts, bounds.Ellipsoid, 1, False, 3)
+    # four blobs in 8-D, mixture members, with the unit-cube clip; two blobs
+    # sit at the cube boundary so that the clip rejects proposals
+    cen = np.array([0.03, 0.35, 0.65, 0.97])
+    pts = np.vstack([np.clip(c + 0.02 * rng.normal(size=(250, 8)), 0,
+                             1 - 1e-9) for c in cen])
+    pts[:, 6:] = rng.random((1000, 2))
+    union_case('union_K4_D8', pts, bounds.UnitCubeEllipsoidMixture, 3, True,
+               8)
+
+
+def emulator_case(d, n, e, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n, d))
+    r = np.linalg.norm(x, axis=1)
+    y = (np.argsort(np.argsort(-r)) + 0.5) / n
+    emu = NeuralNetworkEmulator.train(x, y, n_networks=e)
+    test = rng.normal(size=(256, d))
+    arrays = dict(x=x, y=y, mean=emu.mean, scale=emu.scale, test=test,
+                  predict=emu.predict(test), n_networks=e)
+    for i, net in enumerate(emu.neural_networks):
+        arrays['n_iter_%d' % i] = net.n_iter_
+        arrays['loss_curve_%d' % i] = np.array(net.loss_curve_)
+        for k in range(4):
+            arrays['coef_%d_%d' % (i, k)] = net.coefs_[k]
+            arrays['intercept_%d_%d' % (i, k)] = net.intercepts_[k]
+    save('emulator_D%d_E%d' % (d, e), **arrays)
+
+
+def neural_and_nautilus_case():
+    np.random.seed(0)
+    pts = np.random.random(size=(500, 4))
+    log_l = -np.linalg.norm(pts - 0.5, axis=1)
+    log_l_min = np.median(log_l)
+    nb = bounds.NeuralBound.compute(pts, log_l, log_l_min, n_networks=1,
+                                    rng=np.random.default_rng(0))
+    test = np.random.default_rng(2).random((512, 4))
+    save('neuralbound_D4', points=pts, log_l=log_l, log_l_min=log_l_min,
+         c=nb.outer_bound.c, B=nb.outer_bound.B, B_inv=nb.outer_bound.B_inv,
+         score_predict_min=nb.score_predict_min, test=test,
+         contains=nb.contains(test),
+         score=nb.emulator.predict(nb.outer_bound.transform(test)))
+
+    full = bounds.NautilusBound.compute(
+        pts, log_l, log_l_min, np.log(0.5), n_networks=1,
+        rng=np.random.default_rng(0))
+    full.reset(np.random.default_rng(3))
+    drawn = full.sample(2000)
+    save('nautilusbound_D4', points=pts, log_l=log_l, log_l_min=log_l_min,
+         log_v_target=np.log(0.5), sample=drawn, n_sample=full.n_sample,
+         n_reject=full.n_reject, outer_n_sample=full.outer_bound.n_sample,
+         outer_n_reject=full.outer_bound.n_reject, log_v=full.log_v,
+         test=test, contains=full.contains(test),
+         n_neural=len(full.neural_bounds),
+         n_outer=len(full.outer_bound.bounds))
+
+
+def gauss3(x):
+    return -0.5 * np.sum(((x - np.array([0.4, 0.5, 0.6])) / 0.1)**2, axis=-1)
+
+
+def e2e_cases():
+    """Full reference runs: the oracle driver must reproduce them exactly,
+    and they give the statistical band for the device path."""
+    rows = []
+    for n_networks, seed in [(0, 0), (0, 1), (1, 0), (1, 1), (2, 2)]:
+        s = nautilus.Sampler(lambda x: x, gauss3, n_dim=3, n_live=400,
+                             n_networks=n_networks, vectorized=True,
+                             seed=seed)
+        s.run(n_eff=3000, discard_exploration=True)
+        pts, log_w, log_l = s.posterior()
+        w = np.exp(log_w)
+        rows.append(dict(
+            n_networks=n_networks, seed=seed, n_live=400, n_eff_target=3000,
+            log_z=float(s.log_z), n_eff=float(s.n_eff), n_like=int(s.n_like),
+            n_bounds=len(s.bounds), eta=float(s.eta),
+            shell_n=s.shell_n.tolist(),
+            shell_n_sample=s.shell_n_sample.tolist(),
+            shell_log_v=s.shell_log_v.tolist(),
+            shell_log_l=s.shell_log_l.tolist(),
+            shell_n_eff=s.shell_n_eff.tolist(),
+            mean=np.average(pts, weights=w, axis=0).tolist(),
+            var=np.average((pts - [0.4, 0.5, 0.6])**2, weights=w,
+                           axis=0).tolist()))
+        print('e2e', rows[-1]['n_networks'], seed, rows[-1]['log_z'],
+              rows[-1]['n_like'])
+    with open(os.path.join(HERE, 'e2e_gauss3.json'), 'w') as f:
+        json.dump(dict(problem='3-D Gaussian mu=(0.4,0.5,0.6) sigma=0.1, '
+                               'identity prior; analytic log_z=-6.4e-5 + '
+                               'log((0.1*sqrt(2pi))^3)',
+                       analytic_log_z=float(3 * np.log(0.1 * np.sqrt(
+                           2 * np.pi)) - 6.4e-5),
+                       runs=rows), f, indent=1)
+
+    # per-shell statistics of one finished run (shellstats fixture)
+    s = nautilus.Sampler(lambda x: x, gauss3, n_dim=3, n_live=400,
+                         n_networks=0, vectorized=True, seed=5)
+    s.run(n_eff=2000)
+    pts, log_w, log_l = s.posterior()
+    arrays = dict(shell_n_sample=s.shell_n_sample, shell_n=s.shell_n,
+                  bound_log_v=np.array([b.log_v for b in s.bounds]),
+                  shell_log_v=s.shell_log_v, shell_log_l=s.shell_log_l,
+                  shell_n_eff=s.shell_n_eff, log_z=s.log_z, n_eff=s.n_eff,
+                  eta=s.eta, log_w=log_w)
+    for i, ll in enumerate(s.log_l):
+        arrays['log_l_%d' % i] = ll
+    save('shellstats', **arrays)
+
+
+if __name__ == '__main__':
+    for d, n in [(3, 200), (20, 400), (50, 600)]:
+        ellipsoid_case(d, n)
+    mvee_sphere()
+    mixture_case()
+    union_cases()
+    emulator_case(5, 1000, 1, 21)
+    emulator_case(20, 600, 2, 22)
+    neural_and_nautilus_case()
+    e2e_cases()

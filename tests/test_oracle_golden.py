@@ -1,0 +1,195 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bounds_oracle as bo
+from oracle import mlp_oracle as mo
+from oracle import sampler_oracle as so
+
+from conftest import GOLDEN, load_golden
+
+
+@pytest.mark.parametrize('d', [3, 20, 50])
+def test_ellipsoid_matches_reference(d):
+    g = load_golden('ellipsoid_D%d' % d)
+    ell = bo.OEllipsoid.build(g['points'], enlarge_per_dim=float(g['enlarge']),
+                              rng=np.random.default_rng(0))
+    for key in ('c', 'A', 'B', 'B_inv'):
+        assert np.array_equal(getattr(ell, key), g[key]), key
+    assert ell.log_v == g['log_v']
+    # same generator, same draw order -> identical samples (basic.py:376-381)
+    assert np.array_equal(ell.sample(512), g['sample'])
+    y = ell.transform(g['test'])
+    assert np.array_equal(y, g['transform'])
+    assert np.array_equal(np.sum(y**2, axis=-1), g['r2'])
+    mask = ell.contains(g['test'])
+    assert np.array_equal(mask, g['contains'])
+    assert 0 < mask.sum() < len(mask)
+
+
+def test_mvee_known_answer():
+    # tests/test_bounds.py:88-101 of the reference: c = 0.5, A = I
+    g = load_golden('mvee_sphere_D10')
+    c, a, a_inv = bo.mvee(g['points'])
+    assert np.array_equal(c, g['c']) and np.array_equal(a, g['A'])
+    assert np.allclose(c, 0.5, rtol=0, atol=1e-3)
+    assert np.allclose(a, np.eye(10), rtol=0, atol=1e-2)
+
+
+def test_spd_inverse():
+    rng = np.random.default_rng(0)
+    m = rng.normal(size=(12, 12))
+    m = m @ m.T + np.eye(12)
+    assert np.allclose(bo.spd_inverse(m), np.linalg.inv(m))
+
+
+def test_mixture_matches_reference():
+    g = load_golden('mixture_D6')
+    mix = bo.OMixture.build(g['points'], enlarge_per_dim=1.1,
+                            rng=np.random.default_rng(0))
+    assert np.array_equal(mix.dim_cube, g['dim_cube'])
+    assert 0 < mix.dim_cube.sum() < 6
+    for key in ('c', 'B', 'B_inv', 'A'):
+        assert np.array_equal(getattr(mix.ellipsoid, key), g[key])
+    assert mix.log_v == g['log_v']
+    assert np.array_equal(mix.sample(512), g['sample'])
+    assert np.array_equal(mix.contains(g['test']), g['contains'])
+    assert np.array_equal(mix.transform(g['test']), g['transform'])
+
+
+@pytest.mark.parametrize('name,cls,n_split,unit', [
+    ('union_K2_D3', bo.OEllipsoid, 1, False),
+    ('union_K4_D8', bo.OMixture, 3, True)])
+def test_union_matches_reference(name, cls, n_split, unit):
+    g = load_golden(name)
+    union = bo.OUnion.build(g['points'], enlarge_per_dim=1.1, unit=unit,
+                            member_cls=cls, rng=np.random.default_rng(0))
+    for _ in range(n_split):
+        union.split()
+    assert len(union.bounds) == int(g['K'])
+    assert np.array_equal(union.log_v_all, g['log_v_all'])
+    for i, b in enumerate(union.bounds):
+        e = b.ellipsoid if hasattr(b, 'dim_cube') else b
+        if hasattr(b, 'dim_cube'):
+            assert np.array_equal(b.dim_cube, g['dim_cube_%d' % i])
+        if e is not None:
+            assert np.array_equal(e.B, g['B_%d' % i])
+    union.reset(np.random.default_rng(7))
+    assert np.array_equal(union.sample(1500), g['sample'])
+    assert union.n_sample == g['n_sample']
+    assert union.n_reject == g['n_reject'] and union.n_reject > 0
+    assert union.log_v == g['log_v']
+    assert np.array_equal(union.points, g['fifo'])
+    assert np.array_equal(union.member_count(g['test']), g['counts'])
+    assert np.array_equal(union.contains(g['test']), g['contains'])
+
+
+def test_union_errors():
+    # tests/test_bounds.py:175-181 and union.py:175-177
+    with pytest.raises(ValueError):
+        bo.OUnion.build(np.random.random(size=(100, 10)), n_points_min=5)
+    u = bo.OUnion.build(np.random.random(size=(100, 3)), member_cls=bo.OMixture)
+    with pytest.raises(ValueError):
+        u.split(allow_overlap=False)
+    with pytest.raises(ValueError):
+        bo.OEllipsoid.build(np.random.random(size=(3, 3)))
+    with pytest.raises(ValueError):
+        bo.OEllipsoid.build(np.random.random(size=(30, 3)), 0.9)
+
+
+@pytest.mark.parametrize('name', ['emulator_D5_E1', 'emulator_D20_E2'])
+def test_emulator_matches_sklearn(name):
+    """The restated MLPRegressor.fit reproduces scikit-learn's weights, loss
+    curve and stopping epoch (same BLAS calls -> expected bit-identical; the
+    assertion allows 1e-9 for other BLAS builds)."""
+    g = load_golden(name)
+    emu = mo.Emulator.train(g['x'], g['y'], n_networks=int(g['n_networks']))
+    assert np.array_equal(emu.mean, g['mean'])
+    assert np.array_equal(emu.scale, g['scale'])
+    for i, net in enumerate(emu.networks):
+        assert net.n_iter == int(g['n_iter_%d' % i])
+        assert np.allclose(net.loss_curve, g['loss_curve_%d' % i], rtol=0,
+                           atol=1e-9)
+        for k in range(4):
+            assert np.allclose(net.coefs[k], g['coef_%d_%d' % (i, k)],
+                               rtol=0, atol=1e-9)
+            assert np.allclose(net.intercepts[k],
+                               g['intercept_%d_%d' % (i, k)], rtol=0,
+                               atol=1e-9)
+    assert np.allclose(emu.predict(g['test']), g['predict'], rtol=0,
+                       atol=1e-9)
+    # reference tests/test_neural.py:6-15 quality pin (D5 case)
+    if name == 'emulator_D5_E1':
+        assert np.sqrt(np.mean((emu.predict(g['x']) - g['y'])**2)) < \
+            0.3 * np.std(g['y'])
+
+
+def test_neural_bound_matches_reference():
+    g = load_golden('neuralbound_D4')
+    nb = bo.ONeural.build(g['points'], g['log_l'], float(g['log_l_min']),
+                          n_networks=1, rng=np.random.default_rng(0))
+    assert np.array_equal(nb.outer_bound.B, g['B'])
+    assert np.isclose(nb.score_predict_min, g['score_predict_min'], rtol=0,
+                      atol=1e-9)
+    score = nb.emulator.predict(nb.outer_bound.transform(g['test']))
+    assert np.allclose(score, g['score'], rtol=0, atol=1e-9)
+    assert np.array_equal(nb.contains(g['test']), g['contains'])
+
+
+def test_nautilus_bound_matches_reference():
+    g = load_golden('nautilusbound_D4')
+    b = bo.ONautilus.build(g['points'], g['log_l'], float(g['log_l_min']),
+                           float(g['log_v_target']), n_networks=1,
+                           rng=np.random.default_rng(0))
+    assert len(b.neural_bounds) == int(g['n_neural'])
+    assert len(b.outer_bound.bounds) == int(g['n_outer'])
+    b.reset(np.random.default_rng(3))
+    assert np.array_equal(b.sample(2000), g['sample'])
+    assert (b.n_sample, b.n_reject) == (g['n_sample'], g['n_reject'])
+    assert (b.outer_bound.n_sample, b.outer_bound.n_reject) == (
+        g['outer_n_sample'], g['outer_n_reject'])
+    assert b.log_v == g['log_v']
+    assert np.array_equal(b.contains(g['test']), g['contains'])
+
+
+def test_shell_statistics_match_reference():
+    g = load_golden('shellstats')
+    n_shell = len(g['shell_n'])
+    out = [so.shell_stats(g['log_l_%d' % i], g['bound_log_v'][i],
+                          g['shell_n_sample'][i]) for i in range(n_shell)]
+    v, l, e = (np.array(col) for col in zip(*out))
+    assert np.array_equal(v, g['shell_log_v'])
+    assert np.array_equal(l, g['shell_log_l'])
+    assert np.array_equal(e, g['shell_n_eff'])
+    assert so.evidence(l, v) == g['log_z']
+    assert so.total_n_eff(l, v, e) == g['n_eff']
+    lw = so.point_log_weights(v, g['shell_n'],
+                              [g['log_l_%d' % i] for i in range(n_shell)])
+    assert np.array_equal(lw, g['log_w'])
+
+
+def _gauss3(x):
+    return -0.5 * np.sum(((x - np.array([0.4, 0.5, 0.6])) / 0.1)**2, axis=-1)
+
+
+@pytest.mark.parametrize('row', [0, 2])
+def test_full_run_reproduces_reference(row):
+    """Whole-driver pin: same seed -> same number of likelihood calls, same
+    shells, same evidence as the reference (tests/golden/e2e_gauss3.json)."""
+    with open(os.path.join(GOLDEN, 'e2e_gauss3.json')) as f:
+        ref = json.load(f)['runs'][row]
+    s = so.OSampler(lambda x: x, _gauss3, n_dim=3, n_live=ref['n_live'],
+                    n_networks=ref['n_networks'], vectorized=True,
+                    seed=ref['seed'])
+    s.run(n_eff=ref['n_eff_target'], discard_exploration=True)
+    assert s.n_like == ref['n_like']
+    assert len(s.bounds) == ref['n_bounds']
+    assert s.shell_n.tolist() == ref['shell_n']
+    assert s.shell_n_sample.tolist() == ref['shell_n_sample']
+    assert np.isclose(s.log_z, ref['log_z'], rtol=0, atol=1e-9)
+    assert np.isclose(s.n_eff, ref['n_eff'], rtol=1e-9)
