@@ -1,0 +1,206 @@
+/* nautilus_hip.h -- C ABI of the MI355X (gfx950) shell-filling hot path.
+ *
+ * The reference (johannesulf/nautilus v1.0.6) is pure Python and has no FFI;
+ * its seam for this path is the duck-typed bound protocol
+ *     Class.compute / .contains(points) / .sample(n) / .log_v / .reset(rng)
+ * used by nautilus/sampler.py:791-798, 932, 1002, 1023-1035, 1069, 1218 and
+ * the emulator protocol NeuralNetworkEmulator.train / .predict
+ * (nautilus/neural.py:50, 100).  Every entry point below states the reference
+ * call it replaces (paths relative to /root/reference).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (NB_OK) on success, nonzero otherwise;
+ *     nb_last_error() gives the message; nothing throws across the boundary;
+ *   - "dev" pointers are device (HBM) pointers, "host" pointers are host
+ *     memory; points are float64, C-contiguous, row-major (n, n_dim) exactly
+ *     like the reference's numpy arrays;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued asynchronously on it, the caller synchronises;
+ *   - n_dim <= 128; the emulator architecture is the reference default
+ *     (100, 50, 20) ReLU MLP (nautilus/neural.py:79-81).
+ */
+#ifndef NAUTILUS_HIP_H
+#define NAUTILUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_ABI_VERSION 1
+
+typedef struct nb_bound nb_bound;          /* opaque bound living in HBM     */
+typedef struct nb_boundlist nb_boundlist;  /* device array of bound pointers */
+
+/* One member of a union: an ellipsoid over the dims `idx_ell`, the unit
+ * interval [0,1) over all other dims.
+ *   n_ell == n_dim -> Ellipsoid                  (bounds/basic.py:244)
+ *   0 < n_ell < n_dim -> UnitCubeEllipsoidMixture (bounds/basic.py:452)
+ *   n_ell == 0 -> UnitCube                        (bounds/basic.py:9)       */
+typedef struct {
+  int32_t n_ell;
+  const int32_t* idx_ell; /* [n_ell] increasing; NULL means 0..n_ell-1       */
+  const double* c;        /* [n_ell]        Ellipsoid.c                      */
+  const double* B;        /* [n_ell*n_ell]  Ellipsoid.B, lower triangular    */
+  const double* B_inv;    /* [n_ell*n_ell]  Ellipsoid.B_inv, lower triangular*/
+  int32_t free_dims;      /* 1: the non-ellipsoid dims are unbounded (a plain
+                             lower-dimensional Ellipsoid), 0: they are [0,1) */
+} nb_member_desc;
+
+/* sklearn MLPRegressor weights of the emulator (neural.py:139-143 layout).  */
+typedef struct {
+  int32_t n_networks;
+  const double* mean;              /* [n_dim] NeuralNetworkEmulator.mean     */
+  const double* scale;             /* [n_dim] NeuralNetworkEmulator.scale    */
+  const double* const* coefs;      /* [n_networks*4] (fan_in, fan_out) arrays*/
+  const double* const* intercepts; /* [n_networks*4]                         */
+} nb_mlp_desc;
+
+/* NeuralBound (bounds/neural.py:10): ellipsoid AND emulator threshold.      */
+typedef struct {
+  nb_member_desc ellipsoid;     /* NeuralBound.outer_bound (n_ell == n_dim)  */
+  const nb_mlp_desc* mlp;       /* NULL when n_networks == 0                 */
+  double score_predict_min;     /* NeuralBound.score_predict_min             */
+} nb_neural_desc;
+
+/* Any bound of the reference as one description:
+ *   UnitCube        n_members=1 (n_ell=0), unit_cube=1, n_neural=0
+ *   Ellipsoid / Mixture   n_members=1, unit_cube=0
+ *   Union           n_members=K, unit_cube = (Union.cube is not None)
+ *   NeuralBound     n_members=0, n_neural=1
+ *   NautilusBound   outer_bound -> members, neural_bounds -> neural         */
+typedef struct {
+  int32_t n_dim;
+  int32_t n_members;
+  const nb_member_desc* members;
+  const double* log_v_all;      /* [n_members] Union.log_v_all               */
+  int32_t unit_cube;
+  int32_t n_neural;
+  const nb_neural_desc* neural;
+} nb_bound_desc;
+
+int nb_abi_version(void);
+const char* nb_last_error(void);
+
+/* Upload a bound (host description -> packed HBM blob).  Replaces the
+ * in-memory state built by *.compute (basic.py:265-316, union.py:78-151,
+ * bounds/neural.py:58-97, nautilus.py:88-144); construction itself (MVEE, GMM
+ * split) stays on the host.                */
+int nb_bound_create(const nb_bound_desc* desc, nb_bound** out);
+int nb_bound_destroy(nb_bound* bound);
+int64_t nb_bound_nbytes(const nb_bound* bound);
+
+/* Device array of bounds for multi-bound queries.                           */
+int nb_boundlist_create(nb_bound* const* bounds, int32_t n, nb_boundlist** out);
+int nb_boundlist_destroy(nb_boundlist* list);
+
+/* contains(points) of any bound: basic.py:51-67, 344-360, 594-617,
+ * union.py:269-289, bounds/neural.py:99-126, nautilus.py:146-169.
+ * mask_dev[i] = 1 if point i is inside.                                     */
+int nb_contains(const nb_bound* bound, const double* x_dev, int64_t n,
+                uint8_t* mask_dev, void* stream);
+
+/* Shell exclusion (sampler.py:796-798): mask_dev[i] = 1 if ANY bound of the
+ * list contains point i (bounds are tested in list order, a tile of points
+ * stops as soon as all of its points are decided).                          */
+int nb_contains_any(const nb_boundlist* list, const double* x_dev, int64_t n,
+                    uint8_t* mask_dev, void* stream);
+
+/* Shell association (sampler.py:1192-1221): idx_dev[i] = position in the list
+ * of the FIRST bound that contains point i, -1 if none (pass the bounds from
+ * the highest index down to get the reference's association).               */
+int nb_first_containing(const nb_boundlist* list, const double* x_dev,
+                        int64_t n, int32_t* idx_dev, void* stream);
+
+/* Overlap count k_i = #members containing x_i (union.py:316-317).           */
+int nb_member_count(const nb_bound* bound, const double* x_dev, int64_t n,
+                    uint8_t* count_dev, void* stream);
+
+/* Ellipsoid-frame radius and emulator score of neural bound 0 of `bound`:
+ * out_dev[2i] = |B_inv (x_i - c)|^2 (basic.py:340,360), out_dev[2i+1] =
+ * NeuralNetworkEmulator.predict(transform(x_i)) (neural.py:100-116).        */
+int nb_neural_score(const nb_bound* bound, const double* x_dev, int64_t n,
+                    double* out_dev, void* stream);
+
+/* Raw proposals of Union.sample / UnitCube.sample / Ellipsoid.sample
+ * (union.py:305-312, basic.py:85, 376-381, 633-640) for the global proposal
+ * indices offset .. offset+n-1 of Philox stream `seed` (DESIGN.md "RNG
+ * contract"): member by inverse CDF on softmax(log_v_all), uniform-in-
+ * ellipsoid map, uniform cube columns.  x_dev receives n rows.              */
+int nb_propose(const nb_bound* bound, uint64_t seed, uint64_t offset,
+               int64_t n, double* x_dev, void* stream);
+
+/* Acceptance of the proposals written by nb_propose with the same (seed,
+ * offset): flags_dev[i] bit0 = kept by the outer union (unit-cube clip,
+ * union.py:313-314, and u > 1 - 1/k, union.py:316-319), bit1 = also inside
+ * any NeuralBound (nautilus.py:217-219).                                    */
+int nb_accept(const nb_bound* bound, uint64_t seed, uint64_t offset,
+              const double* x_dev, int64_t n, uint8_t* flags_dev,
+              void* stream);
+
+/* Stable stream compaction (the reference's boolean indexing
+ * `points[in_bound]`): rows with (flags & mask) != 0 are copied to out_dev in
+ * input order.  counts_dev[0] = rows with bit0 set, counts_dev[1] = rows
+ * copied.  src_idx_dev (optional) receives the source row of every output
+ * row.  scratch_dev must hold nb_compact_scratch_bytes(n) bytes.            */
+int64_t nb_compact_scratch_bytes(int64_t n);
+int nb_compact_rows(const double* x_dev, const uint8_t* flags_dev,
+                    uint8_t mask, int64_t n, int32_t n_dim, double* out_dev,
+                    int64_t* src_idx_dev, int64_t* counts_dev,
+                    void* scratch_dev, void* stream);
+
+/* Per-shell evidence statistics (sampler.py:927-943): out_dev[0] =
+ * logsumexp(log_l), out_dev[1] = logsumexp(2 log_l), out_dev[2] = max,
+ * out_dev[3] = number of elements >= threshold (sampler.py:1144).           */
+int nb_shell_stats(const double* log_l_dev, int64_t n, double threshold,
+                   double* out_dev, void* scratch_dev, void* stream);
+int64_t nb_shell_stats_scratch_bytes(int64_t n);
+
+/* Emulator training, NeuralNetworkEmulator.train -> MLPRegressor.fit
+ * (neural.py:50-98; sklearn/_multilayer_perceptron.py:620-760): Adam,
+ * minibatch 200, squared loss, stop after 11 stale epochs.  One workgroup per
+ * network.  See nb_mlp_train.hip for the state layout.                      */
+typedef struct nb_trainer nb_trainer;
+int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
+                      const double* x_dev, const double* y_dev,
+                      const double* const* coefs_host,
+                      const double* const* intercepts_host,
+                      nb_trainer** out);
+/* Optional: MLPRegressor hyper-parameters (defaults are the reference's,
+ * neural.py:79-81: lr 1e-2, betas 0.9/0.999, eps 1e-8, batch 200, max_iter
+ * 10000, n_iter_no_change 10, tol 0).                                       */
+int nb_trainer_set_hparams(nb_trainer* t, double lr, double beta1,
+                           double beta2, double epsilon, int32_t batch,
+                           int32_t max_iter, int32_t n_iter_no_change,
+                           double tol);
+/* Run up to n_epochs epochs; perm_dev holds n_networks*n_epochs*n_rows int32
+ * row orders (network-major).  status_host[e] receives n_iter so far, or
+ * -n_iter when network e has stopped.                                       */
+int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
+                   int32_t* status_host, void* stream);
+int nb_trainer_loss_curve(nb_trainer* t, int32_t net, double* out_host,
+                          int32_t max_len);
+int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs_host,
+                       double* const* intercepts_host);
+int nb_trainer_destroy(nb_trainer* t);
+
+/* Philox helper for tests: u_dev[2i], u_dev[2i+1] = the two uniforms of
+ * (seed, offset+i, block, tag).                                             */
+int nb_philox_uniform(uint64_t seed, uint64_t offset, uint32_t block,
+                      uint32_t tag, int64_t n, double* u_dev, void* stream);
+
+/* fp64 MFMA issue-rate microbenchmark (peak calibration for bench.py):
+ * returns achieved TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64.          */
+int nb_mfma_f64_peak(int32_t iters, double* tflops_host);
+
+/* The roofline kernel: single-ellipsoid contains (basic.py:344-360) with the
+ * points streamed once from HBM.  Same result as nb_contains.               */
+int nb_ellipsoid_contains_stream(const nb_bound* bound, const double* x_dev,
+                                 int64_t n, uint8_t* mask_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAUTILUS_HIP_H */

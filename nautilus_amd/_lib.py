@@ -1,0 +1,130 @@
+"""ctypes binding of the C ABI in ``include/nautilus_hip.h``.
+
+The HIP library is the product path; there is no CPU fallback.  If the shared
+object is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libnautilus_hip.so')
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class MemberDesc(C.Structure):
+    _fields_ = [('n_ell', C.c_int32), ('idx_ell', c_int32_p),
+                ('c', c_double_p), ('B', c_double_p), ('B_inv', c_double_p),
+                ('free_dims', C.c_int32)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [('n_networks', C.c_int32), ('mean', c_double_p),
+                ('scale', c_double_p), ('coefs', C.POINTER(c_double_p)),
+                ('intercepts', C.POINTER(c_double_p))]
+
+
+class NeuralDesc(C.Structure):
+    _fields_ = [('ellipsoid', MemberDesc), ('mlp', C.POINTER(MlpDesc)),
+                ('score_predict_min', C.c_double)]
+
+
+class BoundDesc(C.Structure):
+    _fields_ = [('n_dim', C.c_int32), ('n_members', C.c_int32),
+                ('members', C.POINTER(MemberDesc)), ('log_v_all', c_double_p),
+                ('unit_cube', C.c_int32), ('n_neural', C.c_int32),
+                ('neural', C.POINTER(NeuralDesc))]
+
+
+_SIGNATURES = {
+    'nb_abi_version': (C.c_int, []),
+    'nb_last_error': (C.c_char_p, []),
+    'nb_bound_create': (C.c_int, [C.POINTER(BoundDesc),
+                                  C.POINTER(C.c_void_p)]),
+    'nb_bound_destroy': (C.c_int, [C.c_void_p]),
+    'nb_bound_nbytes': (C.c_int64, [C.c_void_p]),
+    'nb_boundlist_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int32,
+                                      C.POINTER(C.c_void_p)]),
+    'nb_boundlist_destroy': (C.c_int, [C.c_void_p]),
+    'nb_contains': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                              C.c_void_p]),
+    'nb_contains_any': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_void_p]),
+    'nb_first_containing': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p]),
+    'nb_member_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_void_p]),
+    'nb_neural_score': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_void_p]),
+    'nb_propose': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64,
+                             C.c_void_p, C.c_void_p]),
+    'nb_accept': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                            C.c_int64, C.c_void_p, C.c_void_p]),
+    'nb_compact_scratch_bytes': (C.c_int64, [C.c_int64]),
+    'nb_compact_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint8,
+                                  C.c_int64, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    'nb_shell_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_double,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nb_shell_stats_scratch_bytes': (C.c_int64, [C.c_int64]),
+    'nb_trainer_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int64,
+                                    C.c_void_p, C.c_void_p,
+                                    C.POINTER(c_double_p),
+                                    C.POINTER(c_double_p),
+                                    C.POINTER(C.c_void_p)]),
+    'nb_trainer_set_hparams': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
+                                         C.c_double, C.c_double, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_double]),
+    'nb_trainer_run': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
+                                 c_int32_p, C.c_void_p]),
+    'nb_trainer_loss_curve': (C.c_int, [C.c_void_p, C.c_int32, c_double_p,
+                                        C.c_int32]),
+    'nb_trainer_weights': (C.c_int, [C.c_void_p, C.c_int32,
+                                     C.POINTER(c_double_p),
+                                     C.POINTER(c_double_p)]),
+    'nb_trainer_destroy': (C.c_int, [C.c_void_p]),
+    'nb_philox_uniform': (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32,
+                                    C.c_uint32, C.c_int64, C.c_void_p,
+                                    C.c_void_p]),
+    'nb_mfma_f64_peak': (C.c_int, [C.c_int32, c_double_p]),
+    'nb_ellipsoid_contains_stream': (C.c_int, [C.c_void_p, C.c_void_p,
+                                               C.c_int64, C.c_void_p,
+                                               C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load ``libnautilus_hip.so`` (built by ``make`` / ``__graft_entry__.build``).
+
+    Raises RuntimeError if it is missing -- the product has no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'nautilus_amd: HIP library %s not found; run `make` (hipcc, '
+            'gfx950).  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nb_abi_version() != 1:
+        raise RuntimeError('nautilus_amd: ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError('nautilus_hip: ' +
+                           load().nb_last_error().decode('utf-8', 'replace'))

@@ -1,0 +1,487 @@
+// C ABI of the hot path (include/nautilus_hip.h): host-side packing of bound
+// descriptions into HBM blobs and thin launch wrappers.  No torch types, no
+// exceptions across the boundary.
+#include "nb_common.h"
+#include "../../include/nautilus_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+// launchers implemented in the kernel translation units
+int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
+                   const double* x, long long n, unsigned char* out_u8,
+                   int* out_i32, double* out_f64, unsigned long long seed,
+                   unsigned long long offset, hipStream_t stream);
+int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
+                   unsigned long long offset, long long n, double* x_out,
+                   hipStream_t stream);
+long long nb_compact_chunks(long long n);
+int nb_launch_compact(const double* x, const unsigned char* flags,
+                      unsigned char mask, long long n, int n_dim, double* out,
+                      long long* src_idx, long long* counts,
+                      long long* chunk_counts, hipStream_t stream);
+int nb_lse_blocks(long long n);
+int nb_launch_shell_stats(const double* log_l, long long n, double threshold,
+                          double* out, double* partial, hipStream_t stream);
+int nb_launch_philox(unsigned long long seed, unsigned long long offset,
+                     unsigned block, unsigned tag, long long n, double* u,
+                     hipStream_t stream);
+int nb_run_mfma_peak(int iters, double* tflops);
+int nb_launch_ell_stream(const double* cvec, const double* binv, int n_dim,
+                         const double* x, long long n, unsigned char* mask,
+                         hipStream_t stream);
+
+static thread_local std::string g_error;
+
+void nb_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+struct nb_bound {
+  double* blob_dev = nullptr;
+  const double** self_list_dev = nullptr;   // device array {blob_dev}
+  int64_t n_doubles = 0;
+  int n_dim = 0, dt = 0, K = 0, M = 0, E = 0;
+  bool single_full_ellipsoid = false;
+  int64_t off_stream = 0;
+};
+
+struct nb_boundlist {
+  const double** ptrs_dev = nullptr;
+  int n = 0, dt = 0, n_dim = 0;
+};
+
+namespace {
+
+const double INF = std::numeric_limits<double>::infinity();
+
+inline void put_i64(std::vector<double>& buf, size_t at, int64_t v) {
+  std::memcpy(&buf[at], &v, sizeof v);
+}
+
+// fills one ell block at buf[at ...]; returns false on invalid input
+bool fill_ell_block(std::vector<double>& buf, size_t at, int n_dim, int dt,
+                    const nb_member_desc& m, bool is_neural) {
+  const int dp = 16 * dt;
+  if (m.n_ell < 0 || m.n_ell > n_dim) {
+    nb_set_error("member n_ell=%d out of range for n_dim=%d", m.n_ell, n_dim);
+    return false;
+  }
+  put_i64(buf, at, m.n_ell);
+  double* lo = &buf[at + 1];
+  double* hi = lo + dp;
+  double* c = hi + dp;
+  double* tiles = c + dp;
+  std::vector<int> idx(m.n_ell);
+  std::vector<char> is_ell(n_dim, 0);
+  for (int i = 0; i < m.n_ell; ++i) {
+    idx[i] = m.idx_ell ? m.idx_ell[i] : i;
+    if (idx[i] < 0 || idx[i] >= n_dim || (i > 0 && idx[i] <= idx[i - 1])) {
+      nb_set_error("idx_ell must be strictly increasing within [0, n_dim)");
+      return false;
+    }
+    is_ell[idx[i]] = 1;
+  }
+  for (int f = 0; f < dp; ++f) {
+    const bool boxed = f < n_dim && !is_ell[f] && !m.free_dims && !is_neural;
+    lo[f] = boxed ? 0.0 : -INF;
+    hi[f] = boxed ? 1.0 : INF;
+    c[f] = 0.0;
+  }
+  for (int i = 0; i < m.n_ell; ++i) c[idx[i]] = m.c[i];
+  for (int i = 0; i < m.n_ell; ++i) {
+    for (int j = 0; j < m.n_ell; ++j) {
+      const double v = m.B_inv[(size_t)i * m.n_ell + j];
+      if (j > i) {
+        if (v != 0.0) {
+          nb_set_error("B_inv must be lower triangular (basic.py:308-309)");
+          return false;
+        }
+        continue;
+      }
+      const int h = idx[i], k = idx[j];       // W0[k][h] = B_inv[h][k]
+      tiles[((size_t)(k >> 4) * dt + (h >> 4)) * NB_TILE + (k & 15) * 16 +
+            (h & 15)] = v;
+    }
+  }
+  return true;
+}
+
+void put_weight(double* tiles, int ht_n, int k, int h, double v) {
+  tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
+        (h & 15)] = v;
+}
+
+void fill_net(double* net, int n_dim, int kt1, const double* const* coefs,
+              const double* const* intercepts) {
+  double* w1 = net;
+  double* w2 = w1 + (size_t)kt1 * NB_HT1 * NB_TILE;
+  double* w3 = w2 + (size_t)NB_HT1 * NB_HT2 * NB_TILE;
+  double* w4 = w3 + (size_t)NB_HT2 * NB_HT3 * NB_TILE;
+  for (int k = 0; k < n_dim; ++k)
+    for (int h = 0; h < NB_H1; ++h)
+      put_weight(w1, NB_HT1, k, h, coefs[0][(size_t)k * NB_H1 + h]);
+  for (int h = 0; h < NB_H1; ++h)
+    put_weight(w1, NB_HT1, n_dim, h, intercepts[0][h]);
+  for (int k = 0; k < NB_H1; ++k)
+    for (int h = 0; h < NB_H2; ++h)
+      put_weight(w2, NB_HT2, k, h, coefs[1][(size_t)k * NB_H2 + h]);
+  for (int h = 0; h < NB_H2; ++h)
+    put_weight(w2, NB_HT2, NB_H1, h, intercepts[1][h]);
+  for (int k = 0; k < NB_H2; ++k)
+    for (int h = 0; h < NB_H3; ++h)
+      put_weight(w3, NB_HT3, k, h, coefs[2][(size_t)k * NB_H3 + h]);
+  for (int h = 0; h < NB_H3; ++h)
+    put_weight(w3, NB_HT3, NB_H2, h, intercepts[2][h]);
+  for (int k = 0; k < NB_H3; ++k) put_weight(w4, 1, k, 0, coefs[3][k]);
+  put_weight(w4, 1, NB_H3, 0, intercepts[3][0]);
+}
+
+inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+}  // namespace
+
+extern "C" {
+
+int nb_abi_version(void) { return NB_ABI_VERSION; }
+
+const char* nb_last_error(void) { return g_error.c_str(); }
+
+int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
+  if (d == nullptr || out == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  const int n_dim = d->n_dim;
+  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT) {
+    nb_set_error("n_dim=%d unsupported (1..%d)", n_dim, 16 * NB_MAX_DT);
+    return NB_ERR_UNSUPPORTED;
+  }
+  const int dt = (n_dim + 15) / 16, dp = 16 * dt;
+  const int K = d->n_members, M = d->n_neural;
+  if (K < 0 || M < 0 || (K > 0 && d->members == nullptr) ||
+      (M > 0 && d->neural == nullptr)) {
+    nb_set_error("inconsistent member / neural counts");
+    return NB_ERR_ARG;
+  }
+  int E = 0;
+  for (int m = 0; m < M; ++m) {
+    const int e = d->neural[m].mlp ? d->neural[m].mlp->n_networks : 0;
+    if (m > 0 && e != E) {
+      nb_set_error("all neural bounds must have the same number of networks");
+      return NB_ERR_ARG;
+    }
+    E = e;
+    if (d->neural[m].ellipsoid.n_ell != n_dim) {
+      nb_set_error("NeuralBound ellipsoid must span all dimensions");
+      return NB_ERR_ARG;
+    }
+  }
+  const int kt1 = (n_dim + 1 + 15) / 16;
+  const int64_t ell_size = nb_ell_block_size(dt);
+  const int64_t net_stride = (int64_t)nb_net_tiles(kt1) * NB_TILE;
+  const int64_t neural_stride = ell_size + 1 + 2 * dp + (int64_t)E * net_stride;
+  const int64_t draw_stride = 2 + 3 * dp + (int64_t)dp * (dp + 1) / 2;
+
+  int64_t off = NB_HDR;
+  const int64_t off_cdf = off; off += (K > 0 ? K : 1);
+  const int64_t off_ulo = off; off += dp;
+  const int64_t off_uhi = off; off += dp;
+  const int64_t off_members = off; off += (int64_t)K * ell_size;
+  const int64_t off_neural = off; off += (int64_t)M * neural_stride;
+  const int64_t off_draw = off; off += (int64_t)K * draw_stride;
+  const bool single_full = (K == 1 && M == 0 && !d->unit_cube &&
+                            d->members[0].n_ell == n_dim);
+  const int64_t off_stream = off;
+  if (single_full) off += dp + (int64_t)dp * (dp + 1) / 2;
+  const int64_t total = off;
+
+  std::vector<double> buf((size_t)total, 0.0);
+  put_i64(buf, NB_H_NDIM, n_dim);
+  put_i64(buf, NB_H_DT, dt);
+  put_i64(buf, NB_H_K, K);
+  put_i64(buf, NB_H_USECUBE, d->unit_cube ? 1 : 0);
+  put_i64(buf, NB_H_M, M);
+  put_i64(buf, NB_H_E, E);
+  put_i64(buf, NB_H_OFF_CDF, off_cdf);
+  put_i64(buf, NB_H_OFF_ULO, off_ulo);
+  put_i64(buf, NB_H_OFF_UHI, off_uhi);
+  put_i64(buf, NB_H_OFF_MEMBERS, off_members);
+  put_i64(buf, NB_H_ELL_STRIDE, ell_size);
+  put_i64(buf, NB_H_OFF_NEURAL, off_neural);
+  put_i64(buf, NB_H_NEURAL_STRIDE, neural_stride);
+  put_i64(buf, NB_H_OFF_DRAW, off_draw);
+  put_i64(buf, NB_H_DRAW_STRIDE, draw_stride);
+  put_i64(buf, NB_H_NET_STRIDE, net_stride);
+  put_i64(buf, NB_H_KT1, kt1);
+  put_i64(buf, NB_H_TOTAL, total);
+  put_i64(buf, NB_H_OFF_STREAM, single_full ? off_stream : 0);
+  if (single_full) {
+    const nb_member_desc& md = d->members[0];
+    for (int i = 0; i < n_dim; ++i) {
+      buf[off_stream + i] = md.c[i];
+      for (int j = 0; j <= i; ++j)
+        buf[off_stream + dp + (size_t)i * (i + 1) / 2 + j] =
+            md.B_inv[(size_t)i * n_dim + j];
+    }
+  }
+
+  // member CDF over softmax(log_v_all), union.py:308
+  if (K > 0) {
+    double mx = -INF;
+    for (int m = 0; m < K; ++m)
+      mx = std::fmax(mx, d->log_v_all ? d->log_v_all[m] : 0.0);
+    std::vector<double> p(K);
+    double sum = 0.0;
+    for (int m = 0; m < K; ++m) {
+      p[m] = std::exp((d->log_v_all ? d->log_v_all[m] : 0.0) - mx);
+      sum += p[m];
+    }
+    double run = 0.0;
+    for (int m = 0; m < K; ++m) {
+      run += p[m] / sum;
+      buf[off_cdf + m] = run;
+    }
+    buf[off_cdf + K - 1] = 1.0;
+  }
+  for (int f = 0; f < dp; ++f) {
+    const bool boxed = d->unit_cube && f < n_dim;
+    buf[off_ulo + f] = boxed ? 0.0 : -INF;
+    buf[off_uhi + f] = boxed ? 1.0 : INF;
+  }
+
+  for (int m = 0; m < K; ++m) {
+    const nb_member_desc& md = d->members[m];
+    if (!fill_ell_block(buf, off_members + m * ell_size, n_dim, dt, md, false))
+      return NB_ERR_ARG;
+    // compact draw block
+    const size_t at = off_draw + m * draw_stride;
+    std::vector<char> is_ell(n_dim, 0);
+    for (int i = 0; i < md.n_ell; ++i)
+      is_ell[md.idx_ell ? md.idx_ell[i] : i] = 1;
+    int nc = 0;
+    for (int f = 0; f < n_dim; ++f) {
+      if (!is_ell[f] && !md.free_dims) {
+        put_i64(buf, at + 2 + dp + nc, f);
+        ++nc;
+      }
+    }
+    put_i64(buf, at, md.n_ell);
+    put_i64(buf, at + 1, nc);
+    for (int i = 0; i < md.n_ell; ++i) {
+      put_i64(buf, at + 2 + i, md.idx_ell ? md.idx_ell[i] : i);
+      buf[at + 2 + 2 * dp + i] = md.c[i];
+      for (int j = 0; j <= i; ++j)
+        buf[at + 2 + 3 * dp + (size_t)i * (i + 1) / 2 + j] =
+            md.B[(size_t)i * md.n_ell + j];
+    }
+  }
+
+  for (int m = 0; m < M; ++m) {
+    const nb_neural_desc& nd = d->neural[m];
+    const size_t at = off_neural + m * neural_stride;
+    if (!fill_ell_block(buf, at, n_dim, dt, nd.ellipsoid, true))
+      return NB_ERR_ARG;
+    buf[at + ell_size] = nd.score_predict_min - 1e-9;   // bounds/neural.py:125
+    double* mean = &buf[at + ell_size + 1];
+    double* scale = mean + dp;
+    for (int f = 0; f < dp; ++f) { mean[f] = 0.0; scale[f] = 1.0; }
+    if (nd.mlp != nullptr) {
+      for (int f = 0; f < n_dim; ++f) {
+        mean[f] = nd.mlp->mean[f];
+        scale[f] = nd.mlp->scale[f];
+      }
+      for (int e = 0; e < E; ++e)
+        fill_net(scale + dp + (size_t)e * net_stride, n_dim, kt1,
+                 nd.mlp->coefs + 4 * e, nd.mlp->intercepts + 4 * e);
+    }
+  }
+
+  nb_bound* b = new nb_bound();
+  b->n_doubles = total;
+  b->n_dim = n_dim; b->dt = dt; b->K = K; b->M = M; b->E = E;
+  b->single_full_ellipsoid = single_full;
+  b->off_stream = off_stream;
+  hipError_t e = hipMalloc((void**)&b->blob_dev, (size_t)total * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemcpy(b->blob_dev, buf.data(), (size_t)total * sizeof(double),
+                  hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->self_list_dev, sizeof(double*));
+  if (e == hipSuccess)
+    e = hipMemcpy(b->self_list_dev, &b->blob_dev, sizeof(double*),
+                  hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    nb_set_error("bound upload failed: %s", hipGetErrorString(e));
+    if (b->blob_dev) (void)hipFree(b->blob_dev);
+    if (b->self_list_dev) (void)hipFree(b->self_list_dev);
+    delete b;
+    return NB_ERR_HIP;
+  }
+  *out = b;
+  return NB_OK;
+}
+
+int nb_bound_destroy(nb_bound* b) {
+  if (b == nullptr) return NB_OK;
+  if (b->blob_dev) (void)hipFree(b->blob_dev);
+  if (b->self_list_dev) (void)hipFree(b->self_list_dev);
+  delete b;
+  return NB_OK;
+}
+
+int64_t nb_bound_nbytes(const nb_bound* b) {
+  return b ? b->n_doubles * (int64_t)sizeof(double) : 0;
+}
+
+int nb_boundlist_create(nb_bound* const* bounds, int32_t n,
+                        nb_boundlist** out) {
+  if (n < 0 || (n > 0 && bounds == nullptr) || out == nullptr) {
+    nb_set_error("bad bound list");
+    return NB_ERR_ARG;
+  }
+  nb_boundlist* l = new nb_boundlist();
+  l->n = n;
+  std::vector<const double*> ptrs(n);
+  for (int i = 0; i < n; ++i) {
+    if (i > 0 && bounds[i]->n_dim != bounds[0]->n_dim) {
+      nb_set_error("bounds of a list must share n_dim");
+      delete l;
+      return NB_ERR_ARG;
+    }
+    ptrs[i] = bounds[i]->blob_dev;
+  }
+  if (n > 0) {
+    l->dt = bounds[0]->dt;
+    l->n_dim = bounds[0]->n_dim;
+    hipError_t e = hipMalloc((void**)&l->ptrs_dev, n * sizeof(double*));
+    if (e == hipSuccess)
+      e = hipMemcpy(l->ptrs_dev, ptrs.data(), n * sizeof(double*),
+                    hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      nb_set_error("bound list upload failed: %s", hipGetErrorString(e));
+      delete l;
+      return NB_ERR_HIP;
+    }
+  }
+  *out = l;
+  return NB_OK;
+}
+
+int nb_boundlist_destroy(nb_boundlist* l) {
+  if (l == nullptr) return NB_OK;
+  if (l->ptrs_dev) (void)hipFree(l->ptrs_dev);
+  delete l;
+  return NB_OK;
+}
+
+int nb_contains(const nb_bound* b, const double* x, int64_t n, uint8_t* mask,
+                void* stream) {
+  return nb_launch_eval(b->dt, b->self_list_dev, 1, 0, x, n, mask, nullptr,
+                        nullptr, 0, 0, as_stream(stream));
+}
+
+int nb_contains_any(const nb_boundlist* l, const double* x, int64_t n,
+                    uint8_t* mask, void* stream) {
+  if (l->n == 0) {
+    NB_HIP_CHECK(hipMemsetAsync(mask, 0, (size_t)n, as_stream(stream)));
+    return NB_OK;
+  }
+  return nb_launch_eval(l->dt, l->ptrs_dev, l->n, 0, x, n, mask, nullptr,
+                        nullptr, 0, 0, as_stream(stream));
+}
+
+int nb_first_containing(const nb_boundlist* l, const double* x, int64_t n,
+                        int32_t* idx, void* stream) {
+  if (l->n == 0) {
+    NB_HIP_CHECK(hipMemsetAsync(idx, 0xFF, (size_t)n * 4, as_stream(stream)));
+    return NB_OK;
+  }
+  return nb_launch_eval(l->dt, l->ptrs_dev, l->n, 1, x, n, nullptr, idx,
+                        nullptr, 0, 0, as_stream(stream));
+}
+
+int nb_member_count(const nb_bound* b, const double* x, int64_t n,
+                    uint8_t* count, void* stream) {
+  return nb_launch_eval(b->dt, b->self_list_dev, 1, 3, x, n, count, nullptr,
+                        nullptr, 0, 0, as_stream(stream));
+}
+
+int nb_neural_score(const nb_bound* b, const double* x, int64_t n, double* out,
+                    void* stream) {
+  if (b->M < 1) {
+    nb_set_error("bound has no neural bound");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_eval(b->dt, b->self_list_dev, 1, 4, x, n, nullptr, nullptr,
+                        out, 0, 0, as_stream(stream));
+}
+
+int nb_propose(const nb_bound* b, uint64_t seed, uint64_t offset, int64_t n,
+               double* x, void* stream) {
+  if (b->K < 1) {
+    nb_set_error("bound has no outer members to draw from");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_draw(b->blob_dev, b->n_dim, seed, offset, n, x,
+                        as_stream(stream));
+}
+
+int nb_accept(const nb_bound* b, uint64_t seed, uint64_t offset,
+              const double* x, int64_t n, uint8_t* flags, void* stream) {
+  return nb_launch_eval(b->dt, b->self_list_dev, 1, 2, x, n, flags, nullptr,
+                        nullptr, seed, offset, as_stream(stream));
+}
+
+int64_t nb_compact_scratch_bytes(int64_t n) {
+  return (nb_compact_chunks(n) * 2 + 2) * (int64_t)sizeof(long long);
+}
+
+int nb_compact_rows(const double* x, const uint8_t* flags, uint8_t mask,
+                    int64_t n, int32_t n_dim, double* out, int64_t* src_idx,
+                    int64_t* counts, void* scratch, void* stream) {
+  return nb_launch_compact(x, flags, mask, n, n_dim, out,
+                           (long long*)src_idx, (long long*)counts,
+                           (long long*)scratch, as_stream(stream));
+}
+
+int64_t nb_shell_stats_scratch_bytes(int64_t n) {
+  return (int64_t)nb_lse_blocks(n) * 4 * sizeof(double);
+}
+
+int nb_shell_stats(const double* log_l, int64_t n, double threshold,
+                   double* out, void* scratch, void* stream) {
+  return nb_launch_shell_stats(log_l, n, threshold, out, (double*)scratch,
+                               as_stream(stream));
+}
+
+int nb_philox_uniform(uint64_t seed, uint64_t offset, uint32_t block,
+                      uint32_t tag, int64_t n, double* u, void* stream) {
+  return nb_launch_philox(seed, offset, block, tag, n, u, as_stream(stream));
+}
+
+int nb_mfma_f64_peak(int32_t iters, double* tflops) {
+  return nb_run_mfma_peak(iters, tflops);
+}
+
+int nb_ellipsoid_contains_stream(const nb_bound* b, const double* x, int64_t n,
+                                 uint8_t* mask, void* stream) {
+  if (!b->single_full_ellipsoid) {
+    nb_set_error("nb_ellipsoid_contains_stream needs a single full ellipsoid");
+    return NB_ERR_ARG;
+  }
+  const double* cvec = b->blob_dev + b->off_stream;
+  return nb_launch_ell_stream(cvec, cvec + 16 * b->dt, b->n_dim, x, n, mask,
+                              as_stream(stream));
+}
+
+}  // extern "C"

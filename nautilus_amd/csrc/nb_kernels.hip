@@ -1,0 +1,368 @@
+// Proposal draw, stream compaction, shell statistics and small helpers.
+#include "nb_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Proposal draw: one thread per proposal, one wavefront per workgroup.
+//   union.py:308-312  member ~ softmax(log_v_all)  (inverse CDF per proposal,
+//                     same distribution as multinomial + shuffle)
+//   basic.py:376-381  z ~ N(0,I); z /= |z|; z *= u^(1/D); x = B z + c
+//   basic.py:85, 633-640  cube columns ~ U[0,1)
+// z lives in LDS in column layout z[j][lane] (bank-conflict free).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
+               unsigned long long offset, long long n,
+               double* __restrict__ x_out) {
+  extern __shared__ __attribute__((aligned(16))) double zs[];
+  const int lane = threadIdx.x;
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  if (i >= n) return;
+  const unsigned long long g = offset + (unsigned long long)i;
+
+  const int n_dim = (int)nb_hdr(blob, NB_H_NDIM);
+  const int dp = 16 * (int)nb_hdr(blob, NB_H_DT);
+  const int K = (int)nb_hdr(blob, NB_H_K);
+  const double* cdf = blob + nb_hdr(blob, NB_H_OFF_CDF);
+  const double* draw = blob + nb_hdr(blob, NB_H_OFF_DRAW);
+  const long long draw_stride = nb_hdr(blob, NB_H_DRAW_STRIDE);
+
+  double u_member, u_accept, u_radius, u_spare;
+  nb_uniform_pair(seed, g, 0u, NB_TAG_CTRL, u_member, u_accept);
+  nb_uniform_pair(seed, g, 1u, NB_TAG_CTRL, u_radius, u_spare);
+
+  int m = 0;
+  for (int j = 0; j < K; ++j) m += (cdf[j] <= u_member) ? 1 : 0;
+  if (m > K - 1) m = K - 1;
+
+  const double* blk = draw + m * draw_stride;
+  const long long* iblk = (const long long*)blk;
+  const int ne = (int)iblk[0];
+  const int nc = (int)iblk[1];
+  const long long* idx_ell = iblk + 2;
+  const long long* idx_cube = idx_ell + dp;
+  const double* c = blk + 2 + 2 * dp;
+  const double* B = c + dp;
+
+  double* row = x_out + i * n_dim;
+
+  if (ne > 0) {
+    double norm2 = 0.0;
+    for (int j = 0; 2 * j < ne; ++j) {
+      double u0, u1;
+      nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_NORMAL, u0, u1);
+      const double r = sqrt(-2.0 * log(1.0 - u0));
+      double sn, cs;
+      sincos(2.0 * M_PI * u1, &sn, &cs);
+      const double z0 = r * cs, z1 = r * sn;
+      zs[(2 * j) * 64 + lane] = z0;
+      norm2 += z0 * z0;
+      if (2 * j + 1 < ne) {
+        zs[(2 * j + 1) * 64 + lane] = z1;
+        norm2 += z1 * z1;
+      }
+    }
+    const double nrm = sqrt(norm2);
+    const double rad = pow(u_radius, 1.0 / (double)ne);
+    for (int j = 0; j < ne; ++j)
+      zs[j * 64 + lane] = (zs[j * 64 + lane] / nrm) * rad;
+    for (int r = 0; r < ne; ++r) {
+      const double* brow = B + (long long)r * (r + 1) / 2;
+      double acc = 0.0;
+      for (int j = 0; j <= r; ++j) acc += brow[j] * zs[j * 64 + lane];
+      row[idx_ell[r]] = acc + c[r];
+    }
+  }
+  for (int j = 0; 2 * j < nc; ++j) {
+    double u0, u1;
+    nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_CUBE, u0, u1);
+    row[idx_cube[2 * j]] = u0;
+    if (2 * j + 1 < nc) row[idx_cube[2 * j + 1]] = u1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Stable stream compaction, three small kernels:
+//   count  : per chunk of CHUNK flags, number of rows with bit0 / with mask
+//   scan   : exclusive scan of the chunk counts (single workgroup)
+//   scatter: wavefront ballot + popcount prefix inside the chunk, survivors
+//            copied row-wise (coalesced) in input order
+// ---------------------------------------------------------------------------
+constexpr int CHUNK = 2048;   // flags per workgroup (256 threads x 8)
+
+__global__ void __launch_bounds__(256)
+nb_count_kernel(const unsigned char* __restrict__ flags, unsigned char mask,
+                long long n, long long* __restrict__ chunk_counts) {
+  __shared__ int s0[4], s1[4];
+  const long long base = (long long)blockIdx.x * CHUNK;
+  int c0 = 0, c1 = 0;
+  for (int k = 0; k < CHUNK / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    const unsigned char f = (i < n) ? flags[i] : 0;
+    c0 += __popcll(__ballot((f & 1) != 0));
+    c1 += __popcll(__ballot((f & mask) != 0));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s0[wave] = c0; s1[wave] = c1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    chunk_counts[2 * blockIdx.x] = s0[0] + s0[1] + s0[2] + s0[3];
+    chunk_counts[2 * blockIdx.x + 1] = s1[0] + s1[1] + s1[2] + s1[3];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+nb_scan_kernel(long long* __restrict__ chunk_counts, long long n_chunks,
+               long long* __restrict__ totals) {
+  // chunk_counts[2c+1] -> exclusive offset (in place); totals = {sum0, sum1}
+  __shared__ long long wsum0[4], wsum1[4];
+  __shared__ long long carry0, carry1;
+  if (threadIdx.x == 0) { carry0 = 0; carry1 = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long base = 0; base < n_chunks; base += 256) {
+    const long long c = base + threadIdx.x;
+    long long v0 = (c < n_chunks) ? chunk_counts[2 * c] : 0;
+    long long v1 = (c < n_chunks) ? chunk_counts[2 * c + 1] : 0;
+    long long i0 = v0, i1 = v1;
+    for (int d = 1; d < 64; d <<= 1) {       // inclusive wave scan
+      const long long t0 = __shfl_up(i0, d), t1 = __shfl_up(i1, d);
+      if (lane >= d) { i0 += t0; i1 += t1; }
+    }
+    if (lane == 63) { wsum0[wave] = i0; wsum1[wave] = i1; }
+    __syncthreads();
+    long long w0 = 0, w1 = 0;
+    for (int w = 0; w < wave; ++w) { w0 += wsum0[w]; w1 += wsum1[w]; }
+    const long long ex1 = carry1 + w1 + i1 - v1;
+    if (c < n_chunks) chunk_counts[2 * c + 1] = ex1;
+    __syncthreads();
+    if (threadIdx.x == 255) { carry0 += w0 + i0; carry1 += w1 + i1; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { totals[0] = carry0; totals[1] = carry1; }
+}
+
+__global__ void __launch_bounds__(256)
+nb_scatter_kernel(const double* __restrict__ x,
+                  const unsigned char* __restrict__ flags, unsigned char mask,
+                  long long n, int n_dim,
+                  const long long* __restrict__ chunk_counts,
+                  double* __restrict__ out, long long* __restrict__ src_idx) {
+  __shared__ int wcount[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * CHUNK;
+  long long dst = chunk_counts[2 * blockIdx.x + 1];
+  for (int k = 0; k < CHUNK / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    const bool keep = (i < n) && ((flags[i] & mask) != 0);
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) wcount[wave] = __popcll(b);
+    __syncthreads();
+    long long wdst = dst;
+    for (int w = 0; w < wave; ++w) wdst += wcount[w];
+    const long long total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    // copy the wave's survivors row by row, all lanes cooperating
+    unsigned long long rem = b;
+    long long o = wdst;
+    const long long wbase = base + k * 256 + wave * 64;
+    while (rem) {
+      const int src_lane = __ffsll((long long)rem) - 1;
+      rem &= rem - 1;
+      const double* srow = x + (wbase + src_lane) * n_dim;
+      double* drow = out + o * n_dim;
+      for (int cidx = lane; cidx < n_dim; cidx += 64) drow[cidx] = srow[cidx];
+      if (src_idx != nullptr && lane == 0) src_idx[o] = wbase + src_lane;
+      ++o;
+    }
+    __syncthreads();
+    dst += total;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Shell statistics (sampler.py:934-937, 1144): streaming (max, sum exp,
+// sum exp^2) with wavefront-shuffle merges.
+// ---------------------------------------------------------------------------
+struct Lse { double m, s1, s2, cnt; };
+
+__device__ inline Lse lse_merge(Lse a, Lse b) {
+  Lse o;
+  o.m = fmax(a.m, b.m);
+  o.cnt = a.cnt + b.cnt;
+  if (o.m == -INFINITY) { o.s1 = 0.0; o.s2 = 0.0; return o; }
+  const double ea = (a.m == -INFINITY) ? 0.0 : exp(a.m - o.m);
+  const double eb = (b.m == -INFINITY) ? 0.0 : exp(b.m - o.m);
+  o.s1 = a.s1 * ea + b.s1 * eb;
+  o.s2 = a.s2 * ea * ea + b.s2 * eb * eb;
+  return o;
+}
+
+__device__ inline Lse lse_wave(Lse v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    Lse o;
+    o.m = __shfl_xor(v.m, d);
+    o.s1 = __shfl_xor(v.s1, d);
+    o.s2 = __shfl_xor(v.s2, d);
+    o.cnt = __shfl_xor(v.cnt, d);
+    v = lse_merge(v, o);
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+nb_lse_partial_kernel(const double* __restrict__ log_l, long long n,
+                      double threshold, double* __restrict__ partial) {
+  __shared__ Lse sh[4];
+  Lse acc = {-INFINITY, 0.0, 0.0, 0.0};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (long long)gridDim.x * 256) {
+    const double v = log_l[i];
+    Lse e = {v, (v == -INFINITY) ? 0.0 : 1.0, (v == -INFINITY) ? 0.0 : 1.0,
+             (v >= threshold) ? 1.0 : 0.0};
+    acc = lse_merge(acc, e);
+  }
+  acc = lse_wave(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Lse t = lse_merge(lse_merge(sh[0], sh[1]), lse_merge(sh[2], sh[3]));
+    partial[4 * blockIdx.x + 0] = t.m;
+    partial[4 * blockIdx.x + 1] = t.s1;
+    partial[4 * blockIdx.x + 2] = t.s2;
+    partial[4 * blockIdx.x + 3] = t.cnt;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+nb_lse_final_kernel(const double* __restrict__ partial, int n_part,
+                    double* __restrict__ out) {
+  Lse acc = {-INFINITY, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n_part; i += 64) {
+    Lse e = {partial[4 * i], partial[4 * i + 1], partial[4 * i + 2],
+             partial[4 * i + 3]};
+    acc = lse_merge(acc, e);
+  }
+  acc = lse_wave(acc);
+  if (threadIdx.x == 0) {
+    out[0] = (acc.m == -INFINITY) ? -INFINITY : acc.m + log(acc.s1);
+    out[1] = (acc.m == -INFINITY) ? -INFINITY : 2.0 * acc.m + log(acc.s2);
+    out[2] = acc.m;
+    out[3] = acc.cnt;
+  }
+}
+
+__global__ void nb_philox_kernel(unsigned long long seed,
+                                 unsigned long long offset, unsigned block,
+                                 unsigned tag, long long n, double* u) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double u0, u1;
+  nb_uniform_pair(seed, offset + (unsigned long long)i, block, tag, u0, u1);
+  u[2 * i] = u0;
+  u[2 * i + 1] = u1;
+}
+
+// back-to-back fp64 MFMA issue-rate probe (4 independent accumulators)
+__global__ void __launch_bounds__(256)
+nb_mfma_peak_kernel(int iters, double* sink) {
+  nb_d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a3, 0, 0, 0);
+  }
+  if (a0[0] + a1[1] + a2[2] + a3[3] == 12345.678)
+    sink[0] = a0[0];
+}
+
+}  // namespace
+
+int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
+                   unsigned long long offset, long long n, double* x_out,
+                   hipStream_t stream) {
+  if (n <= 0) return NB_OK;
+  const long long blocks = (n + 63) / 64;
+  const size_t lds = (size_t)n_dim * 64 * sizeof(double);
+  hipLaunchKernelGGL(nb_draw_kernel, dim3((unsigned)blocks), dim3(64), lds,
+                     stream, blob_dev, seed, offset, n, x_out);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+long long nb_compact_chunks(long long n) { return (n + CHUNK - 1) / CHUNK; }
+
+int nb_launch_compact(const double* x, const unsigned char* flags,
+                      unsigned char mask, long long n, int n_dim, double* out,
+                      long long* src_idx, long long* counts,
+                      long long* chunk_counts, hipStream_t stream) {
+  const long long n_chunks = nb_compact_chunks(n);
+  if (n_chunks == 0) {
+    NB_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(long long), stream));
+    return NB_OK;
+  }
+  hipLaunchKernelGGL(nb_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0,
+                     stream, flags, mask, n, chunk_counts);
+  hipLaunchKernelGGL(nb_scan_kernel, dim3(1), dim3(256), 0, stream,
+                     chunk_counts, n_chunks, counts);
+  if (out != nullptr)
+    hipLaunchKernelGGL(nb_scatter_kernel, dim3((unsigned)n_chunks), dim3(256),
+                       0, stream, x, flags, mask, n, n_dim, chunk_counts, out,
+                       src_idx);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+int nb_lse_blocks(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int nb_launch_shell_stats(const double* log_l, long long n, double threshold,
+                          double* out, double* partial, hipStream_t stream) {
+  const int blocks = nb_lse_blocks(n);
+  hipLaunchKernelGGL(nb_lse_partial_kernel, dim3(blocks), dim3(256), 0,
+                     stream, log_l, n, threshold, partial);
+  hipLaunchKernelGGL(nb_lse_final_kernel, dim3(1), dim3(64), 0, stream,
+                     partial, blocks, out);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+int nb_launch_philox(unsigned long long seed, unsigned long long offset,
+                     unsigned block, unsigned tag, long long n, double* u,
+                     hipStream_t stream) {
+  if (n <= 0) return NB_OK;
+  hipLaunchKernelGGL(nb_philox_kernel, dim3((unsigned)((n + 255) / 256)),
+                     dim3(256), 0, stream, seed, offset, block, tag, n, u);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+int nb_run_mfma_peak(int iters, double* tflops) {
+  double* sink = nullptr;
+  NB_HIP_CHECK(hipMalloc(&sink, 8));
+  hipEvent_t e0, e1;
+  NB_HIP_CHECK(hipEventCreate(&e0));
+  NB_HIP_CHECK(hipEventCreate(&e1));
+  const int blocks = 256 * 4;   // 4 workgroups of 4 waves per CU
+  hipLaunchKernelGGL(nb_mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, 16,
+                     sink);
+  NB_HIP_CHECK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(nb_mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters,
+                     sink);
+  NB_HIP_CHECK(hipEventRecord(e1, 0));
+  NB_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  NB_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4.0 * iters * 4.0 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  return NB_OK;
+}

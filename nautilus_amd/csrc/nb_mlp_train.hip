@@ -1,0 +1,515 @@
+// Emulator training on the matrix cores: NeuralNetworkEmulator.train ->
+// MLPRegressor.fit restated for gfx950 (reference nautilus/neural.py:50-98;
+// algorithm: sklearn/neural_network/_multilayer_perceptron.py:620-760
+// (_fit_stochastic), :297-389 (_backprop), _stochastic_optimizers.py:255-287
+// (Adam), _base.py:187-189 (squared loss)).
+//
+// One persistent workgroup (8 wavefronts) per network; the E networks of an
+// emulator (and of all M neural bounds) train concurrently on different CUs.
+// Every Adam step has two phases separated by a workgroup barrier:
+//
+//  FB  each wavefront takes 16-row tiles of the minibatch: forward through
+//      the four layers with activations held in registers (the MFMA C/D
+//      layout is the next layer's B-operand layout), output delta, backward
+//      deltas through W^T read from the same 16x16 tile-major weights; the
+//      activations and deltas are written row-major to a stash in global
+//      memory (L2 resident, ~0.8 MB per network).
+//  G   each wavefront owns weight tiles: dW = act^T delta contracted over all
+//      rows of the minibatch in a fixed order (deterministic, no atomics),
+//      then the Adam update of that tile in place.  The bias is row K of the
+//      weight matrix (the activations carry a constant 1 in column K).
+//
+// Minibatch order comes from the host (numpy RandomState shuffles identical to
+// sklearn's), so the device sees exactly the reference's data order.
+#include "nb_common.h"
+#include "../../include/nautilus_hip.h"
+
+#include <cstring>
+#include <vector>
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+constexpr int MAXB = 208;        // minibatch rows padded to 16 (batch <= 200)
+constexpr int LD1 = 112, LD2 = 64, LD3 = 32, LD4 = 16;
+constexpr int NWAVE = 8;
+
+struct NetState {
+  double* W; double* M; double* V;   // tile-major weights and Adam moments
+  double* stash;                     // A0 A1 A2 A3 D1 D2 D3 D4
+  double* loss_curve;
+  double* scal;   // [0] adam t  [1] best loss  [2] stale  [3] n_iter  [4] done
+};
+
+struct TrainArgs {
+  const NetState* nets;
+  const double* X;       // (n, D) standardised inputs
+  const double* y;       // (n)
+  const int* perm;       // (E, n_epochs, n)
+  long long n;
+  int n_dim, kt1, n_epochs, max_iter, n_iter_no_change, batch;
+  double tol, lr, b1, b2, eps;
+};
+
+// out[h] = sum_k in[k] W[k][h] for one layer, tiles [kt][HT]
+template <int KSMAX, int HT>
+__device__ __forceinline__ void fwd_layer(const double* __restrict__ w,
+                                          int ks_n, const double* in, int lane,
+                                          double* out, bool relu) {
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks) {
+      if (ks < ks_n) {
+        const double a = w[((ks >> 2) * HT + ht) * NB_TILE + (ks & 3) * 64 + lane];
+        acc = MFMA(a, in[ks], acc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      out[4 * ht + r] = relu ? fmax(acc[r], 0.0) : acc[r];
+  }
+}
+
+// din[k] = sum_h dout[h] W[k][h]  (k over KT tiles, h over HS k-steps of 4)
+template <int KT, int HT, int HS>
+__device__ __forceinline__ void bwd_layer(const double* __restrict__ w,
+                                          const double* dout, int lane,
+                                          double* din) {
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int hs = 0; hs < HS; ++hs) {
+      const int h0 = 4 * hs;
+      const double a = w[(kt * HT + (h0 >> 4)) * NB_TILE + li * 16 +
+                         (h0 & 15) + lg];
+      acc = MFMA(a, dout[hs], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) din[4 * kt + r] = acc[r];
+  }
+}
+
+// write a register block (unit = 4*j + lg of point li) to stash[pt][ld]
+template <int NREG>
+__device__ __forceinline__ void put_stash(double* __restrict__ base, int ld,
+                                          int pt, int lane, const double* v) {
+  const int lg = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NREG; ++j) base[(long long)pt * ld + 4 * j + lg] = v[j];
+}
+
+template <int DT>
+__global__ void __launch_bounds__(64 * NWAVE)
+nb_train_kernel(TrainArgs a) {
+  constexpr int KS1MAX = 4 * DT + 1;
+  __shared__ double tile_loss[MAXB / 16];
+  __shared__ int stop_flag;
+
+  const NetState st = a.nets[blockIdx.x];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int D = a.n_dim, kt1 = a.kt1;
+  const int ld0 = 16 * kt1;
+  const int ks1 = (D + 1 + 3) >> 2;
+
+  if (st.scal[4] != 0.0) return;                 // already stopped
+
+  double* Wbase = st.W;
+  double* Sbase = st.stash;
+
+  const int n_gt1 = kt1 * NB_HT1, n_gt2 = NB_HT1 * NB_HT2,
+            n_gt3 = NB_HT2 * NB_HT3, n_gt4 = NB_HT3;
+  const int n_gt = n_gt1 + n_gt2 + n_gt3 + n_gt4;
+
+  long long t_adam = (long long)st.scal[0];
+  double best = st.scal[1];
+  int stale = (int)st.scal[2];
+  int n_iter = (int)st.scal[3];
+  const long long n = a.n;
+  const int* perm_net = a.perm + (long long)blockIdx.x * a.n_epochs * n;
+
+  for (int ep = 0; ep < a.n_epochs; ++ep) {
+    const int* perm = perm_net + (long long)ep * n;
+    double epoch_acc = 0.0;                       // thread 0 only
+
+    for (long long start = 0; start < n; start += a.batch) {
+      const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
+      const int n_tiles = (nb + 15) >> 4;
+
+      // ------------------------------ phase FB -------------------------
+      for (int tile = wave; tile < n_tiles; tile += NWAVE) {
+        // Launder the (loop-invariant) base pointers: otherwise LICM hoists
+        // several hundred per-lane 64-bit addresses out of the loops and
+        // spills them (cdna_hip_programming.md, "lane-constant address
+        // hoisted to kernel entry").
+        asm volatile("" : "+s"(Wbase));
+        asm volatile("" : "+s"(Sbase));
+        double* W1 = Wbase;
+        double* W2 = W1 + kt1 * NB_HT1 * NB_TILE;
+        double* W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
+        double* W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
+        double* A0 = Sbase;
+        double* A1 = A0 + MAXB * ld0;
+        double* A2 = A1 + MAXB * LD1;
+        double* A3 = A2 + MAXB * LD2;
+        double* D1 = A3 + MAXB * LD3;
+        double* D2 = D1 + MAXB * LD1;
+        double* D3 = D2 + MAXB * LD2;
+        double* D4 = D3 + MAXB * LD3;
+        const int pt = tile * 16 + li;
+        const bool valid = pt < nb;
+        const long long row = valid ? perm[start + pt] : 0;
+
+        double t[KS1MAX];
+#pragma unroll
+        for (int ks = 0; ks < KS1MAX; ++ks) {
+          const int f = 4 * ks + lg;
+          t[ks] = (f < D) ? (valid ? a.X[row * D + f] : 0.0)
+                          : ((f == D) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS1MAX; ++ks)
+          if (4 * ks < ld0) A0[(long long)pt * ld0 + 4 * ks + lg] = t[ks];
+
+        // forward; every layer's activations go to the stash at once so
+        // that only two layers are ever live in registers
+        double h3[4 * NB_HT3], o[4];
+        {
+          double h2[4 * NB_HT2];
+          {
+            double h1[4 * NB_HT1];
+            fwd_layer<KS1MAX, NB_HT1>(W1, ks1, t, lane, h1, true);
+            if (lg == 0) h1[25] = 1.0;
+            put_stash<4 * NB_HT1>(A1, LD1, pt, lane, h1);
+            fwd_layer<26, NB_HT2>(W2, 26, h1, lane, h2, true);
+          }
+          if (lg == 2) h2[12] = 1.0;
+          put_stash<4 * NB_HT2>(A2, LD2, pt, lane, h2);
+          fwd_layer<13, NB_HT3>(W3, 13, h2, lane, h3, true);
+        }
+        if (lg == 0) h3[5] = 1.0;
+        put_stash<4 * NB_HT3>(A3, LD3, pt, lane, h3);
+        fwd_layer<6, 1>(W4, 6, h3, lane, o, false);
+
+        // output delta (sklearn :365) and the squared-loss partial
+        double d4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (lg == 0 && valid) d4[0] = o[0] - a.y[row];
+        put_stash<4>(D4, LD4, pt, lane, d4);
+        double lp = 0.5 * d4[0] * d4[0];
+        for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
+        if (lane == 0) tile_loss[tile] = lp;
+
+        // backward; ReLU masks (activation == 0, sklearn inplace_relu_
+        // derivative) are re-read from the stash this lane wrote above
+        double d2[4 * NB_HT2];
+        {
+          double d3[4 * NB_HT3];
+          bwd_layer<NB_HT3, 1, 1>(W4, d4, lane, d3);
+#pragma unroll
+          for (int j = 0; j < 4 * NB_HT3; ++j) if (h3[j] == 0.0) d3[j] = 0.0;
+          if (lg == 0) d3[5] = 0.0;
+          put_stash<4 * NB_HT3>(D3, LD3, pt, lane, d3);
+          bwd_layer<NB_HT2, NB_HT3, 5>(W3, d3, lane, d2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * NB_HT2; ++j)
+          if (A2[(long long)pt * LD2 + 4 * j + lg] == 0.0) d2[j] = 0.0;
+        if (lg == 2) d2[12] = 0.0;
+        put_stash<4 * NB_HT2>(D2, LD2, pt, lane, d2);
+        {
+          double d1[4 * NB_HT1];
+          bwd_layer<NB_HT1, NB_HT2, 13>(W2, d2, lane, d1);
+#pragma unroll
+          for (int j = 0; j < 4 * NB_HT1; ++j)
+            if (A1[(long long)pt * LD1 + 4 * j + lg] == 0.0) d1[j] = 0.0;
+          if (lg == 0) d1[25] = 0.0;
+          put_stash<4 * NB_HT1>(D1, LD1, pt, lane, d1);
+        }
+      }
+      __syncthreads();
+
+      if (threadIdx.x == 0)
+        for (int i = 0; i < n_tiles; ++i) epoch_acc += tile_loss[i];
+
+      // ------------------------------ phase G + Adam --------------------
+      t_adam += 1;
+      const double lr_t = a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
+                          (1.0 - pow(a.b1, (double)t_adam));
+      const double inv_nb = 1.0 / (double)nb;
+      const int n_steps = n_tiles * 4;
+      for (int gt = wave; gt < n_gt; gt += NWAVE) {
+        asm volatile("" : "+s"(Sbase));
+        const double* A0 = Sbase;
+        const double* A1 = A0 + MAXB * ld0;
+        const double* A2 = A1 + MAXB * LD1;
+        const double* A3 = A2 + MAXB * LD2;
+        const double* D1 = A3 + MAXB * LD3;
+        const double* D2 = D1 + MAXB * LD1;
+        const double* D3 = D2 + MAXB * LD2;
+        const double* D4 = D3 + MAXB * LD3;
+        const double* As; const double* Bs; int lda, ldb, kt, ht;
+        long long woff;
+        if (gt < n_gt1) {
+          kt = gt / NB_HT1; ht = gt % NB_HT1; As = A0; lda = ld0; Bs = D1;
+          ldb = LD1; woff = 0;
+          woff += (long long)(kt * NB_HT1 + ht) * NB_TILE;
+        } else if (gt < n_gt1 + n_gt2) {
+          const int g = gt - n_gt1;
+          kt = g / NB_HT2; ht = g % NB_HT2; As = A1; lda = LD1; Bs = D2;
+          ldb = LD2;
+          woff = (long long)(n_gt1 + kt * NB_HT2 + ht) * NB_TILE;
+        } else if (gt < n_gt1 + n_gt2 + n_gt3) {
+          const int g = gt - n_gt1 - n_gt2;
+          kt = g / NB_HT3; ht = g % NB_HT3; As = A2; lda = LD2; Bs = D3;
+          ldb = LD3;
+          woff = (long long)(n_gt1 + n_gt2 + kt * NB_HT3 + ht) * NB_TILE;
+        } else {
+          const int g = gt - n_gt1 - n_gt2 - n_gt3;
+          kt = g; ht = 0; As = A3; lda = LD3; Bs = D4; ldb = LD4;
+          woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
+        }
+        nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ap = As + (long long)lg * lda + 16 * kt + li;
+        const double* bp = Bs + (long long)lg * ldb + 16 * ht + li;
+        for (int s = 0; s < n_steps; ++s) {
+          acc = MFMA(ap[0], bp[0], acc);
+          ap += 4 * lda;
+          bp += 4 * ldb;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long idx = woff + (lg + 4 * r) * 16 + li;
+          const double g = acc[r] * inv_nb;
+          const double m = a.b1 * st.M[idx] + (1.0 - a.b1) * g;
+          const double v = a.b2 * st.V[idx] + (1.0 - a.b2) * (g * g);
+          st.M[idx] = m;
+          st.V[idx] = v;
+          st.W[idx] += -lr_t * m / (sqrt(v) + a.eps);
+        }
+      }
+      __syncthreads();
+    }
+
+    // ------------------------------ end of epoch ------------------------
+    if (threadIdx.x == 0) {
+      const double loss = epoch_acc / (double)n;
+      st.loss_curve[n_iter] = loss;
+      n_iter += 1;
+      if (loss > best - a.tol) stale += 1; else stale = 0;
+      if (loss < best) best = loss;
+      stop_flag = (stale > a.n_iter_no_change || n_iter >= a.max_iter) ? 1 : 0;
+    }
+    __syncthreads();
+    const int stop = stop_flag;
+    __syncthreads();
+    if (stop) {
+      if (threadIdx.x == 0) st.scal[4] = 1.0;
+      break;
+    }
+  }
+  if (threadIdx.x == 0) {
+    st.scal[0] = (double)t_adam;
+    st.scal[1] = best;
+    st.scal[2] = (double)stale;
+    st.scal[3] = (double)n_iter;
+  }
+}
+
+void put_w(double* tiles, int ht_n, int k, int h, double v) {
+  tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
+        (h & 15)] = v;
+}
+double get_w(const double* tiles, int ht_n, int k, int h) {
+  return tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
+               (h & 15)];
+}
+
+}  // namespace
+
+struct nb_trainer {
+  int n_dim = 0, E = 0, kt1 = 0, dt = 0;
+  long long n = 0;
+  long long n_w = 0;
+  const double* X = nullptr;
+  const double* y = nullptr;
+  std::vector<NetState> nets_host;
+  NetState* nets_dev = nullptr;
+  double* pool = nullptr;          // one allocation for all per-net buffers
+  int max_iter = 10000, n_iter_no_change = 10, batch = 200;
+  double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
+};
+
+extern "C" {
+
+int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
+                      const double* x_dev, const double* y_dev,
+                      const double* const* coefs, const double* const* icpts,
+                      nb_trainer** out) {
+  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT || n_networks < 1 || n_rows < 1) {
+    nb_set_error("bad trainer shape (n_dim=%d, n_networks=%d, n_rows=%lld)",
+                 n_dim, n_networks, (long long)n_rows);
+    return NB_ERR_ARG;
+  }
+  nb_trainer* t = new nb_trainer();
+  t->n_dim = n_dim; t->E = n_networks; t->n = n_rows;
+  t->dt = (n_dim + 15) / 16;
+  t->kt1 = (n_dim + 1 + 15) / 16;
+  t->X = x_dev; t->y = y_dev;
+  t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
+  const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
+  const long long curve = t->max_iter;
+  const long long per_net = 3 * t->n_w + stash + curve + 8;
+  const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
+  hipError_t e = hipMalloc((void**)&t->pool, bytes);
+  if (e == hipSuccess) e = hipMemset(t->pool, 0, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc((void**)&t->nets_dev, n_networks * sizeof(NetState));
+  if (e != hipSuccess) {
+    nb_set_error("trainer allocation failed: %s", hipGetErrorString(e));
+    delete t;
+    return NB_ERR_HIP;
+  }
+  std::vector<double> w((size_t)t->n_w);
+  for (int i = 0; i < n_networks; ++i) {
+    NetState s;
+    double* base = t->pool + (size_t)i * per_net;
+    s.W = base; s.M = s.W + t->n_w; s.V = s.M + t->n_w;
+    s.stash = s.V + t->n_w;
+    s.loss_curve = s.stash + stash;
+    s.scal = s.loss_curve + curve;
+    t->nets_host.push_back(s);
+    std::fill(w.begin(), w.end(), 0.0);
+    double* w1 = w.data();
+    double* w2 = w1 + (size_t)t->kt1 * NB_HT1 * NB_TILE;
+    double* w3 = w2 + (size_t)NB_HT1 * NB_HT2 * NB_TILE;
+    double* w4 = w3 + (size_t)NB_HT2 * NB_HT3 * NB_TILE;
+    const double* const* c = coefs + 4 * i;
+    const double* const* b = icpts + 4 * i;
+    for (int k = 0; k < n_dim; ++k)
+      for (int h = 0; h < NB_H1; ++h) put_w(w1, NB_HT1, k, h, c[0][(size_t)k * NB_H1 + h]);
+    for (int h = 0; h < NB_H1; ++h) put_w(w1, NB_HT1, n_dim, h, b[0][h]);
+    for (int k = 0; k < NB_H1; ++k)
+      for (int h = 0; h < NB_H2; ++h) put_w(w2, NB_HT2, k, h, c[1][(size_t)k * NB_H2 + h]);
+    for (int h = 0; h < NB_H2; ++h) put_w(w2, NB_HT2, NB_H1, h, b[1][h]);
+    for (int k = 0; k < NB_H2; ++k)
+      for (int h = 0; h < NB_H3; ++h) put_w(w3, NB_HT3, k, h, c[2][(size_t)k * NB_H3 + h]);
+    for (int h = 0; h < NB_H3; ++h) put_w(w3, NB_HT3, NB_H2, h, b[2][h]);
+    for (int k = 0; k < NB_H3; ++k) put_w(w4, 1, k, 0, c[3][k]);
+    put_w(w4, 1, NB_H3, 0, b[3][0]);
+    e = hipMemcpy(s.W, w.data(), (size_t)t->n_w * sizeof(double),
+                  hipMemcpyHostToDevice);
+    const double scal0[8] = {0.0, INFINITY, 0.0, 0.0, 0.0, 0, 0, 0};
+    if (e == hipSuccess)
+      e = hipMemcpy(s.scal, scal0, sizeof scal0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) break;
+  }
+  if (e == hipSuccess)
+    e = hipMemcpy(t->nets_dev, t->nets_host.data(),
+                  n_networks * sizeof(NetState), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    nb_set_error("trainer upload failed: %s", hipGetErrorString(e));
+    nb_trainer_destroy(t);
+    return NB_ERR_HIP;
+  }
+  *out = t;
+  return NB_OK;
+}
+
+int nb_trainer_set_hparams(nb_trainer* t, double lr, double beta1,
+                           double beta2, double epsilon, int32_t batch,
+                           int32_t max_iter, int32_t n_iter_no_change,
+                           double tol) {
+  if (batch < 1 || batch > 200 || max_iter < 1 || max_iter > 10000) {
+    nb_set_error("trainer: batch must be 1..200 and max_iter 1..10000");
+    return NB_ERR_UNSUPPORTED;
+  }
+  t->lr = lr; t->b1 = beta1; t->b2 = beta2; t->eps = epsilon;
+  t->batch = batch; t->max_iter = max_iter;
+  t->n_iter_no_change = n_iter_no_change; t->tol = tol;
+  return NB_OK;
+}
+
+int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
+                   int32_t* status_host, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TrainArgs a;
+  a.nets = t->nets_dev; a.X = t->X; a.y = t->y; a.perm = perm_dev;
+  a.n = t->n; a.n_dim = t->n_dim; a.kt1 = t->kt1; a.n_epochs = n_epochs;
+  a.max_iter = t->max_iter; a.n_iter_no_change = t->n_iter_no_change;
+  a.batch = (int)((t->n < t->batch) ? t->n : t->batch);
+  a.tol = t->tol; a.lr = t->lr; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps;
+  const dim3 grid(t->E), block(64 * NWAVE);
+  switch (t->dt) {
+    case 1: hipLaunchKernelGGL(nb_train_kernel<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(nb_train_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(nb_train_kernel<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(nb_train_kernel<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(nb_train_kernel<5>, grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL(nb_train_kernel<6>, grid, block, 0, s, a); break;
+    case 7: hipLaunchKernelGGL(nb_train_kernel<7>, grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL(nb_train_kernel<8>, grid, block, 0, s, a); break;
+    default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
+  }
+  NB_HIP_CHECK(hipGetLastError());
+  if (status_host != nullptr) {
+    NB_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < t->E; ++i) {
+      double scal[8];
+      NB_HIP_CHECK(hipMemcpy(scal, t->nets_host[i].scal, sizeof scal,
+                             hipMemcpyDeviceToHost));
+      const int n_iter = (int)scal[3];
+      status_host[i] = (scal[4] != 0.0) ? -n_iter : n_iter;
+    }
+  }
+  return NB_OK;
+}
+
+int nb_trainer_loss_curve(nb_trainer* t, int32_t net, double* out_host,
+                          int32_t max_len) {
+  if (net < 0 || net >= t->E) { nb_set_error("bad net index"); return NB_ERR_ARG; }
+  const int len = max_len < t->max_iter ? max_len : t->max_iter;
+  NB_HIP_CHECK(hipMemcpy(out_host, t->nets_host[net].loss_curve,
+                         (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
+  return NB_OK;
+}
+
+int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs,
+                       double* const* icpts) {
+  if (net < 0 || net >= t->E) { nb_set_error("bad net index"); return NB_ERR_ARG; }
+  std::vector<double> w((size_t)t->n_w);
+  NB_HIP_CHECK(hipMemcpy(w.data(), t->nets_host[net].W,
+                         (size_t)t->n_w * sizeof(double), hipMemcpyDeviceToHost));
+  const int D = t->n_dim;
+  const double* w1 = w.data();
+  const double* w2 = w1 + (size_t)t->kt1 * NB_HT1 * NB_TILE;
+  const double* w3 = w2 + (size_t)NB_HT1 * NB_HT2 * NB_TILE;
+  const double* w4 = w3 + (size_t)NB_HT2 * NB_HT3 * NB_TILE;
+  for (int k = 0; k < D; ++k)
+    for (int h = 0; h < NB_H1; ++h) coefs[0][(size_t)k * NB_H1 + h] = get_w(w1, NB_HT1, k, h);
+  for (int h = 0; h < NB_H1; ++h) icpts[0][h] = get_w(w1, NB_HT1, D, h);
+  for (int k = 0; k < NB_H1; ++k)
+    for (int h = 0; h < NB_H2; ++h) coefs[1][(size_t)k * NB_H2 + h] = get_w(w2, NB_HT2, k, h);
+  for (int h = 0; h < NB_H2; ++h) icpts[1][h] = get_w(w2, NB_HT2, NB_H1, h);
+  for (int k = 0; k < NB_H2; ++k)
+    for (int h = 0; h < NB_H3; ++h) coefs[2][(size_t)k * NB_H3 + h] = get_w(w3, NB_HT3, k, h);
+  for (int h = 0; h < NB_H3; ++h) icpts[2][h] = get_w(w3, NB_HT3, NB_H2, h);
+  for (int k = 0; k < NB_H3; ++k) coefs[3][k] = get_w(w4, 1, k, 0);
+  icpts[3][0] = get_w(w4, 1, NB_H3, 0);
+  return NB_OK;
+}
+
+int nb_trainer_destroy(nb_trainer* t) {
+  if (t == nullptr) return NB_OK;
+  if (t->pool) (void)hipFree(t->pool);
+  if (t->nets_dev) (void)hipFree(t->nets_dev);
+  delete t;
+  return NB_OK;
+}
+
+}  // extern "C"

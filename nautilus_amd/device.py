@@ -1,0 +1,276 @@
+"""Handles of bounds living in HBM and the launch wrappers around the C ABI.
+
+torch is used for device memory and streams only; every computation on the
+path runs in the hand-written HIP kernels of ``libnautilus_hip.so``.
+"""
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def as_device_points(x, n_dim=None):
+    """numpy / torch (n, D) -> contiguous float64 cuda tensor."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device='cuda', dtype=torch.float64)
+    else:
+        t = torch.from_numpy(_f64(x)).cuda()
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    t = t.contiguous()
+    if n_dim is not None and t.shape[1] != n_dim:
+        raise ValueError('points have %d columns, bound has n_dim=%d' %
+                         (t.shape[1], n_dim))
+    return t
+
+
+def member(c=None, B=None, B_inv=None, idx_ell=None, free_dims=False):
+    """Description of one union member (Ellipsoid / Mixture / cube)."""
+    if c is None:
+        return dict(n_ell=0, c=np.zeros(0), B=np.zeros((0, 0)),
+                    B_inv=np.zeros((0, 0)), idx_ell=None, free_dims=free_dims)
+    c = _f64(c)
+    B = _f64(B)
+    B_inv = _f64(np.linalg.inv(B) if B_inv is None else B_inv)
+    # exact zeros above the diagonal (the kernels exploit the triangle)
+    B_inv = np.tril(B_inv)
+    return dict(n_ell=len(c), c=c, B=np.tril(B), B_inv=B_inv,
+                idx_ell=None if idx_ell is None else
+                np.ascontiguousarray(idx_ell, dtype=np.int32),
+                free_dims=free_dims)
+
+
+class DeviceBound:
+    """One bound (any type of the reference) uploaded to HBM."""
+
+    def __init__(self, n_dim, members=(), log_v_all=None, unit_cube=False,
+                 neural=()):
+        lib = _lib.load()
+        self.n_dim = int(n_dim)
+        self.n_members = len(members)
+        self.n_neural = len(neural)
+        keep = []          # keep numpy buffers alive during the call
+
+        def fill_member(md, src):
+            md.n_ell = src['n_ell']
+            md.free_dims = 1 if src.get('free_dims') else 0
+            if src['idx_ell'] is not None:
+                keep.append(src['idx_ell'])
+                md.idx_ell = src['idx_ell'].ctypes.data_as(_lib.c_int32_p)
+            else:
+                md.idx_ell = None
+            for key in ('c', 'B', 'B_inv'):
+                arr = _f64(src[key])
+                keep.append(arr)
+                setattr(md, key, _dp(arr))
+
+        m_arr = (_lib.MemberDesc * max(1, self.n_members))()
+        for md, src in zip(m_arr, members):
+            fill_member(md, src)
+        n_arr = (_lib.NeuralDesc * max(1, self.n_neural))()
+        self.n_networks = 0
+        for nd, src in zip(n_arr, neural):
+            fill_member(nd.ellipsoid, src['ellipsoid'])
+            nd.score_predict_min = float(src.get('score_predict_min', 0.0))
+            mlp = src.get('mlp')
+            if mlp is None:
+                nd.mlp = None
+                continue
+            e = len(mlp['nets'])
+            self.n_networks = e
+            md = _lib.MlpDesc()
+            md.n_networks = e
+            mean, scale = _f64(mlp['mean']), _f64(mlp['scale'])
+            keep += [mean, scale]
+            md.mean, md.scale = _dp(mean), _dp(scale)
+            cp = (_lib.c_double_p * (4 * e))()
+            ip = (_lib.c_double_p * (4 * e))()
+            for i, (coefs, intercepts) in enumerate(mlp['nets']):
+                for k in range(4):
+                    w, b = _f64(coefs[k]), _f64(intercepts[k])
+                    keep += [w, b]
+                    cp[4 * i + k], ip[4 * i + k] = _dp(w), _dp(b)
+            md.coefs, md.intercepts = cp, ip
+            keep += [md, cp, ip]
+            nd.mlp = C.pointer(md)
+
+        desc = _lib.BoundDesc()
+        desc.n_dim = self.n_dim
+        desc.n_members = self.n_members
+        desc.members = m_arr
+        lv = _f64(np.zeros(self.n_members) if log_v_all is None
+                  else log_v_all)
+        desc.log_v_all = _dp(lv)
+        desc.unit_cube = 1 if unit_cube else 0
+        desc.n_neural = self.n_neural
+        desc.neural = n_arr
+        handle = C.c_void_p()
+        _lib.check(lib.nb_bound_create(C.byref(desc), C.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        del keep
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.nb_bound_destroy(h)
+            self._h = None
+
+    @property
+    def nbytes(self):
+        return self._lib.nb_bound_nbytes(self._h)
+
+    # -- queries ---------------------------------------------------------
+    def contains(self, x):
+        x = as_device_points(x, self.n_dim)
+        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+        _lib.check(self._lib.nb_contains(self._h, _ptr(x), x.shape[0],
+                                         _ptr(mask), _stream()))
+        return mask.bool()
+
+    def contains_stream(self, x):
+        x = as_device_points(x, self.n_dim)
+        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+        _lib.check(self._lib.nb_ellipsoid_contains_stream(
+            self._h, _ptr(x), x.shape[0], _ptr(mask), _stream()))
+        return mask.bool()
+
+    def member_count(self, x):
+        x = as_device_points(x, self.n_dim)
+        cnt = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+        _lib.check(self._lib.nb_member_count(self._h, _ptr(x), x.shape[0],
+                                             _ptr(cnt), _stream()))
+        return cnt
+
+    def neural_score(self, x):
+        """(r2, score) of neural bound 0."""
+        x = as_device_points(x, self.n_dim)
+        out = torch.empty((x.shape[0], 2), dtype=torch.float64, device='cuda')
+        _lib.check(self._lib.nb_neural_score(self._h, _ptr(x), x.shape[0],
+                                             _ptr(out), _stream()))
+        return out[:, 0], out[:, 1]
+
+    def propose(self, seed, offset, n):
+        x = torch.empty((n, self.n_dim), dtype=torch.float64, device='cuda')
+        _lib.check(self._lib.nb_propose(self._h, seed, offset, n, _ptr(x),
+                                        _stream()))
+        return x
+
+    def accept(self, seed, offset, x):
+        flags = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+        _lib.check(self._lib.nb_accept(self._h, seed, offset, _ptr(x),
+                                       x.shape[0], _ptr(flags), _stream()))
+        return flags
+
+    def sample_launch(self, seed, offset, n_draw):
+        """One launch of the device ``sample`` pipeline: draw, accept,
+        compact.  Returns (points, counters) with counters = int64 tensor
+        [n kept by the outer union, n kept in total] still on the device."""
+        x = self.propose(seed, offset, n_draw)
+        flags = self.accept(seed, offset, x)
+        out, counts, _ = compact_rows(x, flags, 2)
+        return out, counts
+
+
+class DeviceBoundList:
+    """Device array of bounds for multi-bound queries."""
+
+    def __init__(self, bounds):
+        lib = _lib.load()
+        self.bounds = list(bounds)
+        arr = (C.c_void_p * max(1, len(self.bounds)))(
+            *[b._h for b in self.bounds])
+        handle = C.c_void_p()
+        _lib.check(lib.nb_boundlist_create(arr, len(self.bounds),
+                                           C.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        self.n_dim = self.bounds[0].n_dim if self.bounds else None
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.nb_boundlist_destroy(h)
+            self._h = None
+
+    def contains_any(self, x):
+        x = as_device_points(x, self.n_dim)
+        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+        _lib.check(self._lib.nb_contains_any(self._h, _ptr(x), x.shape[0],
+                                             _ptr(mask), _stream()))
+        return mask.bool()
+
+    def first_containing(self, x):
+        x = as_device_points(x, self.n_dim)
+        idx = torch.empty(x.shape[0], dtype=torch.int32, device='cuda')
+        _lib.check(self._lib.nb_first_containing(self._h, _ptr(x), x.shape[0],
+                                                 _ptr(idx), _stream()))
+        return idx
+
+
+def compact_rows(x, flags, mask=1, want_index=False):
+    """Stable compaction of the rows of ``x`` with (flags & mask) != 0.
+
+    Returns (rows, counts, src_idx): ``rows`` has x.shape[0] allocated rows of
+    which the first counts[1] are valid; counts is an int64 device tensor
+    [rows with bit0, rows kept]."""
+    lib = _lib.load()
+    n, d = x.shape
+    out = torch.empty_like(x)
+    counts = torch.zeros(2, dtype=torch.int64, device='cuda')
+    scratch = torch.empty(max(16, lib.nb_compact_scratch_bytes(n)),
+                          dtype=torch.uint8, device='cuda')
+    src = (torch.empty(n, dtype=torch.int64, device='cuda')
+           if want_index else None)
+    _lib.check(lib.nb_compact_rows(
+        _ptr(x), _ptr(flags), mask, n, d, _ptr(out),
+        _ptr(src) if src is not None else None, _ptr(counts), _ptr(scratch),
+        _stream()))
+    return out, counts, src
+
+
+def shell_stats(log_l, threshold=-np.inf):
+    """(logsumexp(l), logsumexp(2l), max l, #(l >= threshold)) on the device
+    (nautilus/sampler.py:927-943, 1144)."""
+    lib = _lib.load()
+    n = log_l.shape[0]
+    out = torch.empty(4, dtype=torch.float64, device='cuda')
+    scratch = torch.empty(max(16, lib.nb_shell_stats_scratch_bytes(n)),
+                          dtype=torch.uint8, device='cuda')
+    _lib.check(lib.nb_shell_stats(_ptr(log_l), n, float(threshold), _ptr(out),
+                                  _ptr(scratch), _stream()))
+    return out
+
+
+def philox_uniform(seed, offset, block, tag, n):
+    lib = _lib.load()
+    u = torch.empty((n, 2), dtype=torch.float64, device='cuda')
+    _lib.check(lib.nb_philox_uniform(seed, offset, block, tag, n, _ptr(u),
+                                     _stream()))
+    return u
+
+
+def mfma_f64_peak(iters=20000):
+    lib = _lib.load()
+    out = C.c_double(0.0)
+    _lib.check(lib.nb_mfma_f64_peak(iters, C.byref(out)))
+    return out.value

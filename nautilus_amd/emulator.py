@@ -1,0 +1,251 @@
+"""Likelihood emulator: an ensemble of (100, 50, 20) ReLU MLPs trained and
+evaluated on the MI355X matrix cores.
+
+Mirrors ``nautilus.neural.NeuralNetworkEmulator`` (reference
+nautilus/neural.py:35-187): ``train(x, y, n_networks, neural_network_kwargs,
+pool)`` / ``predict(x)`` / attributes ``mean``, ``scale``,
+``neural_networks``.  The training algorithm is scikit-learn's
+``MLPRegressor.fit`` as the reference configures it (neural.py:79-81); weight
+initialisation and the per-epoch shuffles are drawn on the host from
+``numpy.random.RandomState(i)`` exactly as scikit-learn does, so network ``i``
+sees the same initial weights and minibatch order as in the reference; all
+arithmetic (forward, backprop, Adam) runs in ``nb_mlp_train.hip``.
+"""
+
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, device
+
+HIDDEN = (100, 50, 20)
+EPOCH_CHUNK = 16     # epochs per kernel launch (host prepares the next chunk
+                     # of shuffles while the GPU trains)
+
+
+class Network:
+    """Weights of one trained network in scikit-learn layout."""
+
+    def __init__(self, coefs, intercepts, n_iter=0, loss_curve=None):
+        self.coefs_ = coefs
+        self.intercepts_ = intercepts
+        self.n_iter_ = n_iter
+        self.loss_curve_ = [] if loss_curve is None else list(loss_curve)
+        self.n_layers_ = 5
+
+
+def _glorot(n_in, rs):
+    """sklearn/_multilayer_perceptron.py:441-456."""
+    units = [n_in, *HIDDEN, 1]
+    coefs, intercepts = [], []
+    for fan_in, fan_out in zip(units[:-1], units[1:]):
+        bound = np.sqrt(6.0 / (fan_in + fan_out))
+        coefs.append(rs.uniform(-bound, bound, (fan_in, fan_out)))
+        intercepts.append(rs.uniform(-bound, bound, fan_out))
+    return coefs, intercepts
+
+
+def _weight_pointers(nets):
+    e = len(nets)
+    cp = (_lib.c_double_p * (4 * e))()
+    ip = (_lib.c_double_p * (4 * e))()
+    keep = []
+    for i, (coefs, intercepts) in enumerate(nets):
+        for k in range(4):
+            w = np.ascontiguousarray(coefs[k], dtype=np.float64)
+            b = np.ascontiguousarray(intercepts[k], dtype=np.float64)
+            keep += [w, b]
+            cp[4 * i + k] = w.ctypes.data_as(_lib.c_double_p)
+            ip[4 * i + k] = b.ctypes.data_as(_lib.c_double_p)
+    return cp, ip, keep
+
+
+class Trainer:
+    """Thin object wrapper of the ``nb_trainer_*`` C ABI."""
+
+    def __init__(self, x_dev, y_dev, init_nets, hparams=None):
+        lib = _lib.load()
+        self._lib = lib
+        self.x, self.y = x_dev, y_dev        # keep device buffers alive
+        self.n, self.n_dim = x_dev.shape
+        self.e = len(init_nets)
+        cp, ip, keep = _weight_pointers(init_nets)
+        h = C.c_void_p()
+        _lib.check(lib.nb_trainer_create(
+            self.n_dim, self.e, self.n, C.c_void_p(x_dev.data_ptr()),
+            C.c_void_p(y_dev.data_ptr()), cp, ip, C.byref(h)))
+        self._h = h
+        if hparams:
+            hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                      batch=200, max_iter=10000, n_iter_no_change=10, tol=0.0)
+            hp.update(hparams)
+            _lib.check(lib.nb_trainer_set_hparams(
+                h, hp['lr'], hp['beta1'], hp['beta2'], hp['epsilon'],
+                hp['batch'], hp['max_iter'], hp['n_iter_no_change'],
+                hp['tol']))
+
+    def run(self, perms, sync=True):
+        """perms: int32 array (E, n_epochs, n).  Returns per-network status
+        (n_iter, negative once stopped) if sync else None."""
+        perms_dev = torch.from_numpy(
+            np.ascontiguousarray(perms, dtype=np.int32)).cuda()
+        status = (C.c_int32 * self.e)()
+        _lib.check(self._lib.nb_trainer_run(
+            self._h, C.c_void_p(perms_dev.data_ptr()), perms.shape[1],
+            status if sync else None,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._perms = perms_dev
+        return np.array(status[:]) if sync else None
+
+    def loss_curve(self, net, n):
+        out = np.zeros(max(1, n))
+        _lib.check(self._lib.nb_trainer_loss_curve(
+            self._h, net, out.ctypes.data_as(_lib.c_double_p), len(out)))
+        return out[:n]
+
+    def weights(self, net):
+        units = [self.n_dim, *HIDDEN, 1]
+        coefs = [np.zeros((a, b)) for a, b in zip(units[:-1], units[1:])]
+        intercepts = [np.zeros(b) for b in units[1:]]
+        cp = (_lib.c_double_p * 4)(*[w.ctypes.data_as(_lib.c_double_p)
+                                      for w in coefs])
+        ip = (_lib.c_double_p * 4)(*[w.ctypes.data_as(_lib.c_double_p)
+                                      for w in intercepts])
+        _lib.check(self._lib.nb_trainer_weights(self._h, net, cp, ip))
+        return coefs, intercepts
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.nb_trainer_destroy(h)
+            self._h = None
+
+
+def _hparams_from_kwargs(kwargs):
+    """Translate MLPRegressor keyword arguments (neural.py:79-88)."""
+    known = dict(learning_rate_init='lr', beta_1='beta1', beta_2='beta2',
+                 epsilon='epsilon', batch_size='batch', max_iter='max_iter',
+                 n_iter_no_change='n_iter_no_change', tol='tol')
+    fixed = dict(hidden_layer_sizes=HIDDEN, alpha=0, activation='relu',
+                 solver='adam', shuffle=True, early_stopping=False)
+    hp = {}
+    for key, val in kwargs.items():
+        if key == 'random_state':
+            warnings.warn("The 'random_state' keyword argument passed to the"
+                          " neural network is ignored.", Warning, stacklevel=3)
+        elif key in known:
+            hp[known[key]] = val
+        elif key in fixed:
+            if (tuple(val) if key == 'hidden_layer_sizes' else val) != \
+                    fixed[key]:
+                raise NotImplementedError(
+                    'nautilus_amd trains the reference default architecture '
+                    'only; %s=%r is not supported on the device' % (key, val))
+        else:
+            raise NotImplementedError(
+                'MLPRegressor option %r is not supported on the device' % key)
+    return hp
+
+
+class NeuralNetworkEmulator:
+    """Drop-in for ``nautilus.neural.NeuralNetworkEmulator``."""
+
+    @classmethod
+    def train(cls, x, y, n_networks=4, neural_network_kwargs={}, pool=None):
+        """neural.py:50-98.  ``x`` / ``y`` may be numpy arrays or cuda
+        tensors; ``pool`` is accepted for API compatibility (the networks
+        train concurrently on the GPU, one workgroup each)."""
+        emu = cls()
+        xt = device.as_device_points(x)
+        yt = (y if isinstance(y, torch.Tensor) else
+              torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64))
+              ).to('cuda', torch.float64).contiguous()
+        mean = xt.mean(dim=0)
+        scale = xt.std(dim=0, unbiased=False)
+        emu.mean = mean.cpu().numpy()
+        emu.scale = scale.cpu().numpy()
+        xs = ((xt - mean) / scale).contiguous()
+        hp = _hparams_from_kwargs(dict(neural_network_kwargs))
+        emu.neural_networks, emu.trainer_stats = train_networks(
+            xs, yt, list(range(n_networks)), hp)
+        emu._dev = None
+        return emu
+
+    @classmethod
+    def from_weights(cls, mean, scale, networks):
+        emu = cls()
+        emu.mean = np.asarray(mean, float)
+        emu.scale = np.asarray(scale, float)
+        emu.neural_networks = list(networks)
+        emu._dev = None
+        return emu
+
+    def mlp_desc(self):
+        return dict(mean=self.mean, scale=self.scale,
+                    nets=[(n.coefs_, n.intercepts_)
+                          for n in self.neural_networks])
+
+    def predict_device(self, x):
+        if self._dev is None:
+            d = len(self.mean)
+            ident = device.member(np.zeros(d), np.eye(d), np.eye(d))
+            self._dev = device.DeviceBound(d, [], None, False, [dict(
+                ellipsoid=ident, score_predict_min=0.0, mlp=self.mlp_desc())])
+        return self._dev.neural_score(x)[1]
+
+    def predict(self, x):
+        """neural.py:100-116; numpy in -> numpy out, tensor in -> tensor."""
+        out = self.predict_device(x)
+        return out if isinstance(x, torch.Tensor) else out.cpu().numpy()
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_dev'] = None
+        return state
+
+
+def train_networks(xs, y, seeds, hparams=None, permutations=None,
+                   init=None, max_epochs=None):
+    """Train ``len(seeds)`` networks on standardised inputs ``xs`` (cuda
+    tensor) concurrently.  ``permutations`` (list over networks of lists of
+    per-epoch orders) and ``init`` override the RandomState draws (tests)."""
+    n, d = xs.shape
+    e = len(seeds)
+    states = [np.random.RandomState(s) for s in seeds]
+    nets0 = [_glorot(d, rs) for rs in states]
+    if init is not None:
+        nets0 = init
+    trainer = Trainer(xs, y, nets0, hparams)
+    max_iter = (hparams or {}).get('max_iter', 10000)
+    if max_epochs is not None:
+        max_iter = min(max_iter, max_epochs)
+    orders = [np.arange(n) for _ in range(e)]
+    status = np.zeros(e, dtype=int)
+    done_epochs = 0
+    while done_epochs < max_iter and np.any(status >= 0):
+        chunk = min(EPOCH_CHUNK, max_iter - done_epochs)
+        perms = np.zeros((e, chunk, n), dtype=np.int32)
+        for i in range(e):
+            for ep in range(chunk):
+                if permutations is not None:
+                    orders[i] = np.asarray(
+                        permutations[i][done_epochs + ep])
+                elif status[i] >= 0:
+                    # sklearn.utils.shuffle: permutations compose
+                    # (_multilayer_perceptron.py:700-704)
+                    idx = np.arange(n)
+                    states[i].shuffle(idx)
+                    orders[i] = orders[i][idx]
+                perms[i, ep] = orders[i]
+        status = trainer.run(perms)
+        done_epochs += chunk
+    networks = []
+    for i in range(e):
+        n_iter = abs(int(status[i]))
+        coefs, intercepts = trainer.weights(i)
+        networks.append(Network(coefs, intercepts, n_iter,
+                                trainer.loss_curve(i, n_iter)))
+    stats = dict(n_iter=[abs(int(s)) for s in status], n_rows=n)
+    return networks, stats

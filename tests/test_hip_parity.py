@@ -1,0 +1,367 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the
+reference's golden vectors.  GPU only.
+
+Tolerances: index / counter / mask work is bit-exact except for points whose
+decision value lies within 1e-11 of the decision threshold (fp64 sums are
+associated differently on the matrix cores than in numpy/BLAS); floating
+point outputs agree to 1e-11 relative."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import upload, near_boundary
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nautilus_amd import device
+    return device
+
+
+def _ell_from_golden(g):
+    from oracle import bounds_oracle as bo
+    return bo.OEllipsoid.from_params(g['c'], g['B'], g['B_inv'], g['A'])
+
+
+def test_philox_matches_oracle(dev):
+    from oracle import philox
+    for seed, off, block, tag in [(0, 0, 0, 0), (2**40 + 17, 2**33 + 5, 3, 1),
+                                  (12345, 999, 7, 2)]:
+        u = dev.philox_uniform(seed, off, block, tag, 4096).cpu().numpy()
+        g = np.uint64(off) + np.arange(4096, dtype=np.uint64)
+        u0, u1 = philox.uniform_pair(seed, g, block, tag)
+        assert np.array_equal(u[:, 0], u0) and np.array_equal(u[:, 1], u1)
+
+
+@pytest.mark.parametrize('d', [3, 20, 50])
+def test_ellipsoid_contains_golden(dev, d):
+    g = load_golden('ellipsoid_D%d' % d)
+    ell = _ell_from_golden(g)
+    b = upload(ell)
+    for fn in (b.contains, b.contains_stream):
+        mask = fn(g['test']).cpu().numpy()
+        diff = mask != g['contains']
+        assert not np.any(diff & ~near_boundary(g['r2'], 1.0, TOL))
+    assert 0 < g['contains'].sum() < len(g['contains'])
+    # the ellipsoid-frame radius through the neural-bound path
+    from nautilus_amd import device
+    nb = device.DeviceBound(d, [], None, False, [dict(
+        ellipsoid=device.member(g['c'], g['B'], g['B_inv']))])
+    r2, _ = nb.neural_score(g['test'])
+    assert np.allclose(r2.cpu().numpy(), g['r2'], rtol=TOL, atol=0)
+
+
+def test_ellipsoid_stream_large(dev):
+    """Full-size streaming run: 2^22 points at D = 50 agree with the
+    matrix-core path and with the oracle on a subsample."""
+    import torch
+    g = load_golden('ellipsoid_D50')
+    ell = _ell_from_golden(g)
+    b = upload(ell)
+    n = 1 << 22
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.rand((n, 50), dtype=torch.float64, device='cuda',
+                   generator=gen)
+    x[::3] = torch.from_numpy(ell.c).cuda() + 0.12 * (x[::3] - 0.5)
+    m1 = b.contains_stream(x)
+    m2 = b.contains(x)
+    assert int((m1 != m2).sum()) <= 2
+    sub = x[:20000].cpu().numpy()
+    r2 = np.sum(ell.transform(sub)**2, axis=-1)
+    bad = (m1[:20000].cpu().numpy() != (r2 < 1)) & ~near_boundary(r2, 1, TOL)
+    assert not np.any(bad)
+    assert 0.05 < float(m1.double().mean()) < 0.95
+    # ragged sizes
+    for k in (1, 63, 64, 65, 1000):
+        assert torch.equal(b.contains_stream(x[:k]), m1[:k])
+
+
+def test_mixture_contains_golden(dev):
+    from oracle import bounds_oracle as bo
+    g = load_golden('mixture_D6')
+    ell = bo.OEllipsoid.from_params(g['c'], g['B'], g['B_inv'], g['A'])
+    mix = bo.OMixture.from_params(g['dim_cube'], ell)
+    mask = upload(mix).contains(g['test']).cpu().numpy()
+    assert np.array_equal(mask, g['contains'])
+    assert np.array_equal(mix.contains(g['test']), g['contains'])
+
+
+def _union_from_golden(g, mixture):
+    from oracle import bounds_oracle as bo
+    members = []
+    for i in range(int(g['K'])):
+        ell = None
+        if 'B_%d' % i in g:
+            ell = bo.OEllipsoid.from_params(g['c_%d' % i], g['B_%d' % i],
+                                            g['B_inv_%d' % i], g['A_%d' % i])
+        members.append(bo.OMixture.from_params(g['dim_cube_%d' % i], ell)
+                       if mixture else ell)
+    u = bo.OUnion.from_members(members, unit=bool(g['unit']))
+    u.log_v_all = g['log_v_all']
+    return u
+
+
+@pytest.mark.parametrize('name,mixture', [('union_K2_D3', False),
+                                          ('union_K4_D8', True)])
+def test_union_golden(dev, name, mixture):
+    g = load_golden(name)
+    u = _union_from_golden(g, mixture)
+    b = upload(u)
+    assert np.array_equal(b.member_count(g['test']).cpu().numpy(),
+                          g['counts'])
+    assert np.array_equal(b.contains(g['test']).cpu().numpy(), g['contains'])
+    # the reference's own accepted samples lie inside (union.py:291-327)
+    assert bool(b.contains(g['sample']).all())
+
+
+@pytest.mark.parametrize('name,mixture', [('union_K2_D3', False),
+                                          ('union_K4_D8', True)])
+def test_union_proposals_match_oracle(dev, name, mixture):
+    """Device Union.sample == oracle Philox tier, proposal by proposal."""
+    from oracle import philox
+    g = load_golden(name)
+    u = _union_from_golden(g, mixture)
+    b = upload(u)
+    seed, offset, n = 77, 123456789, 20000
+    x = b.propose(seed, offset, n)
+    flags = b.accept(seed, offset, x).cpu().numpy()
+    x_o, keep_o, k_o = philox.union_propose(u, seed, offset, n)
+    assert np.allclose(x.cpu().numpy(), x_o, rtol=0, atol=1e-12)
+    assert np.array_equal((flags & 1).astype(bool), keep_o)
+    assert 0 < keep_o.sum() < n
+    # compaction keeps proposal order; counters are exact
+    pts, counts, src = dev.compact_rows(x, __import__('torch').from_numpy(
+        flags).cuda(), 1, want_index=True)
+    c = counts.cpu().numpy()
+    assert c[0] == c[1] == keep_o.sum()
+    assert np.array_equal(src[:c[1]].cpu().numpy(), np.flatnonzero(keep_o))
+    assert np.allclose(pts[:c[1]].cpu().numpy(), x_o[keep_o], rtol=0,
+                       atol=1e-12)
+    # statistical: survivors are uniform over the union -> volume estimate
+    log_v = np.logaddexp.reduce(u.log_v_all) + np.log(keep_o.mean())
+    assert abs(log_v - float(g['log_v'])) < 0.1
+
+
+def test_unit_cube(dev):
+    from oracle import bounds_oracle as bo
+    from oracle import philox
+    cube = bo.OCube(5)
+    b = upload(cube)
+    x = b.propose(3, 0, 5000)
+    xo, keep, _ = philox.union_propose(
+        bo.OUnion.from_members([bo.OMixture.from_params(np.ones(5, bool),
+                                                        None)]), 3, 0, 5000)
+    assert np.array_equal(x.cpu().numpy(), xo)
+    assert bool(b.contains(x).all())
+    pts = np.array([[0.5] * 5, [1.0] + [0.5] * 4, [-1e-9] + [0.5] * 4,
+                    [0.0] * 5])
+    assert b.contains(pts).cpu().numpy().tolist() == [True, False, False,
+                                                     True]
+
+
+@pytest.fixture(scope='module')
+def neural_d4():
+    from oracle import bounds_oracle as bo
+    g = load_golden('neuralbound_D4')
+    nb = bo.ONeural.build(g['points'], g['log_l'], float(g['log_l_min']),
+                          n_networks=1, rng=np.random.default_rng(0))
+    return g, nb
+
+
+def test_neural_bound_golden(dev, neural_d4):
+    g, nb = neural_d4
+    b = upload(nb)
+    r2, score = b.neural_score(g['test'])
+    r2_o = np.sum(nb.outer_bound.transform(g['test'])**2, axis=-1)
+    assert np.allclose(r2.cpu().numpy(), r2_o, rtol=TOL)
+    assert np.allclose(score.cpu().numpy(), g['score'], rtol=0, atol=1e-10)
+    mask = b.contains(g['test']).cpu().numpy()
+    edge = near_boundary(g['score'], nb.score_predict_min - 1e-9, 1e-10) | \
+        near_boundary(r2_o, 1.0, TOL)
+    assert not np.any((mask != g['contains']) & ~edge)
+    assert 0 < g['contains'].sum() < len(g['contains'])
+
+
+@pytest.mark.parametrize('d,e', [(5, 1), (20, 2)])
+def test_emulator_predict_golden(dev, d, e):
+    """NeuralNetworkEmulator.predict (neural.py:100-116) on the matrix cores
+    against sklearn's own predictions."""
+    from nautilus_amd import device
+    g = load_golden('emulator_D%d_E%d' % (d, e))
+    nets = [([g['coef_%d_%d' % (i, k)] for k in range(4)],
+             [g['intercept_%d_%d' % (i, k)] for k in range(4)])
+            for i in range(e)]
+    ident = device.member(np.zeros(d), np.eye(d), np.eye(d))
+    b = device.DeviceBound(d, [], None, False, [dict(
+        ellipsoid=ident, score_predict_min=0.0,
+        mlp=dict(mean=g['mean'], scale=g['scale'], nets=nets))])
+    _, score = b.neural_score(g['test'])
+    assert np.allclose(score.cpu().numpy(), g['predict'], rtol=0, atol=1e-11)
+
+
+@pytest.fixture(scope='module')
+def nautilus_d4():
+    from oracle import bounds_oracle as bo
+    g = load_golden('nautilusbound_D4')
+    b = bo.ONautilus.build(g['points'], g['log_l'], float(g['log_l_min']),
+                           float(g['log_v_target']), n_networks=1,
+                           rng=np.random.default_rng(0))
+    return g, b
+
+
+def test_nautilus_bound_contains_and_sample(dev, nautilus_d4):
+    from oracle import philox
+    g, ob = nautilus_d4
+    b = upload(ob)
+    mask = b.contains(g['test']).cpu().numpy()
+    assert (mask != g['contains']).sum() <= 1
+    assert bool(b.contains(g['sample']).all())
+    seed, offset, n = 5, 10**12, 30000
+    pts, counts = b.sample_launch(seed, offset, n)
+    c = counts.cpu().numpy()
+    pts_o, cnt_o = philox.nautilus_sample(ob, seed, offset, n)
+    assert abs(int(c[0]) - int(cnt_o[2])) <= 1
+    assert abs(int(c[1]) - len(pts_o)) <= 2
+    if int(c[1]) == len(pts_o):
+        assert np.allclose(pts[:c[1]].cpu().numpy(), pts_o, rtol=0,
+                           atol=1e-12)
+    # the MC volume agrees with the reference's estimate (nautilus.py:257-261)
+    log_v = (np.logaddexp.reduce(ob.outer_bound.log_v_all) +
+             np.log(c[1] / n))
+    assert abs(log_v - float(g['log_v'])) < 0.1
+
+
+def test_shell_exclusion_and_association(dev, nautilus_d4, neural_d4):
+    """sampler.py:797-798 and 1213-1219 over a list of nested bounds."""
+    import torch
+    from oracle import bounds_oracle as bo
+    g, ob = nautilus_d4
+    # three nested bounds: the golden one and two shrunken ellipsoids
+    c = 0.5 * np.ones(4)
+    e1 = bo.OEllipsoid.from_params(c, 0.2 * np.eye(4))
+    e2 = bo.OEllipsoid.from_params(c + 0.05, 0.1 * np.eye(4))
+    obs = [ob, e1, e2]
+    devs = [upload(o) for o in obs]
+    x = np.random.default_rng(4).random((5000, 4))
+    contains = np.array([o.contains(x) for o in obs])
+    lst = dev.DeviceBoundList(devs)
+    assert np.array_equal(lst.contains_any(x).cpu().numpy(),
+                          contains.any(axis=0))
+    rev = dev.DeviceBoundList(devs[::-1])
+    idx = rev.first_containing(x).cpu().numpy()
+    want = np.full(len(x), -1)
+    for i in range(3):                   # highest index wins
+        want[contains[i]] = 2 - i
+    want_first = np.full(len(x), -1)
+    for pos, i in enumerate([2, 1, 0]):
+        sel = contains[i] & (want_first < 0)
+        want_first[sel] = pos
+    assert np.array_equal(idx, want_first)
+    assert np.array_equal(dev.DeviceBoundList([]).contains_any(
+        torch.from_numpy(x).cuda()).cpu().numpy(), np.zeros(len(x), bool))
+
+
+def test_compaction_edge_cases(dev):
+    import torch
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    for n, d in [(1, 3), (2047, 5), (2048, 50), (2049, 7), (100000, 20)]:
+        x = torch.rand((n, d), dtype=torch.float64, device='cuda',
+                       generator=gen)
+        for p in (0.0, 0.01, 0.5, 1.0):
+            flags = (torch.rand(n, device='cuda', generator=gen) < p).to(
+                torch.uint8) * 3
+            out, counts, src = dev.compact_rows(x, flags, 2, want_index=True)
+            k = int(counts[1])
+            keep = flags.bool()
+            assert k == int(keep.sum()) == int(counts[0])
+            assert torch.equal(out[:k], x[keep])
+            assert torch.equal(src[:k], torch.nonzero(keep).flatten())
+
+
+def test_shell_stats_match_reference(dev):
+    import torch
+    from scipy.special import logsumexp
+    g = load_golden('shellstats')
+    for i in range(len(g['shell_n'])):
+        ll = g['log_l_%d' % i]
+        out = dev.shell_stats(torch.from_numpy(ll).cuda(),
+                              float(np.median(ll))).cpu().numpy()
+        assert np.isclose(out[0], logsumexp(ll), rtol=1e-13, atol=1e-13)
+        assert np.isclose(out[1], logsumexp(2 * ll), rtol=1e-13, atol=1e-13)
+        assert out[2] == ll.max()
+        assert out[3] == np.sum(ll >= np.median(ll))
+        n_eff = np.exp(2 * out[0] - out[1])
+        assert np.isclose(n_eff, g['shell_n_eff'][i], rtol=1e-11)
+    ninf = torch.full((100,), -np.inf, dtype=torch.float64, device='cuda')
+    out = dev.shell_stats(ninf).cpu().numpy()
+    assert out[0] == -np.inf and out[1] == -np.inf
+    big = np.random.default_rng(0).normal(size=3_000_000) * 30
+    out = dev.shell_stats(torch.from_numpy(big).cuda()).cpu().numpy()
+    assert np.isclose(out[0], logsumexp(big), rtol=1e-12)
+
+
+def test_emulator_training_matches_oracle(dev):
+    """nb_mlp_train.hip against the restated MLPRegressor.fit: same Glorot
+    draw, same minibatch order, fp64 -> the loss curve and the weights track
+    the oracle (differences only from the association of fp64 sums)."""
+    import torch
+    from nautilus_amd import emulator
+    from oracle import mlp_oracle as mo
+    g = load_golden('emulator_D5_E1')
+    x = (g['x'] - g['mean']) / g['scale']
+    y = g['y']
+    n_ep = 6
+    nets, _ = emulator.train_networks(
+        torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), [0, 3],
+        max_epochs=n_ep)
+    for seed, net in zip([0, 3], nets):
+        ref = mo.fit_network(x, y, seed, max_iter=n_ep)
+        assert net.n_iter_ == ref.n_iter == n_ep
+        assert np.allclose(net.loss_curve_, ref.loss_curve, rtol=1e-9, atol=0)
+        for k in range(4):
+            assert np.allclose(net.coefs_[k], ref.coefs[k], rtol=0, atol=1e-8)
+            assert np.allclose(net.intercepts_[k], ref.intercepts[k], rtol=0,
+                               atol=1e-8)
+
+
+def test_emulator_training_ragged_batches(dev):
+    """n not a multiple of 200 and n < 200 (last / only minibatch short)."""
+    import torch
+    from nautilus_amd import emulator
+    from oracle import mlp_oracle as mo
+    rng = np.random.default_rng(9)
+    for n, d in [(437, 20), (90, 3), (1, 2)]:
+        x = rng.normal(size=(n, d))
+        y = rng.random(n)
+        nets, _ = emulator.train_networks(
+            torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), [1],
+            max_epochs=3)
+        ref = mo.fit_network(x, y, 1, max_iter=3)
+        assert np.allclose(nets[0].loss_curve_, ref.loss_curve, rtol=1e-9)
+        assert np.allclose(nets[0].coefs_[0], ref.coefs[0], rtol=0, atol=1e-8)
+
+
+def test_emulator_full_training_quality(dev):
+    """Reference tests/test_neural.py:6-15: RMSE < 0.3 std on the 5-D radial
+    rank target; stopping epoch in the reference's range."""
+    from nautilus_amd.emulator import NeuralNetworkEmulator
+    g = load_golden('emulator_D5_E1')
+    emu = NeuralNetworkEmulator.train(g['x'], g['y'], n_networks=2)
+    assert np.allclose(emu.mean, g['mean']) and np.allclose(emu.scale,
+                                                            g['scale'])
+    pred = emu.predict(g['x'])
+    assert np.sqrt(np.mean((pred - g['y'])**2)) < 0.3 * np.std(g['y'])
+    n_ref = int(g['n_iter_0'])
+    assert 11 <= emu.neural_networks[0].n_iter_ <= 10000
+    assert 0.2 * n_ref <= emu.neural_networks[0].n_iter_ <= 5 * n_ref
+    # early epochs of network 0 follow sklearn's own loss curve
+    assert np.allclose(emu.neural_networks[0].loss_curve_[:5],
+                       g['loss_curve_0'][:5], rtol=1e-6)
