@@ -14,6 +14,7 @@ from scipy.linalg.lapack import dpotrf, dpotri
 from scipy.optimize import minimize
 from scipy.special import gammaln, logsumexp
 from scipy.stats import multivariate_normal, rankdata
+from threadpoolctl import threadpool_limits
 
 from . import mlp_oracle
 
@@ -111,7 +112,8 @@ class OEllipsoid:
         if not points.shape[0] > self.n_dim:
             raise ValueError('Number of points must be larger than number '
                              'dimensions.')
-        self.c, self.A, a_inv = mvee(points)
+        with threadpool_limits(limits=1):               # basic.py:302
+            self.c, self.A, a_inv = mvee(points)
         self.A /= enlarge_per_dim**2.0
         a_inv *= enlarge_per_dim**2.0
         self.B = np.linalg.cholesky(a_inv)

@@ -16,6 +16,7 @@ pinned against ``MLPRegressor.fit`` itself by ``tests/golden/emulator_*.npz``
 """
 
 import numpy as np
+from threadpoolctl import threadpool_limits
 
 HIDDEN = (100, 50, 20)
 
@@ -116,6 +117,7 @@ class Network:
         return forward(x, self.coefs, self.intercepts)[-1].ravel()
 
 
+@threadpool_limits.wrap(limits=1)                       # neural.py:10
 def fit_network(x, y, random_state, max_iter=10000, n_iter_no_change=10,
                 tol=0.0, batch_size=200, lr=1e-2, permutations=None,
                 init=None):

@@ -12,6 +12,7 @@ from time import time
 
 import numpy as np
 from scipy.special import logsumexp
+from threadpoolctl import threadpool_limits
 
 from .bounds_oracle import OCube, ONautilus
 
@@ -221,6 +222,7 @@ class OSampler:
             shell[idx] = i
         return shell
 
+    @threadpool_limits.wrap(limits=1)                   # sampler.py:789
     def sample_shell(self, index, shell_t=None):
         """sampler.py:784-830."""
         n_bound = 0
@@ -304,15 +306,16 @@ class OSampler:
             if np.all(log_l >= log_l_min):
                 ok = False
             else:
-                b = ONautilus.build(
-                    pts, log_l, log_l_min, self.log_v_live,
-                    enlarge_per_dim=self.enlarge_per_dim,
-                    n_points_min=self.n_points_min,
-                    split_threshold=self.split_threshold,
-                    n_networks=self.n_networks,
-                    neural_network_kwargs=self.neural_network_kwargs,
-                    rng=self.rng)
-                b.sample(1000, return_points=False)
+                with threadpool_limits(limits=1):        # sampler.py:1022
+                    b = ONautilus.build(
+                        pts, log_l, log_l_min, self.log_v_live,
+                        enlarge_per_dim=self.enlarge_per_dim,
+                        n_points_min=self.n_points_min,
+                        split_threshold=self.split_threshold,
+                        n_networks=self.n_networks,
+                        neural_network_kwargs=self.neural_network_kwargs,
+                        rng=self.rng)
+                    b.sample(1000, return_points=False)
                 ok = b.log_v < self.bounds[-1].log_v
                 if ok:
                     self.bounds.append(b)

@@ -3,6 +3,12 @@ import sys
 
 import numpy as np
 import pytest
+from threadpoolctl import threadpool_limits
+
+# The reference pins BLAS to one thread in its hot regions (basic.py:302,
+# neural.py:10, sampler.py:789, 1022) and its CI sets OMP_NUM_THREADS=1; the
+# golden vectors were generated that way.  Threaded BLAS re-associates sums.
+threadpool_limits(limits=1)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

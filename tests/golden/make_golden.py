@@ -151,6 +151,23 @@ def emulator_case(d, n, e, seed):
     save('emulator_D%d_E%d' % (d, e), **arrays)
 
 
+def neural_arrays(nb, prefix):
+    """Every parameter of a NeuralBound (bounds/neural.py:10-26)."""
+    out = {prefix + 'c': nb.outer_bound.c, prefix + 'B': nb.outer_bound.B,
+           prefix + 'B_inv': nb.outer_bound.B_inv,
+           prefix + 'A': nb.outer_bound.A,
+           prefix + 'score_predict_min': nb.score_predict_min}
+    if nb.emulator is not None:
+        out[prefix + 'mean'] = nb.emulator.mean
+        out[prefix + 'scale'] = nb.emulator.scale
+        out[prefix + 'n_networks'] = len(nb.emulator.neural_networks)
+        for i, net in enumerate(nb.emulator.neural_networks):
+            for k in range(4):
+                out[prefix + 'coef_%d_%d' % (i, k)] = net.coefs_[k]
+                out[prefix + 'intercept_%d_%d' % (i, k)] = net.intercepts_[k]
+    return out
+
+
 def neural_and_nautilus_case():
     np.random.seed(0)
     pts = np.random.random(size=(500, 4))
@@ -163,7 +180,8 @@ def neural_and_nautilus_case():
          c=nb.outer_bound.c, B=nb.outer_bound.B, B_inv=nb.outer_bound.B_inv,
          score_predict_min=nb.score_predict_min, test=test,
          contains=nb.contains(test),
-         score=nb.emulator.predict(nb.outer_bound.transform(test)))
+         score=nb.emulator.predict(nb.outer_bound.transform(test)),
+         **neural_arrays(nb, 'nb_'))
 
     full = bounds.NautilusBound.compute(
         pts, log_l, log_l_min, np.log(0.5), n_networks=1,
@@ -176,7 +194,12 @@ def neural_and_nautilus_case():
          outer_n_reject=full.outer_bound.n_reject, log_v=full.log_v,
          test=test, contains=full.contains(test),
          n_neural=len(full.neural_bounds),
-         n_outer=len(full.outer_bound.bounds))
+         n_outer=len(full.outer_bound.bounds),
+         K=len(full.outer_bound.bounds), unit=True,
+         log_v_all=full.outer_bound.log_v_all,
+         **member_arrays(full.outer_bound),
+         **{k: v for i, nb_i in enumerate(full.neural_bounds)
+            for k, v in neural_arrays(nb_i, 'nb%d_' % i).items()})
 
 
 def gauss3(x):
@@ -232,6 +255,9 @@ def e2e_cases():
 
 
 if __name__ == '__main__':
+    if '--neural-only' in sys.argv:
+        neural_and_nautilus_case()
+        sys.exit(0)
     for d, n in [(3, 200), (20, 400), (50, 600)]:
         ellipsoid_case(d, n)
     mvee_sphere()

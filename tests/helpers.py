@@ -55,3 +55,48 @@ def upload(bound):
 
 def near_boundary(values, edge, tol):
     return np.abs(np.asarray(values) - edge) < tol
+
+
+def neural_from_golden(g, prefix):
+    """Rebuild an oracle NeuralBound from the parameters stored in a golden
+    file (no retraining: the GPU box may have a different CPU / BLAS)."""
+    from oracle import bounds_oracle as bo
+    from oracle import mlp_oracle as mo
+    nb = bo.ONeural()
+    nb.outer_bound = bo.OEllipsoid.from_params(
+        g[prefix + 'c'], g[prefix + 'B'], g[prefix + 'B_inv'],
+        g[prefix + 'A'])
+    nb.n_dim = nb.outer_bound.n_dim
+    nb.score_predict_min = float(g[prefix + 'score_predict_min'])
+    nb.emulator = None
+    if prefix + 'mean' in g:
+        e = int(g[prefix + 'n_networks'])
+        nets = [([g[prefix + 'coef_%d_%d' % (i, k)] for k in range(4)],
+                 [g[prefix + 'intercept_%d_%d' % (i, k)] for k in range(4)])
+                for i in range(e)]
+        nb.emulator = mo.Emulator.from_weights(g[prefix + 'mean'],
+                                               g[prefix + 'scale'], nets)
+    return nb
+
+
+def union_from_golden(g, mixture):
+    from oracle import bounds_oracle as bo
+    members = []
+    for i in range(int(g['K'])):
+        ell = None
+        if 'B_%d' % i in g:
+            ell = bo.OEllipsoid.from_params(g['c_%d' % i], g['B_%d' % i],
+                                            g['B_inv_%d' % i], g['A_%d' % i])
+        members.append(bo.OMixture.from_params(g['dim_cube_%d' % i], ell)
+                       if mixture else ell)
+    u = bo.OUnion.from_members(members, unit=bool(g['unit']))
+    u.log_v_all = g['log_v_all']
+    return u
+
+
+def nautilus_from_golden(g):
+    from oracle import bounds_oracle as bo
+    outer = union_from_golden(g, True)
+    neural = [neural_from_golden(g, 'nb%d_' % i)
+              for i in range(int(g['n_neural']))]
+    return bo.ONautilus.from_parts(outer, neural)

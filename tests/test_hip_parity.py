@@ -95,18 +95,8 @@ def test_mixture_contains_golden(dev):
 
 
 def _union_from_golden(g, mixture):
-    from oracle import bounds_oracle as bo
-    members = []
-    for i in range(int(g['K'])):
-        ell = None
-        if 'B_%d' % i in g:
-            ell = bo.OEllipsoid.from_params(g['c_%d' % i], g['B_%d' % i],
-                                            g['B_inv_%d' % i], g['A_%d' % i])
-        members.append(bo.OMixture.from_params(g['dim_cube_%d' % i], ell)
-                       if mixture else ell)
-    u = bo.OUnion.from_members(members, unit=bool(g['unit']))
-    u.log_v_all = g['log_v_all']
-    return u
+    from helpers import union_from_golden
+    return union_from_golden(g, mixture)
 
 
 @pytest.mark.parametrize('name,mixture', [('union_K2_D3', False),
@@ -169,11 +159,9 @@ def test_unit_cube(dev):
 
 @pytest.fixture(scope='module')
 def neural_d4():
-    from oracle import bounds_oracle as bo
+    from helpers import neural_from_golden
     g = load_golden('neuralbound_D4')
-    nb = bo.ONeural.build(g['points'], g['log_l'], float(g['log_l_min']),
-                          n_networks=1, rng=np.random.default_rng(0))
-    return g, nb
+    return g, neural_from_golden(g, 'nb_')
 
 
 def test_neural_bound_golden(dev, neural_d4):
@@ -209,12 +197,9 @@ def test_emulator_predict_golden(dev, d, e):
 
 @pytest.fixture(scope='module')
 def nautilus_d4():
-    from oracle import bounds_oracle as bo
+    from helpers import nautilus_from_golden
     g = load_golden('nautilusbound_D4')
-    b = bo.ONautilus.build(g['points'], g['log_l'], float(g['log_l_min']),
-                           float(g['log_v_target']), n_networks=1,
-                           rng=np.random.default_rng(0))
-    return g, b
+    return g, nautilus_from_golden(g)
 
 
 def test_nautilus_bound_contains_and_sample(dev, nautilus_d4):

