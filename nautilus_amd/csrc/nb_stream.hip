@@ -67,7 +67,7 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (q < nq) {
-          tile_lds[row * S + col] = stage[q].x;
+          if (row < 64) tile_lds[row * S + col] = stage[q].x;
           int rw2 = row, c2 = col + 1;
           if (c2 == n_dim) { c2 = 0; ++rw2; }
           if (rw2 < 64) tile_lds[rw2 * S + c2] = stage[q].y;
