@@ -1,0 +1,696 @@
+"""Device-backed bounds with the reference's duck-typed protocol.
+
+Every class offers what ``nautilus.Sampler`` touches on a bound (reference
+nautilus/sampler.py:791-798, 932, 1002, 1023-1035, 1069, 1218):
+``Class.compute(...)``, ``.contains(points)``, ``.sample(n_points)``,
+``.log_v``, ``.reset(rng)`` (and ``n_ell`` / ``n_net`` where the reference has
+them).  Construction runs on the host (``geometry.py``); the parameters are
+uploaded once (``device.DeviceBound``) and every per-point operation runs in
+the HIP kernels.  ``contains`` / ``sample`` accept and return numpy arrays
+like the reference; the ``*_device`` variants keep cuda tensors on the GPU
+(used by the sampler's hot loop).
+
+Random numbers: a bound owns a Philox stream whose 64-bit key is drawn from
+the shared ``numpy.random.Generator`` when the bound is created or ``reset``
+(DESIGN.md "RNG contract"); the same generator state therefore reproduces the
+same points bit for bit, as in the reference (tests/test_bounds.py:59-74,
+412-441 of the reference), while different pool sizes / GPU counts agree
+statistically only.
+"""
+
+import numpy as np
+import torch
+from scipy.special import logsumexp
+from scipy.stats import rankdata
+
+from . import device, geometry
+from .emulator import NeuralNetworkEmulator
+
+MIN_DRAW = 1 << 14          # proposals per launch, lower limit
+MAX_DRAW = 1 << 22          # upper limit (bounds the scratch memory)
+
+
+def _default_rng(rng):
+    return np.random.default_rng() if rng is None else rng
+
+
+def _to_numpy_mask(mask, like):
+    return mask if isinstance(like, torch.Tensor) else mask.cpu().numpy()
+
+
+class _PhiloxStream:
+    """64-bit key + running proposal index of one bound."""
+
+    def __init__(self, rng):
+        self.rekey(rng)
+
+    def rekey(self, rng):
+        self.seed = int(rng.integers(0, 2**63 - 1))
+        self.offset = 0
+
+    def take(self, n):
+        start = self.offset
+        self.offset += int(n)
+        return self.seed, start
+
+
+class _Fifo:
+    """Accepted points waiting to be handed out (``self.points`` of the
+    reference's Union / NautilusBound), kept on the device."""
+
+    def __init__(self, n_dim):
+        self.n_dim = n_dim
+        self.buf = torch.empty((0, n_dim), dtype=torch.float64, device='cuda')
+        self.head = 0
+
+    def __len__(self):
+        return self.buf.shape[0] - self.head
+
+    def push(self, rows):
+        if self.head > 0 or len(self) == 0:
+            self.buf = torch.cat([self.buf[self.head:], rows])
+            self.head = 0
+        else:
+            self.buf = torch.cat([self.buf, rows])
+
+    def pop(self, n):
+        out = self.buf[self.head:self.head + n]
+        self.head += n
+        return out
+
+    def unpop(self, n):
+        """Return the last ``n`` popped rows to the front of the queue."""
+        self.head -= n
+
+    def clear(self):
+        self.buf = self.buf[:0]
+        self.head = 0
+
+
+class _DeviceBoundBase:
+    """Shared contains / upload plumbing."""
+
+    _dev = None
+
+    def device_bound(self):
+        if self._dev is None:
+            self._dev = self._upload()
+        return self._dev
+
+    def contains_device(self, x):
+        return self.device_bound().contains(x)
+
+    def contains(self, points):
+        single = (not isinstance(points, torch.Tensor) and
+                  np.ndim(points) == 1)
+        mask = self.contains_device(points)
+        out = _to_numpy_mask(mask, points)
+        return bool(out[0]) if single else out
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_dev'] = None
+        return state
+
+
+# ---------------------------------------------------------------------------
+# primitive bounds
+# ---------------------------------------------------------------------------
+
+class UnitCube(_DeviceBoundBase):
+    """Unit hypercube (reference bounds/basic.py:9-151)."""
+
+    @classmethod
+    def compute(cls, n_dim, rng=None):
+        self = cls()
+        self.n_dim = n_dim
+        self.rng = _default_rng(rng)
+        self._stream = _PhiloxStream(self.rng)
+        return self
+
+    def _member(self):
+        return device.member()
+
+    def _upload(self):
+        return device.DeviceBound(self.n_dim, [self._member()], [0.0], True)
+
+    def sample_device(self, n_points=100):
+        seed, off = self._stream.take(n_points)
+        return self.device_bound().propose(seed, off, n_points)
+
+    def sample(self, n_points=100, pool=None):
+        return self.sample_device(n_points).cpu().numpy()
+
+    @property
+    def log_v(self):
+        return 0
+
+    def reset(self, rng=None):
+        if rng is not None:
+            self.rng = rng
+            self._stream.rekey(rng)
+
+
+class Ellipsoid(_DeviceBoundBase):
+    """Ellipsoid (reference bounds/basic.py:244-449)."""
+
+    @classmethod
+    def compute(cls, points, enlarge_per_dim=1.1, rng=None):
+        self = cls()
+        self.n_dim = points.shape[1]
+        p = geometry.ellipsoid_params(np.asarray(points), enlarge_per_dim)
+        self.c, self.A, self.B, self.B_inv = p['c'], p['A'], p['B'], p['B_inv']
+        self.rng = _default_rng(rng)
+        self._stream = _PhiloxStream(self.rng)
+        return self
+
+    @classmethod
+    def from_params(cls, c, B, B_inv=None, A=None, rng=None):
+        self = cls()
+        self.c = np.asarray(c, float)
+        self.n_dim = len(self.c)
+        self.B = np.tril(np.asarray(B, float))
+        self.B_inv = np.tril(np.linalg.inv(self.B) if B_inv is None
+                             else np.asarray(B_inv, float))
+        self.A = self.B_inv.T @ self.B_inv if A is None else A
+        self.rng = _default_rng(rng)
+        self._stream = _PhiloxStream(self.rng)
+        return self
+
+    def params(self):
+        return dict(c=self.c, A=self.A, B=self.B, B_inv=self.B_inv)
+
+    def _member(self, idx_ell=None, free_dims=False):
+        return device.member(self.c, self.B, self.B_inv, idx_ell=idx_ell,
+                             free_dims=free_dims)
+
+    def _upload(self):
+        return device.DeviceBound(self.n_dim, [self._member()], [self.log_v],
+                                  False)
+
+    def transform(self, points, inverse=False):
+        """basic.py:318-342 (host helper; the device path fuses it)."""
+        if not inverse:
+            return np.einsum('ij, ...j', self.B_inv, points - self.c)
+        return np.einsum('ij, ...j', self.B, points) + self.c
+
+    def contains_device(self, x):
+        x = device.as_device_points(x, self.n_dim)
+        if x.shape[0] >= 4096:
+            return self.device_bound().contains_stream(x)
+        return self.device_bound().contains(x)
+
+    def sample_device(self, n_points=100):
+        seed, off = self._stream.take(n_points)
+        return self.device_bound().propose(seed, off, n_points)
+
+    def sample(self, n_points=100):
+        return self.sample_device(n_points).cpu().numpy()
+
+    @property
+    def log_v(self):
+        return geometry.ellipsoid_log_volume(self.B)
+
+    def reset(self, rng=None):
+        if rng is not None:
+            self.rng = rng
+            self._stream.rekey(rng)
+
+
+class UnitCubeEllipsoidMixture(_DeviceBoundBase):
+    """Cube along some dimensions, ellipsoid along the others (reference
+    bounds/basic.py:452-726)."""
+
+    @classmethod
+    def compute(cls, points, enlarge_per_dim=1.1, rng=None):
+        self = cls()
+        points = np.asarray(points)
+        self.n_dim = points.shape[1]
+        self.dim_cube, ell = geometry.mixture_params(points, enlarge_per_dim)
+        self.rng = _default_rng(rng)
+        self.ellipsoid = None if ell is None else Ellipsoid.from_params(
+            ell['c'], ell['B'], ell['B_inv'], ell['A'], rng=self.rng)
+        self.cube = (UnitCube.compute(int(np.sum(self.dim_cube)),
+                                      rng=self.rng)
+                     if np.any(self.dim_cube) else None)
+        self._stream = _PhiloxStream(self.rng)
+        return self
+
+    @classmethod
+    def from_params(cls, dim_cube, ellipsoid, rng=None):
+        self = cls()
+        self.dim_cube = np.asarray(dim_cube, bool)
+        self.n_dim = len(self.dim_cube)
+        self.rng = _default_rng(rng)
+        self.ellipsoid = ellipsoid
+        self.cube = (UnitCube.compute(int(np.sum(self.dim_cube)),
+                                      rng=self.rng)
+                     if np.any(self.dim_cube) else None)
+        self._stream = _PhiloxStream(self.rng)
+        return self
+
+    def _member(self):
+        if self.ellipsoid is None:
+            return device.member()
+        idx = np.flatnonzero(~self.dim_cube).astype(np.int32)
+        return self.ellipsoid._member(idx_ell=idx)
+
+    def _upload(self):
+        return device.DeviceBound(self.n_dim, [self._member()], [self.log_v],
+                                  False)
+
+    def transform(self, points):
+        """basic.py:565-592 (host helper used by the mixture split)."""
+        out = np.copy(points)
+        if self.cube is not None:
+            idx = np.flatnonzero(self.dim_cube)
+            out[:, idx] = points[:, idx] * 2 - 1
+        if self.ellipsoid is not None:
+            idx = np.flatnonzero(~self.dim_cube)
+            out[:, idx] = self.ellipsoid.transform(points[:, idx])
+        return out
+
+    def sample_device(self, n_points=100):
+        seed, off = self._stream.take(n_points)
+        return self.device_bound().propose(seed, off, n_points)
+
+    def sample(self, n_points=100):
+        return self.sample_device(n_points).cpu().numpy()
+
+    @property
+    def log_v(self):
+        return 0 if self.ellipsoid is None else self.ellipsoid.log_v
+
+    def reset(self, rng=None):
+        if rng is not None:
+            self.rng = rng
+            self._stream.rekey(rng)
+            if self.ellipsoid is not None:
+                self.ellipsoid.reset(rng)
+            if self.cube is not None:
+                self.cube.reset(rng)
+
+
+# ---------------------------------------------------------------------------
+# rejection sampling shared by Union and NautilusBound
+# ---------------------------------------------------------------------------
+
+class _RejectionSampler(_DeviceBoundBase):
+    """FIFO + Monte-Carlo volume counters around ``DeviceBound.sample_launch``
+    (the chunked loops of bounds/union.py:305-327 and bounds/nautilus.py:
+    212-244, with one launch of >= 16384 proposals instead of chunks of
+    1000)."""
+
+    def _init_sampling(self, rng):
+        self.rng = _default_rng(rng)
+        self._stream = _PhiloxStream(self.rng)
+        self._fifo = None
+        self.n_sample = 0
+        self.n_reject = 0
+
+    def _queue(self):
+        if self._fifo is None:
+            self._fifo = _Fifo(self.n_dim)
+        return self._fifo
+
+    @property
+    def points(self):
+        """The reference's ``self.points`` (numpy view of the FIFO)."""
+        q = self._queue()
+        return q.buf[q.head:].cpu().numpy()
+
+    def _acceptance(self):
+        raise NotImplementedError
+
+    def _account(self, n_draw, n_outer, n_final):
+        raise NotImplementedError
+
+    def _fill(self, n_points):
+        q = self._queue()
+        while len(q) < n_points:
+            need = n_points - len(q)
+            acc = max(self._acceptance(), 1e-7)
+            n_draw = int(min(MAX_DRAW, max(MIN_DRAW, 1.2 * need / acc)))
+            n_draw = (n_draw + 63) // 64 * 64
+            seed, off = self._stream.take(n_draw)
+            rows, counts = self.device_bound().sample_launch(seed, off, n_draw)
+            c = counts.cpu().numpy()
+            self._account(n_draw, int(c[0]), int(c[1]))
+            q.push(rows[:int(c[1])])
+
+    def sample_device(self, n_points=100):
+        self._fill(n_points)
+        return self._queue().pop(n_points)
+
+    def _reset_sampling(self, rng=None):
+        self._queue().clear()
+        self.n_sample = 0
+        self.n_reject = 0
+        if rng is not None:
+            self.rng = rng
+            self._stream.rekey(rng)
+
+
+class Union(_RejectionSampler):
+    """Union of ellipsoids or cube-ellipsoid mixtures (reference
+    bounds/union.py:43-451)."""
+
+    _final_bit = 1
+
+    @classmethod
+    def compute(cls, points, enlarge_per_dim=1.1, n_points_min=None,
+                unit=True, bound_class=Ellipsoid, rng=None):
+        self = cls()
+        points = np.asarray(points)
+        self.n_dim = points.shape[1]
+        self.enlarge_per_dim = enlarge_per_dim
+        if n_points_min is None:
+            self.n_points_min = self.n_dim + 1
+        else:
+            if n_points_min < self.n_dim + 1:
+                raise ValueError('The number of points per bound must be '
+                                 'larger than the number of dimensions.')
+            self.n_points_min = n_points_min
+        self._init_sampling(rng)
+        self.cube = UnitCube.compute(self.n_dim, rng=self.rng) if unit \
+            else None
+        self.points_bounds = [points]
+        self.bounds = [bound_class.compute(
+            points, enlarge_per_dim=enlarge_per_dim, rng=self.rng)]
+        self.log_v_all = np.array([self.bounds[0].log_v])
+        self.block = np.atleast_1d(len(points) < 2 * self.n_points_min)
+        return self
+
+    @classmethod
+    def from_members(cls, members, unit=True, rng=None):
+        self = cls()
+        self.bounds = list(members)
+        self.n_dim = self.bounds[0].n_dim
+        self._init_sampling(rng)
+        self.cube = UnitCube.compute(self.n_dim, rng=self.rng) if unit \
+            else None
+        self.log_v_all = np.array([b.log_v for b in self.bounds])
+        return self
+
+    def _upload(self):
+        return device.DeviceBound(
+            self.n_dim, [b._member() for b in self.bounds], self.log_v_all,
+            self.cube is not None)
+
+    def _invalidate(self):
+        self._dev = None
+        self._reset_sampling()
+
+    # -- decomposition (host) ---------------------------------------------
+    def split(self, allow_overlap=True):
+        """union.py:153-229."""
+        if not allow_overlap and not isinstance(self.bounds[0], Ellipsoid):
+            raise ValueError("'allow_overlap' can only be False if bounds are "
+                             "ellipsoids.")
+        if not np.any(~self.block):
+            return False
+        index = int(np.argmax(np.where(~self.block, self.log_v_all, -np.inf)))
+        pts = self.points_bounds[index]
+        labels = geometry.two_component_labels(
+            self.bounds[index].transform(pts), self.n_points_min,
+            int(self.rng.integers(2**32 - 1)))
+        cls = type(self.bounds[0])
+        halves = [cls.compute(pts[labels == lab],
+                              enlarge_per_dim=self.enlarge_per_dim,
+                              rng=self.rng) for lab in (0, 1)]
+        if not allow_overlap and geometry.ellipsoids_overlap(
+                [b.params() for b in
+                 self.bounds[:index] + self.bounds[index + 1:] + halves]):
+            return False
+        if logsumexp([halves[0].log_v, halves[1].log_v]) > \
+                self.bounds[index].log_v:
+            self.block[index] = True
+            return self.split(allow_overlap=allow_overlap)
+        self.points_bounds.pop(index)
+        self.points_bounds += [pts[labels == 0], pts[labels == 1]]
+        self.bounds.pop(index)
+        self.bounds = self.bounds + halves
+        self.log_v_all = np.array([b.log_v for b in self.bounds])
+        self.block = np.concatenate((
+            np.delete(self.block, index),
+            [len(self.points_bounds[-2]) < 2 * self.n_points_min,
+             len(self.points_bounds[-1]) < 2 * self.n_points_min]))
+        self._invalidate()
+        return True
+
+    def trim(self, threshold=1e3):
+        """union.py:231-267."""
+        if len(self.bounds) == 1:
+            return False
+        log_r = (np.log([len(p) for p in self.points_bounds]) -
+                 np.array([b.log_v for b in self.bounds]))
+        index = int(np.argmin(log_r))
+        if log_r[index] - np.median(np.delete(log_r, index)) < \
+                -np.log(threshold):
+            self.points_bounds.pop(index)
+            self.bounds.pop(index)
+            self.block = np.delete(self.block, index)
+            self.log_v_all = np.array([b.log_v for b in self.bounds])
+            self._invalidate()
+            return True
+        return False
+
+    # -- sampling ---------------------------------------------------------
+    def _acceptance(self):
+        if self.n_sample == 0:
+            return 1.0
+        return 1.0 - self.n_reject / self.n_sample
+
+    def _account(self, n_draw, n_outer, n_final):
+        self.n_sample += n_draw                    # union.py:322
+        self.n_reject += n_draw - n_outer          # union.py:323
+
+    def _fill(self, n_points):
+        q = self._queue()
+        while len(q) < n_points:
+            need = n_points - len(q)
+            acc = max(self._acceptance(), 1e-7)
+            n_draw = int(min(MAX_DRAW, max(MIN_DRAW, 1.2 * need / acc)))
+            n_draw = (n_draw + 63) // 64 * 64
+            seed, off = self._stream.take(n_draw)
+            dev = self.device_bound()
+            x = dev.propose(seed, off, n_draw)
+            flags = dev.accept(seed, off, x)
+            rows, counts, _ = device.compact_rows(x, flags, 1)
+            k = int(counts[1])
+            self._account(n_draw, k, k)
+            q.push(rows[:k])
+
+    def sample(self, n_points=100):
+        return self.sample_device(n_points).cpu().numpy()
+
+    @property
+    def log_v(self):
+        """union.py:329-343."""
+        if self.n_sample == 0:
+            self._fill(1)
+        return geometry.log_volume_union(self.log_v_all, self.n_reject,
+                                         self.n_sample)
+
+    def reset(self, rng=None):
+        """union.py:431-450."""
+        self._reset_sampling(rng)
+        if rng is not None:
+            if self.cube is not None:
+                self.cube.reset(rng)
+            for b in self.bounds:
+                b.reset(rng)
+
+
+class NeuralBound(_DeviceBoundBase):
+    """Ellipsoid AND emulator score above a threshold (reference
+    bounds/neural.py:10-174)."""
+
+    @classmethod
+    def compute(cls, points, log_l, log_l_min, enlarge_per_dim=1.1,
+                n_networks=4, neural_network_kwargs={}, pool=None, rng=None):
+        """``points`` may be a numpy array or a cuda tensor (the sampler keeps
+        all points on the device); ``log_l`` is a numpy array."""
+        self = cls()
+        log_l = np.asarray(log_l)
+        x = device.as_device_points(points)
+        self.n_dim = x.shape[1]
+        rng = _default_rng(rng)
+        live = x[torch.from_numpy(log_l >= log_l_min).cuda()].cpu().numpy()
+        self.outer_bound = Ellipsoid.compute(
+            live, enlarge_per_dim=enlarge_per_dim, rng=rng)
+        if n_networks == 0:
+            self.emulator = None
+            self.score_predict_min = 0
+            return self
+
+        inside = self.outer_bound.contains_device(x)
+        x_in = x[inside]
+        log_l = log_l[inside.cpu().numpy()]
+        # ellipsoid-frame coordinates on the device (basic.py:340)
+        x_t = transform_device(self.outer_bound, x_in)
+        score = np.zeros(len(log_l))
+        hi = log_l >= log_l_min
+        score[hi] = 0.5 * (1 + (rankdata(log_l[hi]) - 0.5) / np.sum(hi))
+        score[~hi] = 0.5 * ((rankdata(log_l[~hi]) - 0.5) / np.sum(~hi))
+        self.emulator = NeuralNetworkEmulator.train(
+            x_t, score, n_networks=n_networks,
+            neural_network_kwargs=neural_network_kwargs, pool=pool)
+        pred = self.emulator.predict_device(x_t).cpu().numpy()
+        self.score_predict_min = np.polyval(
+            np.polyfit(score, pred, 3), np.amin(score[hi]))
+        return self
+
+    @classmethod
+    def from_parts(cls, ellipsoid, emulator, score_predict_min):
+        self = cls()
+        self.n_dim = ellipsoid.n_dim
+        self.outer_bound = ellipsoid
+        self.emulator = emulator
+        self.score_predict_min = score_predict_min
+        return self
+
+    def _neural(self):
+        return dict(ellipsoid=self.outer_bound._member(),
+                    score_predict_min=float(self.score_predict_min),
+                    mlp=None if self.emulator is None
+                    else self.emulator.mlp_desc())
+
+    def _upload(self):
+        return device.DeviceBound(self.n_dim, [], None, False,
+                                  [self._neural()])
+
+    def contains(self, points):
+        pts = points if isinstance(points, torch.Tensor) else \
+            np.atleast_2d(points)
+        return _to_numpy_mask(self.contains_device(pts), points)
+
+
+def transform_device(ellipsoid, x):
+    """B_inv (x - c) for a cuda tensor of points (reference basic.py:340).
+    A one-off per bound construction; expressed as a dense product."""
+    c = torch.from_numpy(ellipsoid.c).cuda()
+    b_inv_t = torch.from_numpy(np.ascontiguousarray(ellipsoid.B_inv.T)).cuda()
+    return ((x - c) @ b_inv_t).contiguous()
+
+
+class NautilusBound(_RejectionSampler):
+    """Outer multi-ellipsoid union AND any neural bound (reference
+    bounds/nautilus.py:13-398)."""
+
+    _final_bit = 2
+
+    @classmethod
+    def compute(cls, points, log_l, log_l_min, log_v_target,
+                enlarge_per_dim=1.1, n_points_min=None, split_threshold=100,
+                periodic=None, n_networks=4, neural_network_kwargs={},
+                pool=None, rng=None):
+        if periodic is not None:
+            raise NotImplementedError(
+                'periodic parameters are not supported by the device path '
+                'yet (SURVEY.md section 8 row f4)')
+        self = cls()
+        log_l = np.asarray(log_l)
+        x = device.as_device_points(points)
+        self.n_dim = x.shape[1]
+        self.shift = None
+        self._init_sampling(rng)
+        live = x[torch.from_numpy(log_l >= log_l_min).cuda()].cpu().numpy()
+
+        # non-overlapping ellipsoids -> one neural bound each (:100-114)
+        multi = Union.compute(live, enlarge_per_dim=enlarge_per_dim,
+                              n_points_min=n_points_min,
+                              bound_class=Ellipsoid, rng=self.rng)
+        while multi.split(allow_overlap=False):
+            pass
+        self.neural_bounds = []
+        for ell in multi.bounds:
+            sel = ell.contains_device(x)
+            self.neural_bounds.append(NeuralBound.compute(
+                x[sel], log_l[sel.cpu().numpy()], log_l_min,
+                enlarge_per_dim=enlarge_per_dim, n_networks=n_networks,
+                neural_network_kwargs=neural_network_kwargs, pool=pool,
+                rng=self.rng))
+
+        # sampling envelope (:116-133)
+        self.outer_bound = Union.compute(
+            live, enlarge_per_dim=enlarge_per_dim, n_points_min=n_points_min,
+            bound_class=UnitCubeEllipsoidMixture, rng=self.rng)
+        limit = np.log(split_threshold * enlarge_per_dim**self.n_dim)
+        while self.outer_bound.log_v - log_v_target > limit:
+            if not self.outer_bound.split():
+                break
+        while self.outer_bound.log_v - log_v_target > limit:
+            if not self.outer_bound.trim():
+                break
+        # the composite draws through its own fused pipeline; the envelope's
+        # counters keep accumulating (they are valid MC samples of the same
+        # volume), only its private FIFO is dropped
+        self.outer_bound._queue().clear()
+        return self
+
+    @classmethod
+    def from_parts(cls, outer_bound, neural_bounds, rng=None):
+        self = cls()
+        self.n_dim = outer_bound.n_dim
+        self.shift = None
+        self.outer_bound = outer_bound
+        self.neural_bounds = list(neural_bounds)
+        self._init_sampling(rng)
+        return self
+
+    def _upload(self):
+        u = self.outer_bound
+        return device.DeviceBound(
+            self.n_dim, [b._member() for b in u.bounds], u.log_v_all,
+            u.cube is not None, [nb._neural() for nb in self.neural_bounds])
+
+    def _acceptance(self):
+        a = 1.0
+        if self.outer_bound.n_sample > 0:
+            a *= 1.0 - self.outer_bound.n_reject / self.outer_bound.n_sample
+        if self.n_sample > 0:
+            a *= 1.0 - self.n_reject / self.n_sample
+        return a
+
+    def _account(self, n_draw, n_outer, n_final):
+        self.outer_bound.n_sample += n_draw        # union.py:322-323
+        self.outer_bound.n_reject += n_draw - n_outer
+        self.n_sample += n_outer                   # nautilus.py:221-222
+        self.n_reject += n_outer - n_final
+
+    def sample(self, n_points=100, return_points=True, pool=None):
+        """nautilus.py:193-244.  ``pool`` is accepted for compatibility: the
+        proposals of one launch are already spread over the whole GPU (and
+        over all GPUs of a ``DevicePool``)."""
+        if not return_points:
+            self._fill(n_points)
+            return None
+        return self.sample_device(n_points).cpu().numpy()
+
+    @property
+    def log_v(self):
+        """nautilus.py:246-261."""
+        if self.n_sample == 0:
+            self._fill(1)
+        u = self.outer_bound
+        return (geometry.log_volume_union(u.log_v_all, u.n_reject,
+                                          u.n_sample) +
+                np.log(1.0 - self.n_reject / self.n_sample))
+
+    @property
+    def n_ell(self):
+        return int(np.sum([np.any(~b.dim_cube)
+                           for b in self.outer_bound.bounds]))
+
+    @property
+    def n_net(self):
+        if self.neural_bounds[0].emulator is not None:
+            return len(self.neural_bounds) * len(
+                self.neural_bounds[0].emulator.neural_networks)
+        return 0
+
+    def reset(self, rng=None):
+        """nautilus.py:382-397."""
+        self._reset_sampling(rng)
+        self.outer_bound.reset(rng)

@@ -1,0 +1,182 @@
+"""Host-side construction of the bound geometry (small, sequential numerics).
+
+Bound *construction* -- minimum-volume enclosing ellipsoids, the greedy
+cube/ellipsoid split, the two-component mixture split and the ellipsoid
+overlap test -- runs a handful of times per bound on ~n_live points and stays
+on the host in this round (SURVEY.md section 8, rows f1/f2 "next").  What is
+built here is uploaded once through ``nb_bound_create``; every per-point
+operation afterwards (draw, contains, emulator, compaction) runs on the GPU.
+
+Semantics follow the reference (paths relative to /root/reference/nautilus):
+bounds/basic.py:154-241 (MVEE), 265-316 (Ellipsoid.compute), 471-563
+(UnitCubeEllipsoidMixture.compute); bounds/union.py:14-40 (overlap test),
+153-229 (split), 231-267 (trim).
+"""
+
+import itertools
+
+import numpy as np
+from scipy.linalg.lapack import dpotrf, dpotri
+from scipy.optimize import minimize
+from scipy.special import gammaln, logsumexp
+from threadpoolctl import threadpool_limits
+
+
+def inv_spd(m):
+    """Inverse of a symmetric positive definite matrix via Cholesky."""
+    tri = dpotri(dpotrf(m)[0])[0]
+    return tri + tri.T - np.diag(np.diag(tri))
+
+
+def mvee(points, n_max=100, n_batch=20):
+    """Batched Khachiyan iteration for the minimum-volume enclosing ellipsoid
+    (reference bounds/basic.py:175-241).  Unlike the reference the
+    (n, D+1, D+1) tensor of outer products is never materialised: the
+    quadratic forms are computed as row sums of (Q V^-1) * Q.
+
+    Returns centre c, shape matrix A ((x-c)^T A (x-c) <= 1) and A^-1.
+    """
+    n, d = points.shape
+    q = np.empty((n, d + 1))
+    q[:, :d] = points
+    q[:, d] = 1.0
+    u = np.full(n, 1.0 / n)
+    v = (q * u[:, None]).T @ q
+    v_inv = inv_spd(v)
+    for _ in range(n_max):
+        g_all = np.einsum('ij,ij->i', q @ v_inv, q)
+        first = True
+        for j in np.argsort(g_all)[-n_batch:][::-1]:
+            g = g_all[j] if first else q[j] @ v_inv @ q[j]
+            first = False
+            if g < d + 1:
+                continue
+            step = (g - (d + 1)) / ((d + 1) * (g - 1))
+            v = v * (1 - step) + step * np.outer(q[j], q[j])
+            v_inv = inv_spd(v)
+            u *= (1 - step)
+            u[j] += step
+    c = np.atleast_1d(np.average(points, weights=u, axis=0))
+    a_inv = np.atleast_2d(np.cov(points, aweights=u, rowvar=False, bias=True))
+    a = np.linalg.inv(a_inv)
+    diff = points - c
+    scale = np.amax(np.einsum('ij,ij->i', diff @ a, diff))
+    return c, a / scale, a_inv * scale
+
+
+def ellipsoid_params(points, enlarge_per_dim=1.1):
+    """Ellipsoid.compute (bounds/basic.py:265-316): returns dict(c, A, B,
+    B_inv) with B = chol(A^-1) lower triangular and B_inv = B^-1."""
+    n, d = points.shape
+    if enlarge_per_dim < 1.0:
+        raise ValueError("The 'enlarge_per_dim' factor cannot be smaller "
+                         "than unity.")
+    if not n > d:
+        raise ValueError('Number of points must be larger than number '
+                         'dimensions.')
+    with threadpool_limits(limits=1):
+        c, a, a_inv = mvee(points)
+    a = a / enlarge_per_dim**2.0
+    a_inv = a_inv * enlarge_per_dim**2.0
+    b = np.linalg.cholesky(a_inv)
+    b_inv = np.tril(np.linalg.inv(b))
+    return dict(c=c, A=a, B=b, B_inv=b_inv)
+
+
+def ellipsoid_log_volume(b):
+    """bounds/basic.py:393-394."""
+    d = b.shape[0]
+    return (np.linalg.slogdet(b)[1] + d * np.log(2.) + d * gammaln(1.5) -
+            gammaln(d / 2.0 + 1))
+
+
+def mixture_params(points, enlarge_per_dim=1.1):
+    """Greedy choice of the dimensions bounded by the unit cube
+    (bounds/basic.py:471-563).  Returns (dim_cube, ellipsoid dict or None)."""
+    d = points.shape[1]
+    ell = ellipsoid_params(points, enlarge_per_dim)
+    log_v = ellipsoid_log_volume(ell['B'])
+    dim_cube = np.zeros(d, dtype=bool)
+
+    while np.sum(~dim_cube) > 1:
+        free = np.flatnonzero(~dim_cube)
+        sub = points[:, free]
+        a_inv = np.linalg.inv(ell['A'])
+        trial_v = np.zeros(len(free))
+        for i in range(len(free)):
+            keep = np.arange(len(free)) != i
+            p = sub[:, keep] - ell['c'][keep]
+            a_p = np.linalg.inv(a_inv[np.ix_(keep, keep)])
+            scale = np.amax(np.einsum('ij,ij->i', p @ a_p, p))
+            trial_v[i] = np.linalg.slogdet(np.linalg.inv(a_p / scale))[1]
+        dim = free[np.argmin(trial_v)]
+        dim_cube[dim] = True
+        cand = ellipsoid_params(points[:, ~dim_cube], enlarge_per_dim)
+        cand_v = ellipsoid_log_volume(cand['B'])
+        if cand_v < log_v:
+            ell, log_v = cand, cand_v
+        else:
+            dim_cube[dim] = False
+            break
+
+    if log_v > 0:
+        # the ellipsoid is larger than the cube: start from the cube and move
+        # dimensions into an ellipsoid while that shrinks the volume
+        ell, log_v = None, 0.0
+        dim_cube = np.ones(d, dtype=bool)
+        tested = np.zeros(d, dtype=bool)
+        while not np.all(tested):
+            for dim in np.flatnonzero(~tested):
+                dim_cube[dim] = False
+                tested[dim] = True
+                cand = ellipsoid_params(points[:, ~dim_cube], enlarge_per_dim)
+                cand_v = ellipsoid_log_volume(cand['B'])
+                if log_v > cand_v:
+                    ell, log_v = cand, cand_v
+                    tested[dim_cube] = False
+                else:
+                    dim_cube[dim] = True
+    if np.all(dim_cube):
+        ell = None
+    return dim_cube, ell
+
+
+def ellipsoids_overlap(params):
+    """Exact pairwise intersection test (bounds/union.py:14-40): minimise
+    1 - d^T (A1^-1/(1-s) + A2^-1/s)^-1 d over s in (0, 1)."""
+    cs = [p['c'] for p in params]
+    covs = [np.linalg.inv(p['A']) for p in params]
+    for i, j in itertools.combinations(range(len(cs)), 2):
+        delta = cs[i] - cs[j]
+
+        def k(s):
+            return 1 - delta @ np.linalg.inv(
+                covs[i] / (1 - s) + covs[j] / s) @ delta
+        if minimize(k, 0.5, bounds=[(1e-9, 1 - 1e-9)]).fun > 0:
+            return True
+    return False
+
+
+def two_component_labels(points_t, n_points_min, random_state):
+    """Hard assignment of points to the two components of a full-covariance
+    Gaussian mixture, re-balanced so that both clusters keep at least
+    ``n_points_min`` members (bounds/union.py:185-197).  The EM fit itself is
+    scikit-learn's ``GaussianMixture`` -- the reference's own dependency for
+    this step."""
+    from scipy.stats import multivariate_normal
+    from sklearn.mixture import GaussianMixture
+    gmm = GaussianMixture(n_components=2, n_init=10,
+                          random_state=random_state).fit(points_t)
+    logp = np.vstack([multivariate_normal.logpdf(
+        points_t, mean=gmm.means_[i], cov=gmm.covariances_[i]) +
+        np.log(gmm.weights_[i]) for i in range(2)]).T
+    labels = np.argmax(logp, axis=1)
+    if not np.all(np.bincount(labels, minlength=2) >= n_points_min):
+        small = np.argmin(np.bincount(labels, minlength=2))
+        labels[np.argsort(-logp[:, small])[:n_points_min]] = small
+    return labels
+
+
+def log_volume_union(log_v_all, n_reject, n_sample):
+    """bounds/union.py:342-343."""
+    return logsumexp(log_v_all) + np.log(1.0 - n_reject / n_sample)

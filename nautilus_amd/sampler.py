@@ -1,0 +1,671 @@
+"""Importance nested sampling driver with the ``nautilus.Sampler`` interface,
+driving the MI355X hot path.
+
+Control flow follows the reference (nautilus/sampler.py: ``run`` 373-505,
+``add_bound`` 982-1091, ``add_samples`` 1093-1144, ``sample_shell`` 751-830,
+``update_shell_info`` 910-943, evidence / ESS properties 650-730, 1147-1190)
+so that evidence and posterior agree with the reference sampler; what differs
+is where the work happens:
+
+* all points stay in HBM (one growable tensor per shell); only ``log_l``
+  (8 bytes per point) is mirrored on the host for the driver's bookkeeping;
+* proposals, bound membership, shell exclusion and shell association are HIP
+  kernels over whole batches (``bounds.py`` / ``device.py``);
+* a shell batch is drawn as "trials until the n_batch-th success" over one
+  large block of in-bound points -- the same negative-binomial law as the
+  reference's shrinking-deficit loop (sampler.py:790-823), with one or two
+  kernel launches instead of dozens;
+* per-shell evidence statistics are wavefront reductions (``nb_shell_stats``).
+
+A likelihood marked with ``device = True`` (see ``likelihoods.py``) receives
+and returns cuda tensors, so nothing crosses PCIe inside the loop; any other
+callable is evaluated on the host exactly like in the reference, including
+``vectorized`` / ``pass_dict`` / ``pool`` handling.
+"""
+
+from functools import partial
+from time import time
+
+import numpy as np
+import torch
+from scipy.special import logsumexp
+
+from . import device
+from .bounds import NautilusBound, UnitCube
+from .pool import NautilusPool, likelihood_worker
+
+
+class _Grow:
+    """Append-only device array with amortised doubling (replaces the
+    reference's ``np.append`` growth, sampler.py:1135-1136)."""
+
+    def __init__(self, width=None):
+        shape = (0,) if width is None else (0, width)
+        self.data = torch.empty(shape, dtype=torch.float64, device='cuda')
+        self.n = 0
+
+    def view(self):
+        return self.data[:self.n]
+
+    def append(self, rows):
+        k = rows.shape[0]
+        if self.n + k > self.data.shape[0]:
+            cap = max(2 * self.data.shape[0], self.n + k, 1024)
+            new = torch.empty((cap,) + tuple(self.data.shape[1:]),
+                              dtype=torch.float64, device='cuda')
+            new[:self.n] = self.data[:self.n]
+            self.data = new
+        self.data[self.n:self.n + k] = rows
+        self.n += k
+
+    def keep(self, mask):
+        kept = self.data[:self.n][mask]
+        self.data = kept.clone()
+        self.n = kept.shape[0]
+
+
+class Sampler:
+    """Drop-in for ``nautilus.Sampler`` (constructor signature and public
+    attributes of the reference, sampler.py:121-129 and 307-327)."""
+
+    def __init__(self, prior, likelihood, n_dim=None, n_live=2000,
+                 n_update=None, enlarge_per_dim=1.1, n_points_min=None,
+                 split_threshold=100, periodic=None, n_networks=4,
+                 neural_network_kwargs={}, prior_args=[], prior_kwargs={},
+                 likelihood_args=[], likelihood_kwargs={}, n_batch=None,
+                 n_like_new_bound=None, vectorized=False, pass_dict=None,
+                 pool=None, seed=None, blobs_dtype=None, filepath=None,
+                 resume=True):
+        if filepath is not None:
+            raise NotImplementedError(
+                'checkpointing is not part of the device path yet '
+                '(SURVEY.md section 8 row f3)')
+        if blobs_dtype is not None:
+            raise NotImplementedError('blobs are not supported yet')
+        if periodic is not None:
+            raise NotImplementedError('periodic parameters are not supported '
+                                      'yet (SURVEY.md section 8 row f4)')
+
+        self._device_likelihood = bool(getattr(likelihood, 'device', False))
+        self._prior_is_identity = getattr(prior, '__name__', '') == \
+            'unit_prior'
+        if self._device_likelihood and not getattr(prior, 'device', False):
+            raise ValueError(
+                'a device likelihood needs a prior transform that works on '
+                'cuda tensors (mark it with `.device = True`, e.g. '
+                'nautilus_amd.unit_prior)')
+        if callable(prior):
+            self.prior = partial(prior, *prior_args, **prior_kwargs)
+            if n_dim is None:
+                raise ValueError("When passing a function as the 'prior' "
+                                 "argument, 'n_dim' cannot be None.")
+            self.n_dim = n_dim
+            pass_dict = False if pass_dict is None else pass_dict
+        else:
+            self.prior = prior
+            self.n_dim = prior.dimensionality()
+            pass_dict = True if pass_dict is None else pass_dict
+        if likelihood_args or likelihood_kwargs:
+            self.likelihood = partial(likelihood, *likelihood_args,
+                                      **likelihood_kwargs)
+        else:
+            self.likelihood = likelihood
+        if self.n_dim <= 1:
+            raise ValueError('Cannot run Nautilus with less than 2 '
+                             'parameters.')
+
+        self.n_live = n_live
+        self.n_update = n_live if n_update is None else n_update
+        self.n_like_new_bound = (10 * n_live if n_like_new_bound is None
+                                 else n_like_new_bound)
+        self.enlarge_per_dim = enlarge_per_dim
+        self.n_points_min = (self.n_dim + 50 if n_points_min is None
+                             else n_points_min)
+        self.split_threshold = split_threshold
+        self.periodic = None
+        self.n_networks = n_networks
+        self.neural_network_kwargs = neural_network_kwargs
+        self.vectorized = vectorized
+        self.pass_dict = pass_dict
+
+        # pool normalisation, sampler.py:283-298
+        try:
+            pools = list(pool)
+        except TypeError:
+            pools = [pool]
+        for i in range(len(pools)):
+            if pools[i] in [None, 1]:
+                pools[i] = None
+            elif i == 0 and isinstance(pools[i], int):
+                pools[i] = NautilusPool(pools[i], likelihood=self.likelihood)
+                self.likelihood = likelihood_worker
+            else:
+                pools[i] = NautilusPool(pools[i])
+        self.pool_l = pools[0]
+        self.pool_s = pools[-1]
+
+        if n_batch is None:
+            s = 1 if self.pool_l is None else self.pool_l.size
+            n_batch = (100 // s + (100 % s != 0)) * s
+        self.n_batch = n_batch
+        self.rng = np.random.default_rng(seed)
+
+        self.n_like = 0
+        self.explored = False
+        self.bounds = []
+        self._pts = []           # per shell: _Grow (n, n_dim) on the device
+        self._ll_dev = []        # per shell: _Grow (n,) on the device
+        self.log_l = []          # per shell: numpy mirror of log_l
+        self.blobs = None
+        self._discard_exploration = False
+        self.shell_n = np.zeros(0, dtype=int)
+        self.shell_n_sample = np.zeros(0, dtype=int)
+        self.shell_n_eff = np.zeros(0, dtype=float)
+        self.shell_log_l_min = np.zeros(0, dtype=float)
+        self.shell_log_l = np.zeros(0, dtype=float)
+        self.shell_log_v = np.zeros(0, dtype=float)
+        self.shell_n_sample_exp = np.zeros(0, dtype=int)
+        self.shell_end_exp = np.zeros(0, dtype=int)
+        self._pts_t = torch.empty((0, self.n_dim), dtype=torch.float64,
+                                  device='cuda')
+        self.shell_t = np.zeros(0, dtype=int)
+        self.log_l_t = np.zeros(0)
+        self._later = {}         # cache: shell index -> DeviceBoundList
+        self.timing = dict(add_bound=0.0, sample_shell=0.0, likelihood=0.0,
+                           bookkeeping=0.0)
+        self.n_proposals = 0     # raw proposal evaluations (outer draws)
+
+    # ------------------------------------------------------------------
+    # public views
+    # ------------------------------------------------------------------
+    @property
+    def points(self):
+        """Per-shell points as numpy arrays (reference attribute)."""
+        return [p.view().cpu().numpy() for p in self._pts]
+
+    @property
+    def points_t(self):
+        return self._pts_t.cpu().numpy()
+
+    @property
+    def n_eff(self):
+        """sampler.py:650-665."""
+        if np.all(self.shell_n_eff == 0):
+            return 0
+        use = self.shell_n_eff > 0
+        s = self.shell_log_l + self.shell_log_v
+        w = np.exp(s - np.nanmax(s))[use]
+        return np.sum(w)**2 / np.sum(w**2 / self.shell_n_eff[use])
+
+    @property
+    def log_z(self):
+        """sampler.py:682-694."""
+        if np.sum(self.shell_n) == 0:
+            return None
+        use = ~np.isnan(self.shell_log_l)
+        return logsumexp(self.shell_log_l[use] + self.shell_log_v[use])
+
+    @property
+    def eta(self):
+        """sampler.py:710-730."""
+        use = ~np.isnan(self.shell_log_l)
+        lz = (self.shell_log_l + self.shell_log_v)[use]
+        eff = (self.shell_n_eff / self.shell_n)[use]
+        return np.exp(2 * logsumexp(lz) - 2 * logsumexp(lz - 0.5 * np.log(eff)))
+
+    def _weights_and_log_l(self):
+        per_point = np.repeat(
+            self.shell_log_v - np.log(np.maximum(self.shell_n, 1)),
+            self.shell_n)
+        return per_point, np.concatenate(self.log_l)
+
+    def _live_slice(self, log_l):
+        """Indices of the n_live largest log_l values, ascending."""
+        if len(log_l) <= self.n_live:
+            return np.argsort(log_l)
+        part = np.argpartition(log_l, len(log_l) - self.n_live)
+        return part[len(log_l) - self.n_live:]
+
+    @property
+    def f_live(self):
+        """sampler.py:1147-1169."""
+        if self.explored:
+            return None
+        if np.sum(self.shell_n) == 0:
+            return 1.0
+        log_v, log_l = self._weights_and_log_l()
+        log_w = log_v + log_l
+        return np.exp(logsumexp(log_w[self._live_slice(log_l)]) -
+                      logsumexp(log_w))
+
+    @property
+    def log_v_live(self):
+        """sampler.py:1171-1190."""
+        if len(self.bounds) == 0:
+            return 1.0
+        log_v, log_l = self._weights_and_log_l()
+        return logsumexp(log_v[self._live_slice(log_l)])
+
+    @property
+    def discard_exploration(self):
+        return self._discard_exploration
+
+    @discard_exploration.setter
+    def discard_exploration(self, flag):
+        if not isinstance(flag, bool):
+            raise ValueError("'discard_exploration' must be a bool.")
+        self._discard_exploration = flag
+        for s in range(len(self.log_l)):
+            self.update_shell_info(s)
+
+    # ------------------------------------------------------------------
+    # main loop
+    # ------------------------------------------------------------------
+    def run(self, f_live=0.01, n_shell=1, n_eff=10000, n_like_max=np.inf,
+            discard_exploration=False, timeout=np.inf, verbose=False):
+        """sampler.py:373-505."""
+        t0 = time()
+        if verbose:
+            print('Starting the nautilus_amd sampler (MI355X hot path)...')
+            self.print_status(header=True)
+        if len(self.bounds) == 0:
+            self.add_bound()
+            self.n_update_iter = -self.n_live
+            self.n_like_iter = 0
+
+        def finished():
+            return bool(self.explored and np.all(self.shell_n >= n_shell) and
+                        self.n_eff >= n_eff)
+
+        done = finished()
+        while self.n_like < n_like_max and time() - t0 < timeout and not done:
+            if not self.explored:
+                if ((self.n_update_iter >= self.n_update or
+                     self.n_like_iter >= self.n_like_new_bound) and
+                        np.sum(self.shell_n) > self.n_live):
+                    self.add_bound(verbose=verbose)
+                    self.n_update_iter = 0
+                    self.n_like_iter = 0
+                self.n_update_iter += self.add_samples(-1, verbose=verbose)
+                self.n_like_iter += self.n_batch
+                if self.f_live <= f_live:
+                    self._finish_exploration(discard_exploration)
+            elif np.any(self.shell_n < n_shell):
+                self.add_samples(int(np.flatnonzero(self.shell_n < n_shell)[0]),
+                                 verbose=verbose)
+            elif self.n_eff < n_eff:
+                self.add_samples(self._next_shell(), verbose=verbose)
+            done = finished()
+        if verbose:
+            self.print_status('Finished' if done else 'Stopped')
+        return done
+
+    def _next_shell(self):
+        """Shell with the largest expected gain (sampler.py:489-491)."""
+        return int(np.argmax(self.shell_log_l + self.shell_log_v -
+                             0.5 * np.log(self.shell_n) -
+                             0.5 * np.log(self.shell_n_eff)))
+
+    def _finish_exploration(self, discard_exploration):
+        """sampler.py:457-480."""
+        for s in np.flatnonzero(self.shell_n == 0)[::-1]:
+            self.bounds.pop(s)
+            self._pts.pop(s)
+            self._ll_dev.pop(s)
+            self.log_l.pop(s)
+            for key in ('shell_n', 'shell_n_sample', 'shell_n_eff',
+                        'shell_log_l_min', 'shell_log_l', 'shell_log_v'):
+                setattr(self, key, np.delete(getattr(self, key), s))
+        self._later = {}
+        self.shell_n_sample_exp = np.copy(self.shell_n_sample)
+        self.shell_end_exp = np.array([len(ll) for ll in self.log_l])
+        self.explored = True
+        self.discard_exploration = discard_exploration
+
+    # ------------------------------------------------------------------
+    # shells
+    # ------------------------------------------------------------------
+    def _later_bounds(self, index):
+        index = index % len(self.bounds)
+        key = (index, len(self.bounds))
+        if key not in self._later:
+            devs = [b.device_bound() for b in self.bounds[index + 1:]]
+            self._later[key] = device.DeviceBoundList(devs) if devs else None
+        return self._later[key]
+
+    def shell_association(self, points, n_max=None):
+        """Highest-index bound (below ``n_max``) containing each point
+        (sampler.py:1192-1221)."""
+        if n_max is None:
+            n_max = len(self.bounds)
+        x = device.as_device_points(points, self.n_dim)
+        lst = device.DeviceBoundList(
+            [b.device_bound() for b in self.bounds[:n_max][::-1]])
+        first = lst.first_containing(x).cpu().numpy().astype(int)
+        shell = np.where(first >= 0, n_max - 1 - first, -1)
+        return shell
+
+    def sample_shell(self, index, shell_t=None):
+        """Fill one batch of the shell ``index`` (sampler.py:751-830).
+
+        Returns (points on the device, n_bound[, idx_t])."""
+        if shell_t is not None and index not in [-1, len(self.bounds) - 1]:
+            raise ValueError("'shell_t' must be empty list if not sampling "
+                             "from the last bound/shell.")
+        bound = self.bounds[index]
+        later = self._later_bounds(index)
+        s_idx = index % len(self.bounds)
+        n_bound = 0
+        have = 0
+        chunks = []
+        idx_t = np.zeros(0, dtype=int)
+        transfer = shell_t is not None and len(shell_t) > 0
+
+        while have < self.n_batch:
+            need = self.n_batch - have
+            if transfer or later is None:
+                n_req = need             # every drawn point is in the shell
+            else:
+                n_s = self.shell_n_sample[s_idx]
+                frac = (self.shell_n[s_idx] + 1.0) / (n_s + 2.0) \
+                    if n_s > 0 else 0.5
+                n_req = int(min(4 * device_block(), need / frac * 1.15 + 256))
+            x = bound.sample_device(n_req)
+            if later is not None:
+                keep = ~later.contains_any(x)             # sampler.py:796-798
+                csum = torch.cumsum(keep.to(torch.int64), 0)
+                total = int(csum[-1])
+                if total >= need:
+                    # stop at the need-th success; the rest goes back
+                    pos = int(torch.searchsorted(csum, need))
+                    used = pos + 1
+                    if hasattr(bound, '_queue'):
+                        bound._queue().unpop(n_req - used)
+                    # (points of a bound without FIFO are i.i.d. draws; the
+                    # unexamined tail is independent of the stopping rule
+                    # and is simply dropped)
+                    x, keep = x[:used], keep[:used]
+                else:
+                    used = n_req
+                n_bound += used
+                x = x[keep]
+            else:
+                n_bound += n_req
+
+            if transfer and x.shape[0] > 0:
+                # pair fresh points with stored candidates of the same
+                # earlier shell (sampler.py:803-819)
+                shell_p = self.shell_association(
+                    x, n_max=len(self.bounds) - 1)
+                swap = np.zeros(x.shape[0], dtype=bool)
+                for s in range(len(self.bounds) - 1):
+                    cand = np.flatnonzero(shell_t == s)
+                    fresh = np.flatnonzero(shell_p == s)
+                    m = min(len(cand), len(fresh))
+                    if m > 0:
+                        idx_t = np.append(idx_t, self.rng.choice(
+                            cand, size=m, replace=False))
+                        shell_t[idx_t] = -1
+                        swap[self.rng.choice(fresh, size=m,
+                                             replace=False)] = True
+                x = x[torch.from_numpy(~swap).cuda()]
+            if x.shape[0] > 0:
+                chunks.append(x)
+                have += x.shape[0]
+
+        pts = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+        if shell_t is None:
+            return pts, n_bound
+        return pts, n_bound, idx_t
+
+    def evaluate_likelihood(self, points):
+        """sampler.py:832-908.  ``points`` is a cuda tensor (n, n_dim);
+        returns (log_l numpy, log_l cuda tensor)."""
+        if self._device_likelihood:
+            args = points
+            if callable(self.prior) and not self._prior_is_identity:
+                args = self.prior(points)
+            ll = self.likelihood(args)
+            self.n_like += ll.shape[0]
+            return ll.cpu().numpy(), ll
+
+        if callable(self.prior):
+            transform = self.prior
+        elif self.pass_dict:
+            transform = self.prior.unit_to_dictionary
+        else:
+            transform = self.prior.unit_to_physical
+        host = points.cpu().numpy()
+        if not self.vectorized:
+            args = list(map(transform, np.copy(host)))
+        else:
+            args = list(map(transform, np.array_split(
+                host, 1 if self.pool_l is None else self.pool_l.size)))
+        if self.pool_l is not None:
+            result = list(self.pool_l.map(self.likelihood, args))
+        else:
+            result = list(map(self.likelihood, args))
+        if isinstance(result[0], tuple):
+            raise NotImplementedError('blobs are not supported yet')
+        log_l = (np.concatenate(result) if self.vectorized
+                 else np.array(result)).astype(float)
+        self.n_like += len(log_l)
+        return log_l, torch.from_numpy(log_l).cuda()
+
+    def update_shell_info(self, index):
+        """sampler.py:910-943 with the reductions on the device."""
+        n_sample = self.shell_n_sample[index]
+        if self._discard_exploration and self.explored:
+            start = self.shell_end_exp[index]
+            n_sample = n_sample - self.shell_n_sample_exp[index]
+        else:
+            start = 0
+        ll = self._ll_dev[index].view()[start:]
+        n = ll.shape[0]
+        self.shell_n[index] = n
+        if n > 0:
+            st = device.shell_stats(ll).cpu().numpy()
+            self.shell_log_v[index] = (self.bounds[index].log_v +
+                                       np.log(n / n_sample))
+            self.shell_log_l[index] = st[0] - np.log(n)
+            if st[2] > -np.inf:
+                self.shell_n_eff[index] = np.exp(2 * st[0] - st[1])
+            else:
+                self.shell_n_eff[index] = n
+        else:
+            self.shell_log_v[index] = -np.inf
+            self.shell_log_l[index] = np.nan
+            self.shell_n_eff[index] = 0
+
+    def add_samples(self, shell, verbose=False):
+        """sampler.py:1093-1144."""
+        if verbose:
+            self.print_status('Sampling', end='\r')
+        t0 = time()
+        if shell == -1 and len(self.shell_t) > 0:
+            pts, n_bound, idx_t = self.sample_shell(-1, self.shell_t)
+            assert pts.shape[0] + len(idx_t) == n_bound
+            if len(idx_t) > 0:
+                sel = torch.from_numpy(idx_t).cuda()
+                self._pts[-1].append(self._pts_t[sel])
+                self._ll_dev[-1].append(
+                    torch.from_numpy(self.log_l_t[idx_t]).cuda())
+                self.log_l[-1] = np.concatenate(
+                    (self.log_l[-1], self.log_l_t[idx_t]))
+        else:
+            pts, n_bound = self.sample_shell(shell)
+        t1 = time()
+        self.shell_n_sample[shell] += n_bound
+        log_l, log_l_dev = self.evaluate_likelihood(pts)
+        t2 = time()
+        self._pts[shell].append(pts)
+        self._ll_dev[shell].append(log_l_dev)
+        self.log_l[shell] = np.append(self.log_l[shell], log_l)
+        self.update_shell_info(shell)
+        t3 = time()
+        self.timing['sample_shell'] += t1 - t0
+        self.timing['likelihood'] += t2 - t1
+        self.timing['bookkeeping'] += t3 - t2
+        return int(np.sum(log_l >= self.shell_log_l_min[shell]))
+
+    # ------------------------------------------------------------------
+    # bounds
+    # ------------------------------------------------------------------
+    def add_bound(self, verbose=False):
+        """sampler.py:982-1091."""
+        t0 = time()
+        if len(self.bounds) == 0:
+            log_l_min = -np.inf
+            self.bounds.append(UnitCube.compute(self.n_dim, rng=self.rng))
+            ok = True
+        else:
+            if verbose:
+                self.print_status('Bounding', end='\r')
+            log_l = np.concatenate(self.log_l)
+            order = np.argsort(log_l)
+            log_l = log_l[order]
+            log_l_min = log_l[-self.n_live]
+            # likelihood plateaus, sampler.py:1012-1020
+            if (np.sum(log_l == log_l_min) > 1 and
+                    np.sum(log_l > log_l_min) >= self.n_points_min):
+                log_l_min = np.amin(log_l[log_l > log_l_min])
+            if np.all(log_l >= log_l_min):
+                ok = False
+            else:
+                pts = torch.cat([p.view() for p in self._pts])[
+                    torch.from_numpy(order).cuda()]
+                bound = NautilusBound.compute(
+                    pts, log_l, log_l_min, self.log_v_live,
+                    enlarge_per_dim=self.enlarge_per_dim,
+                    n_points_min=self.n_points_min,
+                    split_threshold=self.split_threshold,
+                    n_networks=self.n_networks,
+                    neural_network_kwargs=self.neural_network_kwargs,
+                    pool=self.pool_s, rng=self.rng)
+                bound.sample(1000, return_points=False)
+                ok = bool(bound.log_v < self.bounds[-1].log_v)
+                if ok:
+                    self.bounds.append(bound)
+        if not ok:
+            self.shell_log_l_min[-1] = log_l_min
+            self.timing['add_bound'] += time() - t0
+            return False
+
+        self.shell_n = np.append(self.shell_n, 0)
+        self.shell_n_sample = np.append(self.shell_n_sample, 0)
+        self.shell_n_eff = np.append(self.shell_n_eff, 0)
+        self.shell_log_l = np.append(self.shell_log_l, np.nan)
+        self.shell_log_v = np.append(self.shell_log_v, np.nan)
+        self.shell_log_l_min = np.append(self.shell_log_l_min, log_l_min)
+        self._pts.append(_Grow(self.n_dim))
+        self._ll_dev.append(_Grow())
+        self.log_l.append(np.zeros(0))
+        self._later = {}
+
+        if len(self.bounds) > 1:
+            # candidates for transfer into the new shell, sampler.py:1057-1089
+            st, pt, lt = [], [], []
+            new = self.bounds[-1]
+            for s in range(len(self.bounds) - 1):
+                if self._pts[s].n == 0:
+                    continue
+                inside = new.contains_device(self._pts[s].view())
+                k = int(inside.sum())
+                if k == 0:
+                    continue
+                inside_h = inside.cpu().numpy()
+                st.append(np.repeat(s, k))
+                pt.append(self._pts[s].view()[inside])
+                lt.append(self.log_l[s][inside_h])
+                self._pts[s].keep(~inside)
+                self._ll_dev[s].keep(~inside)
+                self.log_l[s] = self.log_l[s][~inside_h]
+                self.shell_n[s] -= k
+                self.update_shell_info(s)
+            if st:
+                self.shell_t = np.concatenate(st)
+                self._pts_t = torch.cat(pt)
+                self.log_l_t = np.concatenate(lt)
+            else:
+                self.shell_t = np.zeros(0, dtype=int)
+                self._pts_t = self._pts_t[:0]
+                self.log_l_t = np.zeros(0)
+        self.timing['add_bound'] += time() - t0
+        return True
+
+    # ------------------------------------------------------------------
+    # results
+    # ------------------------------------------------------------------
+    def posterior(self, return_as_dict=None, equal_weight=False,
+                  equal_weight_boost=1.0, return_blobs=False):
+        """sampler.py:541-647."""
+        if return_blobs:
+            raise ValueError('No blobs have been calculated.')
+        if return_as_dict is None:
+            return_as_dict = bool(callable(self.prior) and self.pass_dict)
+        if self._discard_exploration and self.explored:
+            start = self.shell_end_exp
+        else:
+            start = np.zeros(len(self.log_l), dtype=int)
+        pts = torch.cat([p.view()[s:] for p, s in zip(self._pts, start)]
+                        ).cpu().numpy()
+        log_l = np.concatenate([ll[s:] for ll, s in zip(self.log_l, start)])
+        log_w = np.repeat(self.shell_log_v -
+                          np.log(np.maximum(self.shell_n, 1)),
+                          self.shell_n) + log_l
+        if equal_weight:
+            rep = np.exp(log_w - np.amax(log_w)) * equal_weight_boost
+            rep = np.floor(rep).astype(int) + (
+                self.rng.random(len(rep)) < rep - np.floor(rep)).astype(int)
+            pts = np.repeat(pts, rep, axis=0)
+            log_w = np.zeros(np.sum(rep))
+            log_l = np.repeat(log_l, rep, axis=0)
+        if callable(self.prior):
+            transform = self.prior
+        elif return_as_dict:
+            transform = self.prior.unit_to_dictionary
+        else:
+            transform = self.prior.unit_to_physical
+        if not self.vectorized and callable(self.prior):
+            pts = np.array(list(map(transform, pts)))
+        else:
+            pts = transform(pts)
+        if not return_as_dict and callable(self.prior) and self.pass_dict:
+            raise ValueError('Cannot return points as numpy array. The prior '
+                             'function only returns dictionaries.')
+        return pts, log_w - logsumexp(log_w), log_l
+
+    def shell_bound_occupation(self, fractional=True):
+        """sampler.py:1223-1251."""
+        m = np.zeros((len(self.bounds), len(self.bounds)), dtype=int)
+        for i, p in enumerate(self._pts):
+            for k, b in enumerate(self.bounds):
+                m[i, k] = int(b.contains_device(p.view()).sum()) \
+                    if p.n > 0 else 0
+        if fractional:
+            m = m / np.diag(m)[:, np.newaxis]
+        return m
+
+    def print_status(self, status='', header=False, end='\n'):
+        """One line of the status table (sampler.py:945-980)."""
+        if header:
+            cells = ['Status', 'Bounds', 'Ellipses', 'Networks', 'Calls',
+                     'f_live', 'N_eff', 'log Z']
+        else:
+            last = self.bounds[-1] if len(self.bounds) > 1 else None
+            vals = [status, len(self.bounds),
+                    last.n_ell if last is not None else 0,
+                    last.n_net if last is not None else 0,
+                    self.n_like, self.f_live, self.n_eff, self.log_z]
+            fmts = ['{}', '{:d}', '{:d}', '{:d}', '{:d}', '{:.4f}', '{:.0f}',
+                    '{:+.2f}']
+            cells = ['N/A' if v is None else f.format(v)
+                     for v, f in zip(vals, fmts)]
+        widths = [9, 6, 8, 8, 8, 6, 5, 7]
+        print(' | '.join('{:<{}}'.format(c, w)
+                         for c, w in zip(cells, widths)), end=end, flush=True)
+
+
+def device_block():
+    """Upper limit of in-bound points examined per launch."""
+    return 1 << 20
