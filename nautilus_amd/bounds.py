@@ -18,6 +18,8 @@ same points bit for bit, as in the reference (tests/test_bounds.py:59-74,
 statistically only.
 """
 
+from time import time
+
 import numpy as np
 import torch
 from scipy.special import logsumexp
@@ -590,6 +592,7 @@ class NautilusBound(_RejectionSampler):
                 'periodic parameters are not supported by the device path '
                 'yet (SURVEY.md section 8 row f4)')
         self = cls()
+        t0 = time()
         log_l = np.asarray(log_l)
         x = device.as_device_points(points)
         self.n_dim = x.shape[1]
@@ -603,6 +606,7 @@ class NautilusBound(_RejectionSampler):
                               bound_class=Ellipsoid, rng=self.rng)
         while multi.split(allow_overlap=False):
             pass
+        t1 = time()
         self.neural_bounds = []
         for ell in multi.bounds:
             sel = ell.contains_device(x)
@@ -612,6 +616,7 @@ class NautilusBound(_RejectionSampler):
                 neural_network_kwargs=neural_network_kwargs, pool=pool,
                 rng=self.rng))
 
+        t2 = time()
         # sampling envelope (:116-133)
         self.outer_bound = Union.compute(
             live, enlarge_per_dim=enlarge_per_dim, n_points_min=n_points_min,
@@ -627,6 +632,8 @@ class NautilusBound(_RejectionSampler):
         # counters keep accumulating (they are valid MC samples of the same
         # volume), only its private FIFO is dropped
         self.outer_bound._queue().clear()
+        self.timing = dict(bound_decompose=t1 - t0, bound_neural=t2 - t1,
+                           bound_envelope=time() - t2)
         return self
 
     @classmethod

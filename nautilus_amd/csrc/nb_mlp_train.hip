@@ -4,17 +4,16 @@
 // (_fit_stochastic), :297-389 (_backprop), _stochastic_optimizers.py:255-287
 // (Adam), _base.py:187-189 (squared loss)).
 //
-// One persistent workgroup (8 wavefronts) per network; the E networks of an
-// emulator (and of all M neural bounds) train concurrently on different CUs.
-// Every Adam step has two phases separated by a workgroup barrier:
+// All networks of an emulator train concurrently.  Every Adam step is two
+// kernel launches on one stream (the kernel boundary is the grid-wide sync):
 //
-//  FB  each wavefront takes 16-row tiles of the minibatch: forward through
+//  FB  one wavefront per 16-row tile of the minibatch: forward through
 //      the four layers with activations held in registers (the MFMA C/D
 //      layout is the next layer's B-operand layout), output delta, backward
 //      deltas through W^T read from the same 16x16 tile-major weights; the
 //      activations and deltas are written row-major to a stash in global
 //      memory (L2 resident, ~0.8 MB per network).
-//  G   each wavefront owns weight tiles: dW = act^T delta contracted over all
+//  G   one wavefront per 16x16 weight tile: dW = act^T delta contracted over all
 //      rows of the minibatch in a fixed order (deterministic, no atomics),
 //      then the Adam update of that tile in place.  The bias is row K of the
 //      weight matrix (the activations carry a constant 1 in column K).
@@ -103,222 +102,196 @@ __device__ __forceinline__ void put_stash(double* __restrict__ base, int ld,
   for (int j = 0; j < NREG; ++j) base[(long long)pt * ld + 4 * j + lg] = v[j];
 }
 
+// ---------------------------------------------------------------------------
+// Step = two launches (kernel boundaries give grid-wide ordering and
+// visibility for ~1.5 us each on MI355X, far cheaper than an in-kernel grid
+// barrier across XCDs):
+//   nb_train_fb_kernel  grid (row tiles of the minibatch, networks), 1 wave
+//   nb_train_g_kernel   grid (weight tiles, networks), 1 wave
+// and one nb_train_epoch_kernel per epoch for the stopping rule.
+// ---------------------------------------------------------------------------
 template <int DT>
-__global__ void __launch_bounds__(64 * NWAVE)
-nb_train_kernel(TrainArgs a) {
+__global__ void __launch_bounds__(64)
+nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   constexpr int KS1MAX = 4 * DT + 1;
-  __shared__ double tile_loss[MAXB / 16];
-  __shared__ int stop_flag;
-
-  const NetState st = a.nets[blockIdx.x];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const NetState st = a.nets[blockIdx.y];
+  if (st.scal[4] != 0.0) return;                 // network already stopped
+  const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
   const int D = a.n_dim, kt1 = a.kt1;
   const int ld0 = 16 * kt1;
   const int ks1 = (D + 1 + 3) >> 2;
+  const int tile = blockIdx.x;
+  const long long n = a.n;
+  const int* perm = a.perm + ((long long)blockIdx.y * a.n_epochs + ep) * n;
 
-  if (st.scal[4] != 0.0) return;                 // already stopped
+  double* W1 = st.W;
+  double* W2 = W1 + kt1 * NB_HT1 * NB_TILE;
+  double* W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
+  double* W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
+  double* A0 = st.stash;
+  double* A1 = A0 + MAXB * ld0;
+  double* A2 = A1 + MAXB * LD1;
+  double* A3 = A2 + MAXB * LD2;
+  double* D1 = A3 + MAXB * LD3;
+  double* D2 = D1 + MAXB * LD1;
+  double* D3 = D2 + MAXB * LD2;
+  double* D4 = D3 + MAXB * LD3;
 
-  double* Wbase = st.W;
-  double* Sbase = st.stash;
+  const int pt = tile * 16 + li;
+  const bool valid = pt < nb;
+  const long long row = valid ? perm[start + pt] : 0;
 
+  double t[KS1MAX];
+#pragma unroll
+  for (int ks = 0; ks < KS1MAX; ++ks) {
+    const int f = 4 * ks + lg;
+    t[ks] = (f < D) ? (valid ? a.X[row * D + f] : 0.0)
+                    : ((f == D) ? 1.0 : 0.0);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS1MAX; ++ks)
+    if (4 * ks < ld0) A0[(long long)pt * ld0 + 4 * ks + lg] = t[ks];
+
+  // forward; every layer's activations go to the stash for the G kernel
+  double h1[4 * NB_HT1], h2[4 * NB_HT2], h3[4 * NB_HT3], o[4];
+  fwd_layer<KS1MAX, NB_HT1>(W1, ks1, t, lane, h1, true);
+  if (lg == 0) h1[25] = 1.0;
+  put_stash<4 * NB_HT1>(A1, LD1, pt, lane, h1);
+  fwd_layer<26, NB_HT2>(W2, 26, h1, lane, h2, true);
+  if (lg == 2) h2[12] = 1.0;
+  put_stash<4 * NB_HT2>(A2, LD2, pt, lane, h2);
+  fwd_layer<13, NB_HT3>(W3, 13, h2, lane, h3, true);
+  if (lg == 0) h3[5] = 1.0;
+  put_stash<4 * NB_HT3>(A3, LD3, pt, lane, h3);
+  fwd_layer<6, 1>(W4, 6, h3, lane, o, false);
+
+  // output delta (sklearn :365) and the squared-loss partial of this tile
+  double d4[4] = {0.0, 0.0, 0.0, 0.0};
+  if (lg == 0 && valid) d4[0] = o[0] - a.y[row];
+  put_stash<4>(D4, LD4, pt, lane, d4);
+  double lp = 0.5 * d4[0] * d4[0];
+  for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
+  if (lane == 0) st.scal[8 + tile] = lp;
+
+  // backward (ReLU mask = activation == 0, sklearn inplace_relu_derivative;
+  // the bias units carry no delta)
+  double d3[4 * NB_HT3], d2[4 * NB_HT2], d1[4 * NB_HT1];
+  bwd_layer<NB_HT3, 1, 1>(W4, d4, lane, d3);
+#pragma unroll
+  for (int j = 0; j < 4 * NB_HT3; ++j) if (h3[j] == 0.0) d3[j] = 0.0;
+  if (lg == 0) d3[5] = 0.0;
+  put_stash<4 * NB_HT3>(D3, LD3, pt, lane, d3);
+  bwd_layer<NB_HT2, NB_HT3, 5>(W3, d3, lane, d2);
+#pragma unroll
+  for (int j = 0; j < 4 * NB_HT2; ++j) if (h2[j] == 0.0) d2[j] = 0.0;
+  if (lg == 2) d2[12] = 0.0;
+  put_stash<4 * NB_HT2>(D2, LD2, pt, lane, d2);
+  bwd_layer<NB_HT1, NB_HT2, 13>(W2, d2, lane, d1);
+#pragma unroll
+  for (int j = 0; j < 4 * NB_HT1; ++j) if (h1[j] == 0.0) d1[j] = 0.0;
+  if (lg == 0) d1[25] = 0.0;
+  put_stash<4 * NB_HT1>(D1, LD1, pt, lane, d1);
+}
+
+__global__ void __launch_bounds__(64)
+nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
+  const NetState st = a.nets[blockIdx.y];
+  if (st.scal[4] != 0.0) return;
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lg = lane >> 4;
+  const int kt1 = a.kt1;
+  const int ld0 = 16 * kt1;
+  const int n_tiles = (nb + 15) >> 4;
   const int n_gt1 = kt1 * NB_HT1, n_gt2 = NB_HT1 * NB_HT2,
-            n_gt3 = NB_HT2 * NB_HT3, n_gt4 = NB_HT3;
-  const int n_gt = n_gt1 + n_gt2 + n_gt3 + n_gt4;
+            n_gt3 = NB_HT2 * NB_HT3;
+  const int gt = blockIdx.x;
 
-  long long t_adam = (long long)st.scal[0];
+  const double* A0 = st.stash;
+  const double* A1 = A0 + MAXB * ld0;
+  const double* A2 = A1 + MAXB * LD1;
+  const double* A3 = A2 + MAXB * LD2;
+  const double* D1 = A3 + MAXB * LD3;
+  const double* D2 = D1 + MAXB * LD1;
+  const double* D3 = D2 + MAXB * LD2;
+  const double* D4 = D3 + MAXB * LD3;
+
+  // the first workgroup also folds the step's loss into the epoch sum, in
+  // tile order (deterministic)
+  if (gt == 0 && lane == 0) {
+    double acc = st.scal[5];
+    for (int i = 0; i < n_tiles; ++i) acc += st.scal[8 + i];
+    st.scal[5] = acc;
+  }
+
+  const double* As; const double* Bs; int lda, ldb, kt, ht;
+  long long woff;
+  if (gt < n_gt1) {
+    kt = gt / NB_HT1; ht = gt % NB_HT1; As = A0; lda = ld0; Bs = D1;
+    ldb = LD1;
+    woff = (long long)(kt * NB_HT1 + ht) * NB_TILE;
+  } else if (gt < n_gt1 + n_gt2) {
+    const int g = gt - n_gt1;
+    kt = g / NB_HT2; ht = g % NB_HT2; As = A1; lda = LD1; Bs = D2; ldb = LD2;
+    woff = (long long)(n_gt1 + kt * NB_HT2 + ht) * NB_TILE;
+  } else if (gt < n_gt1 + n_gt2 + n_gt3) {
+    const int g = gt - n_gt1 - n_gt2;
+    kt = g / NB_HT3; ht = g % NB_HT3; As = A2; lda = LD2; Bs = D3; ldb = LD3;
+    woff = (long long)(n_gt1 + n_gt2 + kt * NB_HT3 + ht) * NB_TILE;
+  } else {
+    const int g = gt - n_gt1 - n_gt2 - n_gt3;
+    kt = g; ht = 0; As = A3; lda = LD3; Bs = D4; ldb = LD4;
+    woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
+  }
+  // dW tile = act^T delta over the rows of the minibatch (fixed order)
+  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  const double* ap = As + (long long)lg * lda + 16 * kt + li;
+  const double* bp = Bs + (long long)lg * ldb + 16 * ht + li;
+  const int n_steps = n_tiles * 4;
+  int s = 0;
+  for (; s + 1 < n_steps; s += 2) {
+    acc0 = MFMA(ap[0], bp[0], acc0);
+    acc1 = MFMA(ap[4 * lda], bp[4 * ldb], acc1);
+    ap += 8 * lda;
+    bp += 8 * ldb;
+  }
+  if (s < n_steps) acc0 = MFMA(ap[0], bp[0], acc0);
+
+  // Adam (sklearn _stochastic_optimizers.py:255-287), in place
+  const double lr_t = a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
+                      (1.0 - pow(a.b1, (double)t_adam));
+  const double inv_nb = 1.0 / (double)nb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long idx = woff + (lg + 4 * r) * 16 + li;
+    const double g = (acc0[r] + acc1[r]) * inv_nb;
+    const double m = a.b1 * st.M[idx] + (1.0 - a.b1) * g;
+    const double v = a.b2 * st.V[idx] + (1.0 - a.b2) * (g * g);
+    st.M[idx] = m;
+    st.V[idx] = v;
+    st.W[idx] += -lr_t * m / (sqrt(v) + a.eps);
+  }
+}
+
+// end of epoch: loss curve and the stopping rule of _fit_stochastic
+// (sklearn/_multilayer_perceptron.py:730-760, 819-822)
+__global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
+  const NetState st = a.nets[blockIdx.x];
+  if (threadIdx.x != 0 || st.scal[4] != 0.0) return;
+  const double loss = st.scal[5] / (double)a.n;
+  int n_iter = (int)st.scal[3];
   double best = st.scal[1];
   int stale = (int)st.scal[2];
-  int n_iter = (int)st.scal[3];
-  const long long n = a.n;
-  const int* perm_net = a.perm + (long long)blockIdx.x * a.n_epochs * n;
-
-  for (int ep = 0; ep < a.n_epochs; ++ep) {
-    const int* perm = perm_net + (long long)ep * n;
-    double epoch_acc = 0.0;                       // thread 0 only
-
-    for (long long start = 0; start < n; start += a.batch) {
-      const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
-      const int n_tiles = (nb + 15) >> 4;
-
-      // ------------------------------ phase FB -------------------------
-      for (int tile = wave; tile < n_tiles; tile += NWAVE) {
-        // Launder the (loop-invariant) base pointers: otherwise LICM hoists
-        // several hundred per-lane 64-bit addresses out of the loops and
-        // spills them (cdna_hip_programming.md, "lane-constant address
-        // hoisted to kernel entry").
-        asm volatile("" : "+s"(Wbase));
-        asm volatile("" : "+s"(Sbase));
-        double* W1 = Wbase;
-        double* W2 = W1 + kt1 * NB_HT1 * NB_TILE;
-        double* W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
-        double* W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
-        double* A0 = Sbase;
-        double* A1 = A0 + MAXB * ld0;
-        double* A2 = A1 + MAXB * LD1;
-        double* A3 = A2 + MAXB * LD2;
-        double* D1 = A3 + MAXB * LD3;
-        double* D2 = D1 + MAXB * LD1;
-        double* D3 = D2 + MAXB * LD2;
-        double* D4 = D3 + MAXB * LD3;
-        const int pt = tile * 16 + li;
-        const bool valid = pt < nb;
-        const long long row = valid ? perm[start + pt] : 0;
-
-        double t[KS1MAX];
-#pragma unroll
-        for (int ks = 0; ks < KS1MAX; ++ks) {
-          const int f = 4 * ks + lg;
-          t[ks] = (f < D) ? (valid ? a.X[row * D + f] : 0.0)
-                          : ((f == D) ? 1.0 : 0.0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS1MAX; ++ks)
-          if (4 * ks < ld0) A0[(long long)pt * ld0 + 4 * ks + lg] = t[ks];
-
-        // forward; every layer's activations go to the stash at once so
-        // that only two layers are ever live in registers
-        double h3[4 * NB_HT3], o[4];
-        {
-          double h2[4 * NB_HT2];
-          {
-            double h1[4 * NB_HT1];
-            fwd_layer<KS1MAX, NB_HT1>(W1, ks1, t, lane, h1, true);
-            if (lg == 0) h1[25] = 1.0;
-            put_stash<4 * NB_HT1>(A1, LD1, pt, lane, h1);
-            fwd_layer<26, NB_HT2>(W2, 26, h1, lane, h2, true);
-          }
-          if (lg == 2) h2[12] = 1.0;
-          put_stash<4 * NB_HT2>(A2, LD2, pt, lane, h2);
-          fwd_layer<13, NB_HT3>(W3, 13, h2, lane, h3, true);
-        }
-        if (lg == 0) h3[5] = 1.0;
-        put_stash<4 * NB_HT3>(A3, LD3, pt, lane, h3);
-        fwd_layer<6, 1>(W4, 6, h3, lane, o, false);
-
-        // output delta (sklearn :365) and the squared-loss partial
-        double d4[4] = {0.0, 0.0, 0.0, 0.0};
-        if (lg == 0 && valid) d4[0] = o[0] - a.y[row];
-        put_stash<4>(D4, LD4, pt, lane, d4);
-        double lp = 0.5 * d4[0] * d4[0];
-        for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
-        if (lane == 0) tile_loss[tile] = lp;
-
-        // backward; ReLU masks (activation == 0, sklearn inplace_relu_
-        // derivative) are re-read from the stash this lane wrote above
-        double d2[4 * NB_HT2];
-        {
-          double d3[4 * NB_HT3];
-          bwd_layer<NB_HT3, 1, 1>(W4, d4, lane, d3);
-#pragma unroll
-          for (int j = 0; j < 4 * NB_HT3; ++j) if (h3[j] == 0.0) d3[j] = 0.0;
-          if (lg == 0) d3[5] = 0.0;
-          put_stash<4 * NB_HT3>(D3, LD3, pt, lane, d3);
-          bwd_layer<NB_HT2, NB_HT3, 5>(W3, d3, lane, d2);
-        }
-#pragma unroll
-        for (int j = 0; j < 4 * NB_HT2; ++j)
-          if (A2[(long long)pt * LD2 + 4 * j + lg] == 0.0) d2[j] = 0.0;
-        if (lg == 2) d2[12] = 0.0;
-        put_stash<4 * NB_HT2>(D2, LD2, pt, lane, d2);
-        {
-          double d1[4 * NB_HT1];
-          bwd_layer<NB_HT1, NB_HT2, 13>(W2, d2, lane, d1);
-#pragma unroll
-          for (int j = 0; j < 4 * NB_HT1; ++j)
-            if (A1[(long long)pt * LD1 + 4 * j + lg] == 0.0) d1[j] = 0.0;
-          if (lg == 0) d1[25] = 0.0;
-          put_stash<4 * NB_HT1>(D1, LD1, pt, lane, d1);
-        }
-      }
-      __syncthreads();
-
-      if (threadIdx.x == 0)
-        for (int i = 0; i < n_tiles; ++i) epoch_acc += tile_loss[i];
-
-      // ------------------------------ phase G + Adam --------------------
-      t_adam += 1;
-      const double lr_t = a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
-                          (1.0 - pow(a.b1, (double)t_adam));
-      const double inv_nb = 1.0 / (double)nb;
-      const int n_steps = n_tiles * 4;
-      for (int gt = wave; gt < n_gt; gt += NWAVE) {
-        asm volatile("" : "+s"(Sbase));
-        const double* A0 = Sbase;
-        const double* A1 = A0 + MAXB * ld0;
-        const double* A2 = A1 + MAXB * LD1;
-        const double* A3 = A2 + MAXB * LD2;
-        const double* D1 = A3 + MAXB * LD3;
-        const double* D2 = D1 + MAXB * LD1;
-        const double* D3 = D2 + MAXB * LD2;
-        const double* D4 = D3 + MAXB * LD3;
-        const double* As; const double* Bs; int lda, ldb, kt, ht;
-        long long woff;
-        if (gt < n_gt1) {
-          kt = gt / NB_HT1; ht = gt % NB_HT1; As = A0; lda = ld0; Bs = D1;
-          ldb = LD1; woff = 0;
-          woff += (long long)(kt * NB_HT1 + ht) * NB_TILE;
-        } else if (gt < n_gt1 + n_gt2) {
-          const int g = gt - n_gt1;
-          kt = g / NB_HT2; ht = g % NB_HT2; As = A1; lda = LD1; Bs = D2;
-          ldb = LD2;
-          woff = (long long)(n_gt1 + kt * NB_HT2 + ht) * NB_TILE;
-        } else if (gt < n_gt1 + n_gt2 + n_gt3) {
-          const int g = gt - n_gt1 - n_gt2;
-          kt = g / NB_HT3; ht = g % NB_HT3; As = A2; lda = LD2; Bs = D3;
-          ldb = LD3;
-          woff = (long long)(n_gt1 + n_gt2 + kt * NB_HT3 + ht) * NB_TILE;
-        } else {
-          const int g = gt - n_gt1 - n_gt2 - n_gt3;
-          kt = g; ht = 0; As = A3; lda = LD3; Bs = D4; ldb = LD4;
-          woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
-        }
-        nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* ap = As + (long long)lg * lda + 16 * kt + li;
-        const double* bp = Bs + (long long)lg * ldb + 16 * ht + li;
-        for (int s = 0; s < n_steps; ++s) {
-          acc = MFMA(ap[0], bp[0], acc);
-          ap += 4 * lda;
-          bp += 4 * ldb;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long long idx = woff + (lg + 4 * r) * 16 + li;
-          const double g = acc[r] * inv_nb;
-          const double m = a.b1 * st.M[idx] + (1.0 - a.b1) * g;
-          const double v = a.b2 * st.V[idx] + (1.0 - a.b2) * (g * g);
-          st.M[idx] = m;
-          st.V[idx] = v;
-          st.W[idx] += -lr_t * m / (sqrt(v) + a.eps);
-        }
-      }
-      __syncthreads();
-    }
-
-    // ------------------------------ end of epoch ------------------------
-    if (threadIdx.x == 0) {
-      const double loss = epoch_acc / (double)n;
-      st.loss_curve[n_iter] = loss;
-      n_iter += 1;
-      if (loss > best - a.tol) stale += 1; else stale = 0;
-      if (loss < best) best = loss;
-      stop_flag = (stale > a.n_iter_no_change || n_iter >= a.max_iter) ? 1 : 0;
-    }
-    __syncthreads();
-    const int stop = stop_flag;
-    __syncthreads();
-    if (stop) {
-      if (threadIdx.x == 0) st.scal[4] = 1.0;
-      break;
-    }
-  }
-  if (threadIdx.x == 0) {
-    st.scal[0] = (double)t_adam;
-    st.scal[1] = best;
-    st.scal[2] = (double)stale;
-    st.scal[3] = (double)n_iter;
-  }
+  st.loss_curve[n_iter] = loss;
+  n_iter += 1;
+  if (loss > best - a.tol) stale += 1; else stale = 0;
+  if (loss < best) best = loss;
+  st.scal[0] = (double)t_adam;
+  st.scal[1] = best;
+  st.scal[2] = (double)stale;
+  st.scal[3] = (double)n_iter;
+  st.scal[5] = 0.0;
+  if (stale > a.n_iter_no_change || n_iter >= a.max_iter) st.scal[4] = 1.0;
 }
 
 void put_w(double* tiles, int ht_n, int k, int h, double v) {
@@ -343,6 +316,7 @@ struct nb_trainer {
   double* pool = nullptr;          // one allocation for all per-net buffers
   int max_iter = 10000, n_iter_no_change = 10, batch = 200;
   double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
+  long long t_adam = 0;
 };
 
 extern "C" {
@@ -364,7 +338,7 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
   t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
   const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
   const long long curve = t->max_iter;
-  const long long per_net = 3 * t->n_w + stash + curve + 8;
+  const long long per_net = 3 * t->n_w + stash + curve + 32;
   const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
   hipError_t e = hipMalloc((void**)&t->pool, bytes);
   if (e == hipSuccess) e = hipMemset(t->pool, 0, bytes);
@@ -404,7 +378,7 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
     put_w(w4, 1, NB_H3, 0, b[3][0]);
     e = hipMemcpy(s.W, w.data(), (size_t)t->n_w * sizeof(double),
                   hipMemcpyHostToDevice);
-    const double scal0[8] = {0.0, INFINITY, 0.0, 0.0, 0.0, 0, 0, 0};
+    const double scal0[8] = {0.0, INFINITY, 0.0, 0.0, 0.0, 0.0, 0, 0};
     if (e == hipSuccess)
       e = hipMemcpy(s.scal, scal0, sizeof scal0, hipMemcpyHostToDevice);
     if (e != hipSuccess) break;
@@ -444,17 +418,31 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
   a.max_iter = t->max_iter; a.n_iter_no_change = t->n_iter_no_change;
   a.batch = (int)((t->n < t->batch) ? t->n : t->batch);
   a.tol = t->tol; a.lr = t->lr; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps;
-  const dim3 grid(t->E), block(64 * NWAVE);
-  switch (t->dt) {
-    case 1: hipLaunchKernelGGL(nb_train_kernel<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(nb_train_kernel<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(nb_train_kernel<3>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(nb_train_kernel<4>, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(nb_train_kernel<5>, grid, block, 0, s, a); break;
-    case 6: hipLaunchKernelGGL(nb_train_kernel<6>, grid, block, 0, s, a); break;
-    case 7: hipLaunchKernelGGL(nb_train_kernel<7>, grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL(nb_train_kernel<8>, grid, block, 0, s, a); break;
-    default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
+  // Adam step counter continues across calls (host mirror of scal[0])
+  const long long n = t->n;
+  const int steps_per_epoch = (int)((n + a.batch - 1) / a.batch);
+  const int n_gt = nb_net_tiles(t->kt1);
+  for (int ep = 0; ep < n_epochs; ++ep) {
+    for (int sidx = 0; sidx < steps_per_epoch; ++sidx) {
+      const long long start = (long long)sidx * a.batch;
+      const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
+      const dim3 gfb((nb + 15) / 16, t->E), gg(n_gt, t->E), blk(64);
+      t->t_adam += 1;
+      switch (t->dt) {
+        case 1: hipLaunchKernelGGL(nb_train_fb_kernel<1>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 2: hipLaunchKernelGGL(nb_train_fb_kernel<2>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 3: hipLaunchKernelGGL(nb_train_fb_kernel<3>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 4: hipLaunchKernelGGL(nb_train_fb_kernel<4>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 5: hipLaunchKernelGGL(nb_train_fb_kernel<5>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 6: hipLaunchKernelGGL(nb_train_fb_kernel<6>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 7: hipLaunchKernelGGL(nb_train_fb_kernel<7>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 8: hipLaunchKernelGGL(nb_train_fb_kernel<8>, gfb, blk, 0, s, a, ep, start, nb); break;
+        default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
+      }
+      hipLaunchKernelGGL(nb_train_g_kernel, gg, blk, 0, s, a, nb, t->t_adam);
+    }
+    hipLaunchKernelGGL(nb_train_epoch_kernel, dim3(t->E), dim3(64), 0, s, a,
+                       t->t_adam);
   }
   NB_HIP_CHECK(hipGetLastError());
   if (status_host != nullptr) {

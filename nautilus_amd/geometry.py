@@ -42,18 +42,25 @@ def mvee(points, n_max=100, n_batch=20):
     q[:, d] = 1.0
     u = np.full(n, 1.0 / n)
     v = (q * u[:, None]).T @ q
-    v_inv = inv_spd(v)
     for _ in range(n_max):
+        # V^-1 is re-factorised once per sweep and then tracked through the
+        # <= n_batch rank-one updates with the Sherman-Morrison identity
+        # (the reference re-factorises after every update, basic.py:230)
+        v_inv = inv_spd(v)
         g_all = np.einsum('ij,ij->i', q @ v_inv, q)
         first = True
         for j in np.argsort(g_all)[-n_batch:][::-1]:
-            g = g_all[j] if first else q[j] @ v_inv @ q[j]
+            qj = q[j]
+            w = v_inv @ qj
+            g = g_all[j] if first else qj @ w
             first = False
             if g < d + 1:
                 continue
             step = (g - (d + 1)) / ((d + 1) * (g - 1))
-            v = v * (1 - step) + step * np.outer(q[j], q[j])
-            v_inv = inv_spd(v)
+            v = v * (1 - step) + step * np.outer(qj, qj)
+            ratio = step / (1 - step)
+            v_inv = (v_inv - np.outer(w, w) * (ratio / (1 + ratio * g))) / \
+                (1 - step)
             u *= (1 - step)
             u[j] += step
     c = np.atleast_1d(np.average(points, weights=u, axis=0))

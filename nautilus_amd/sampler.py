@@ -29,6 +29,7 @@ from time import time
 import numpy as np
 import torch
 from scipy.special import logsumexp
+from threadpoolctl import threadpool_limits
 
 from . import device
 from .bounds import NautilusBound, UnitCube
@@ -534,15 +535,20 @@ class Sampler:
             else:
                 pts = torch.cat([p.view() for p in self._pts])[
                     torch.from_numpy(order).cuda()]
-                bound = NautilusBound.compute(
-                    pts, log_l, log_l_min, self.log_v_live,
-                    enlarge_per_dim=self.enlarge_per_dim,
-                    n_points_min=self.n_points_min,
-                    split_threshold=self.split_threshold,
-                    n_networks=self.n_networks,
-                    neural_network_kwargs=self.neural_network_kwargs,
-                    pool=self.pool_s, rng=self.rng)
-                bound.sample(1000, return_points=False)
+                # host BLAS pinned to one thread as in the reference
+                # (sampler.py:1022): the construction works on tiny matrices
+                with threadpool_limits(limits=1):
+                    bound = NautilusBound.compute(
+                        pts, log_l, log_l_min, self.log_v_live,
+                        enlarge_per_dim=self.enlarge_per_dim,
+                        n_points_min=self.n_points_min,
+                        split_threshold=self.split_threshold,
+                        n_networks=self.n_networks,
+                        neural_network_kwargs=self.neural_network_kwargs,
+                        pool=self.pool_s, rng=self.rng)
+                    bound.sample(1000, return_points=False)
+                for key, val in bound.timing.items():
+                    self.timing[key] = self.timing.get(key, 0.0) + val
                 ok = bool(bound.log_v < self.bounds[-1].log_v)
                 if ok:
                     self.bounds.append(bound)
