@@ -191,6 +191,12 @@ int nb_trainer_destroy(nb_trainer* t);
 int nb_philox_uniform(uint64_t seed, uint64_t offset, uint32_t block,
                       uint32_t tag, int64_t n, double* u_dev, void* stream);
 
+/* Measurement hook for bench.py: when non-NULL, every bound-evaluation launch
+ * adds to counters_dev[0..2] the number of point evaluations it performed
+ * (outer-member tests, neural-ellipsoid transforms, emulator forward passes x
+ * networks) -- the algorithmic work of the roofline.  */
+int nb_set_eval_counters(uint64_t* counters_dev);
+
 /* fp64 MFMA issue-rate microbenchmark (peak calibration for bench.py):
  * returns achieved TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64.          */
 int nb_mfma_f64_peak(int32_t iters, double* tflops_host);

@@ -89,6 +89,7 @@ _SIGNATURES = {
     'nb_philox_uniform': (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32,
                                     C.c_uint32, C.c_int64, C.c_void_p,
                                     C.c_void_p]),
+    'nb_set_eval_counters': (C.c_int, [C.c_void_p]),
     'nb_mfma_f64_peak': (C.c_int, [C.c_int32, c_double_p]),
     'nb_ellipsoid_contains_stream': (C.c_int, [C.c_void_p, C.c_void_p,
                                                C.c_int64, C.c_void_p,

@@ -17,6 +17,7 @@ int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
                    int* out_i32, double* out_f64, unsigned long long seed,
                    unsigned long long offset, hipStream_t stream);
+void nb_eval_set_counters(unsigned long long* dev);
 int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
                    unsigned long long offset, long long n, double* x_out,
                    hipStream_t stream);
@@ -467,6 +468,11 @@ int nb_shell_stats(const double* log_l, int64_t n, double threshold,
 int nb_philox_uniform(uint64_t seed, uint64_t offset, uint32_t block,
                       uint32_t tag, int64_t n, double* u, void* stream) {
   return nb_launch_philox(seed, offset, block, tag, n, u, as_stream(stream));
+}
+
+int nb_set_eval_counters(uint64_t* counters_dev) {
+  nb_eval_set_counters((unsigned long long*)counters_dev);
+  return NB_OK;
 }
 
 int nb_mfma_f64_peak(int32_t iters, double* tflops) {

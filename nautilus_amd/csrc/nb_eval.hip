@@ -39,6 +39,9 @@ struct EvalArgs {
   double* out_f64;
   unsigned long long seed;
   unsigned long long offset;
+  unsigned long long* counters;   // optional: [0] outer-member point evals,
+                                  // [1] neural-ellipsoid point evals,
+                                  // [2] emulator point evals (x E networks)
 };
 
 enum { MODE_ANY = 0, MODE_ASSOC = 1, MODE_SAMPLE = 2, MODE_COUNT = 3,
@@ -183,10 +186,11 @@ __global__ void __launch_bounds__(256)
 nb_eval_kernel(EvalArgs a) {
   constexpr int DP = 16 * DT;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = lane >> 4;
   const long long n_tiles = (a.n + 15) >> 4;
   const long long stride = (long long)gridDim.x * 4;
+  unsigned long long cnt_outer = 0, cnt_ell = 0, cnt_mlp = 0;
 
   for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles;
        tile += stride) {
@@ -244,6 +248,8 @@ nb_eval_kernel(EvalArgs a) {
                                          lane, y, box_bad, false);
           k_cnt += (!box_bad && r2 < 1.0) ? 1 : 0;
         }
+        cnt_outer += (unsigned long long)K *
+                     __popcll(__ballot(active && lg == 0));
       }
       const bool outer_ok = in_cube && (K == 0 || k_cnt > 0);
 
@@ -276,6 +282,10 @@ nb_eval_kernel(EvalArgs a) {
           const bool inside_e = !box_bad && r2 < 1.0;
           bool ok = inside_e;
           const bool need = want && inside_e && !neural_ok;
+          cnt_ell += __popcll(__ballot(want && lg == 0));
+          cnt_mlp += (unsigned long long)E *
+                     __popcll(__ballot((need || (a.mode == MODE_SCORE && valid))
+                                       && lg == 0));
           if (E > 0 && (a.mode == MODE_SCORE || __any(need))) {
             const double thr = nb_m[nb_ell_block_size(DT)];
             const double score = mlp_score<DT>(nb_m, n_dim, E, kt1,
@@ -310,6 +320,11 @@ nb_eval_kernel(EvalArgs a) {
       }
     }
   }
+  if (a.counters != nullptr && lane == 0) {
+    atomicAdd(&a.counters[0], cnt_outer);
+    atomicAdd(&a.counters[1], cnt_ell);
+    atomicAdd(&a.counters[2], cnt_mlp);
+  }
 }
 
 template <int DT>
@@ -325,6 +340,9 @@ int launch_eval(const EvalArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+static unsigned long long* g_eval_counters = nullptr;
+void nb_eval_set_counters(unsigned long long* dev) { g_eval_counters = dev; }
+
 // host entry used by nb_api.cpp
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
@@ -334,6 +352,7 @@ int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
   a.blobs = blobs_dev; a.nb = nb; a.mode = mode; a.x = x; a.n = n;
   a.out_u8 = out_u8; a.out_i32 = out_i32; a.out_f64 = out_f64;
   a.seed = seed; a.offset = offset;
+  a.counters = g_eval_counters;
   if (n <= 0 || nb <= 0) return NB_OK;
   switch (dt) {
     case 1: launch_eval<1>(a, stream); break;

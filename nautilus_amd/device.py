@@ -274,3 +274,84 @@ def mfma_f64_peak(iters=20000):
     out = C.c_double(0.0)
     _lib.check(lib.nb_mfma_f64_peak(iters, C.byref(out)))
     return out.value
+
+
+class EvalCounters:
+    """Algorithmic-work counters of the bound-evaluation kernel (bench.py)."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self.buf = torch.zeros(4, dtype=torch.int64, device='cuda')
+
+    def __enter__(self):
+        self.buf.zero_()
+        _lib.check(self._lib.nb_set_eval_counters(_ptr(self.buf)))
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        _lib.check(self._lib.nb_set_eval_counters(None))
+
+    def read(self):
+        c = self.buf.cpu().numpy()
+        return dict(outer_point_evals=int(c[0]), ellipsoid_point_evals=int(c[1]),
+                    emulator_point_evals=int(c[2]))
+
+
+class KernelTimer:
+    """Per-kernel-family wall time on the current stream with HIP events
+    (torch.cuda.Event records on torch's current stream, which is the stream
+    every launch of this module uses)."""
+
+    active = None
+
+    def __init__(self):
+        self.events = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def totals(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.events.items():
+            out[name] = dict(launches=len(pairs),
+                             ms=sum(a.elapsed_time(b) for a, b in pairs))
+        return out
+
+
+def _timed(name):
+    def deco(fn):
+        def wrapper(*args, **kwargs):
+            timer = KernelTimer.active
+            if timer is None:
+                return fn(*args, **kwargs)
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(*args, **kwargs)
+            b.record()
+            timer.events.setdefault(name, []).append((a, b))
+            return out
+        wrapper.__name__ = fn.__name__
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
+
+
+DeviceBound.contains = _timed('nb_eval_kernel')(DeviceBound.contains)
+DeviceBound.accept = _timed('nb_eval_kernel')(DeviceBound.accept)
+DeviceBound.neural_score = _timed('nb_eval_kernel')(DeviceBound.neural_score)
+DeviceBound.propose = _timed('nb_draw_kernel')(DeviceBound.propose)
+DeviceBound.contains_stream = _timed('nb_ell_stream_kernel')(
+    DeviceBound.contains_stream)
+DeviceBoundList.contains_any = _timed('nb_eval_kernel')(
+    DeviceBoundList.contains_any)
+DeviceBoundList.first_containing = _timed('nb_eval_kernel')(
+    DeviceBoundList.first_containing)
+compact_rows = _timed('nb_compact')(compact_rows)
+shell_stats = _timed('nb_lse')(shell_stats)

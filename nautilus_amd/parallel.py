@@ -1,0 +1,96 @@
+"""Multi-GPU sharding of the shell-filling loop: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm).
+
+The reference's only parallel pattern on this path is "replicate the bound,
+draw independent streams, concatenate the accepted points and add up the
+counters" (nautilus/bounds/nautilus.py:223-237).
+The MI355X version of it:
+
+* every rank holds the (tiny) bound parameters and the full sampler state;
+* a batch of ``n_batch`` shell points is split into ``n_batch / world`` per
+  rank; each rank draws its share from its own Philox stream (key mixed with
+  the rank) and evaluates the likelihood for it;
+* ONE ``all_gather`` per batch moves the accepted points (+ their log L) to
+  every rank -- equal counts, so no padding -- and one ``all_reduce`` adds the
+  integer counters (``n_bound`` and the four MC-volume counters) that the
+  evidence depends on (sampler.py:1133, nautilus.py:232-237).
+
+There is no collective inside the kernels; bound construction is replicated
+(identical seeds give identical bounds on every rank).
+"""
+
+import torch
+import torch.distributed as dist
+
+_MIX = 0x9E3779B97F4A7C15
+
+
+def rank_key(seed, rank):
+    """Philox key of ``rank`` derived from the shared key (rank 0 keeps the
+    single-GPU stream)."""
+    return (int(seed) ^ ((rank * _MIX) & (2**63 - 1))) & (2**63 - 1)
+
+
+class ShardedComm:
+    """Thin wrapper of the collectives the sampler needs."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def gather_rows(self, rows):
+        """Concatenate equally sized (n_local, k) blocks of all ranks in rank
+        order."""
+        rows = rows.contiguous()
+        out = torch.empty((self.world * rows.shape[0],) + tuple(rows.shape[1:]),
+                          dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out, rows, group=self.group)
+        return out
+
+    def sum_ints(self, values, device):
+        """Element-wise sum of a short list of python ints over all ranks."""
+        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [int(v) for v in t.cpu()]
+
+    def max_float(self, value, device):
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.cpu()[0])
+
+    def assert_identical(self, values, device, what='state'):
+        """All ranks must hold bit-identical float values (replicated
+        exploration)."""
+        t = torch.tensor(list(values), dtype=torch.float64, device=device)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError('replicated %s diverged between ranks: %s vs %s'
+                               % (what, lo.tolist(), hi.tolist()))
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+def split_batch(n_batch, world):
+    """Per-rank share of a batch; the global batch must divide evenly so that
+    the all-gather needs no padding."""
+    if n_batch % world != 0:
+        raise ValueError('n_batch=%d must be a multiple of the number of '
+                         'ranks (%d)' % (n_batch, world))
+    return n_batch // world
+
+
+def shard_shell_batch(comm, local_rows, local_log_l, local_counts):
+    """Exchange one batch: returns (all rows, all log_l, summed counters).
+
+    local_rows (n_local, D) and local_log_l (n_local,) live on the same
+    device; local_counts is a list of python ints."""
+    packed = torch.cat([local_rows, local_log_l[:, None]], dim=1)
+    gathered = comm.gather_rows(packed)
+    totals = comm.sum_ints(local_counts, local_rows.device)
+    return gathered[:, :-1].contiguous(), gathered[:, -1].contiguous(), totals

@@ -76,7 +76,7 @@ class Sampler:
                  likelihood_args=[], likelihood_kwargs={}, n_batch=None,
                  n_like_new_bound=None, vectorized=False, pass_dict=None,
                  pool=None, seed=None, blobs_dtype=None, filepath=None,
-                 resume=True):
+                 resume=True, comm=None):
         if filepath is not None:
             raise NotImplementedError(
                 'checkpointing is not part of the device path yet '
@@ -171,6 +171,8 @@ class Sampler:
                                   device='cuda')
         self.shell_t = np.zeros(0, dtype=int)
         self.log_l_t = np.zeros(0)
+        self.comm = comm         # parallel.ShardedComm or None
+        self._sharded = False    # per-rank Philox keys active
         self._later = {}         # cache: shell index -> DeviceBoundList
         self.timing = dict(add_bound=0.0, sample_shell=0.0, likelihood=0.0,
                            bookkeeping=0.0)
@@ -346,10 +348,12 @@ class Sampler:
         shell = np.where(first >= 0, n_max - 1 - first, -1)
         return shell
 
-    def sample_shell(self, index, shell_t=None):
+    def sample_shell(self, index, shell_t=None, n_target=None):
         """Fill one batch of the shell ``index`` (sampler.py:751-830).
 
-        Returns (points on the device, n_bound[, idx_t])."""
+        Returns (points on the device, n_bound[, idx_t]).  ``n_target``
+        (default ``n_batch``) is this rank's share of the batch."""
+        n_target = self.n_batch if n_target is None else n_target
         if shell_t is not None and index not in [-1, len(self.bounds) - 1]:
             raise ValueError("'shell_t' must be empty list if not sampling "
                              "from the last bound/shell.")
@@ -362,8 +366,8 @@ class Sampler:
         idx_t = np.zeros(0, dtype=int)
         transfer = shell_t is not None and len(shell_t) > 0
 
-        while have < self.n_batch:
-            need = self.n_batch - have
+        while have < n_target:
+            need = n_target - have
             if transfer or later is None:
                 n_req = need             # every drawn point is in the shell
             else:
@@ -483,6 +487,7 @@ class Sampler:
         if verbose:
             self.print_status('Sampling', end='\r')
         t0 = time()
+        log_l = None
         if shell == -1 and len(self.shell_t) > 0:
             pts, n_bound, idx_t = self.sample_shell(-1, self.shell_t)
             assert pts.shape[0] + len(idx_t) == n_bound
@@ -493,11 +498,14 @@ class Sampler:
                     torch.from_numpy(self.log_l_t[idx_t]).cuda())
                 self.log_l[-1] = np.concatenate(
                     (self.log_l[-1], self.log_l_t[idx_t]))
+        elif self.comm is not None and self.comm.world > 1 and self.explored:
+            pts, log_l, log_l_dev, n_bound = self._sharded_batch(shell)
         else:
             pts, n_bound = self.sample_shell(shell)
         t1 = time()
         self.shell_n_sample[shell] += n_bound
-        log_l, log_l_dev = self.evaluate_likelihood(pts)
+        if log_l is None:
+            log_l, log_l_dev = self.evaluate_likelihood(pts)
         t2 = time()
         self._pts[shell].append(pts)
         self._ll_dev[shell].append(log_l_dev)
@@ -508,6 +516,42 @@ class Sampler:
         self.timing['likelihood'] += t2 - t1
         self.timing['bookkeeping'] += t3 - t2
         return int(np.sum(log_l >= self.shell_log_l_min[shell]))
+
+    def _sharded_batch(self, shell):
+        """One batch of the sampling phase spread over all ranks
+        (parallel.py): local draw + likelihood, one all-gather of the
+        accepted points, one all-reduce of the integer counters."""
+        from . import parallel
+        comm = self.comm
+        if not self._sharded:
+            # from here on every rank draws from its own Philox stream
+            for b in self.bounds:
+                b._stream.seed = parallel.rank_key(b._stream.seed, comm.rank)
+                if hasattr(b, '_queue'):
+                    b._queue().clear()
+            self._sharded = True
+        bound = self.bounds[shell]
+        counters = ['n_sample', 'n_reject']
+        owners = [bound] + ([bound.outer_bound]
+                            if hasattr(bound, 'outer_bound') else [])
+        owners = [o for o in owners if hasattr(o, 'n_sample')]
+        before = [getattr(o, c) for o in owners for c in counters]
+        n_local = parallel.split_batch(self.n_batch, comm.world)
+        pts, n_bound = self.sample_shell(shell, n_target=n_local)
+        n_like0 = self.n_like
+        _, ll_dev = self.evaluate_likelihood(pts)
+        self.n_like = n_like0
+        after = [getattr(o, c) for o in owners for c in counters]
+        delta = [a - b for a, b in zip(after, before)]
+        pts, ll_dev, totals = parallel.shard_shell_batch(
+            comm, pts, ll_dev, [n_bound] + delta)
+        self.n_like += pts.shape[0]
+        k = 0
+        for o in owners:
+            for c in counters:
+                setattr(o, c, before[k] + totals[1 + k])
+                k += 1
+        return pts, ll_dev.cpu().numpy(), ll_dev, totals[0]
 
     # ------------------------------------------------------------------
     # bounds

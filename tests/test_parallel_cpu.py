@@ -1,0 +1,64 @@
+"""World-size-2 test of the sharding collectives on the CPU (gloo)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nautilus_amd import parallel
+    comm = parallel.ShardedComm()
+    assert (comm.rank, comm.world) == (rank, world)
+
+    # a "batch": each rank contributes n_local rows drawn from its own stream
+    n_local, d = parallel.split_batch(8, world), 3
+    rng = np.random.default_rng(parallel.rank_key(1234, rank))
+    rows = torch.from_numpy(rng.random((n_local, d)))
+    log_l = torch.from_numpy(-rng.random(n_local))
+    counts = [10 + rank, 100 * (rank + 1), 7, 0, 1]
+    all_rows, all_ll, totals = parallel.shard_shell_batch(comm, rows, log_l,
+                                                          counts)
+    assert all_rows.shape == (8, d) and all_ll.shape == (8,)
+    # rank order is preserved and every rank sees the same result
+    assert torch.equal(all_rows[rank * n_local:(rank + 1) * n_local], rows)
+    assert torch.equal(all_ll[rank * n_local:(rank + 1) * n_local], log_l)
+    assert totals == [21, 300, 14, 0, 2]
+    comm.assert_identical([float(all_rows.sum()), float(all_ll.sum())],
+                          'cpu', 'gathered batch')
+    assert comm.max_float(float(rank), 'cpu') == world - 1
+    with pytest.raises(RuntimeError):
+        comm.assert_identical([float(rank)], 'cpu')
+    with pytest.raises(ValueError):
+        parallel.split_batch(7, world)
+    comm.barrier()
+    np.save(os.path.join(out_dir, 'rows_%d.npy' % rank), all_rows.numpy())
+    dist.destroy_process_group()
+
+
+def test_sharded_batch_two_ranks(tmp_path):
+    port = 29500 + os.getpid() % 1000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / 'rows_0.npy')
+    b = np.load(tmp_path / 'rows_1.npy')
+    assert np.array_equal(a, b)
+    # different ranks drew different points
+    assert not np.array_equal(a[:4], a[4:])
+
+
+def test_rank_keys_are_distinct():
+    from nautilus_amd import parallel
+    keys = {parallel.rank_key(987654321, r) for r in range(8)}
+    assert len(keys) == 8
+    assert parallel.rank_key(987654321, 0) == 987654321
+    assert all(0 <= k < 2**63 for k in keys)
