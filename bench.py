@@ -145,11 +145,14 @@ def roctx_region(resume):
     """Under ``rocprofv3 --selected-regions`` only the timed region is
     traced; a no-op otherwise."""
     import ctypes
-    try:
-        lib = ctypes.CDLL('librocprofiler-sdk-roctx.so')
+    for path in ('librocprofiler-sdk-roctx.so',
+                 '/opt/rocm/lib/librocprofiler-sdk-roctx.so'):
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError:
+            continue
         (lib.roctxProfilerResume if resume else lib.roctxProfilerPause)(0)
-    except OSError:
-        pass
+        return
 
 
 def main():

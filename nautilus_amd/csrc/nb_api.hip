@@ -79,7 +79,7 @@ bool fill_ell_block(std::vector<double>& buf, size_t at, int n_dim, int dt,
     return false;
   }
   put_i64(buf, at, m.n_ell);
-  double* lo = &buf[at + 1];
+  double* lo = &buf[at + 2];
   double* hi = lo + dp;
   double* c = hi + dp;
   double* tiles = c + dp;
@@ -191,11 +191,11 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   const int kt1 = (n_dim + 1 + 15) / 16;
   const int64_t ell_size = nb_ell_block_size(dt);
   const int64_t net_stride = (int64_t)nb_net_tiles(kt1) * NB_TILE;
-  const int64_t neural_stride = ell_size + 1 + 2 * dp + (int64_t)E * net_stride;
+  const int64_t neural_stride = ell_size + 2 + 2 * dp + (int64_t)E * net_stride;
   const int64_t draw_stride = 2 + 3 * dp + (int64_t)dp * (dp + 1) / 2;
 
   int64_t off = NB_HDR;
-  const int64_t off_cdf = off; off += (K > 0 ? K : 1);
+  const int64_t off_cdf = off; off += ((K > 0 ? K : 1) + 1) / 2 * 2;
   const int64_t off_ulo = off; off += dp;
   const int64_t off_uhi = off; off += dp;
   const int64_t off_members = off; off += (int64_t)K * ell_size;
@@ -294,7 +294,7 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
     if (!fill_ell_block(buf, at, n_dim, dt, nd.ellipsoid, true))
       return NB_ERR_ARG;
     buf[at + ell_size] = nd.score_predict_min - 1e-9;   // bounds/neural.py:125
-    double* mean = &buf[at + ell_size + 1];
+    double* mean = &buf[at + ell_size + 2];
     double* scale = mean + dp;
     for (int f = 0; f < dp; ++f) { mean[f] = 0.0; scale[f] = 1.0; }
     if (nd.mlp != nullptr) {

@@ -37,13 +37,14 @@ typedef double nb_d4 __attribute__((ext_vector_type(4)));
 //
 // Ell block (member of the outer union, or ellipsoid of a neural bound):
 //   [0]            n_ell (as int64 bits; 0 => pure cube member, no MFMA work)
-//   [1 .. 1+DP)    lo   per-dimension lower limit (0 for cube dims, -inf else)
+//   [1]            padding (keeps every tile 16-byte aligned)
+//   [2 .. 2+DP)    lo   per-dimension lower limit (0 for cube dims, -inf else)
 //   [..+DP)        hi   per-dimension upper limit (1 for cube dims, +inf else)
 //   [..+DP)        c    centre embedded in full-D order (0 for cube dims)
 //   [.. DT*DT tiles)  W0[k][h] = B_inv[h][k] embedded in full-D order, stored as
 //                  16x16 tiles [kt][ht], tile element (kk, hh) at kk*16+hh
 // Neural block = ell block, then:
-//   thr            score_predict_min - 1e-9 (bounds/neural.py:125)
+//   thr, pad       score_predict_min - 1e-9 (bounds/neural.py:125)
 //   mean[DP], inv_scale[DP]
 //   E nets, each: L1 tiles [KT1][7], L2 [7][4], L3 [4][2], L4 [2][1]
 //   (weights W_l[k][h] with the bias stored as row k = K_l; zero padded)
@@ -65,7 +66,7 @@ __host__ __device__ inline int64_t nb_hdr(const double* blob, int i) {
 }
 
 __host__ __device__ inline int nb_ell_block_size(int dt) {
-  return 1 + 3 * dt * 16 + dt * dt * NB_TILE;
+  return 2 + 3 * dt * 16 + dt * dt * NB_TILE;   // even => 16-byte aligned tiles
 }
 // tiles of one network given KT1
 __host__ __device__ inline int nb_net_tiles(int kt1) {

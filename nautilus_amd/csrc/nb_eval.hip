@@ -22,6 +22,16 @@
 // so activations never leave the registers between layers.  Weights are read
 // as A operands from 16x16 tile-major storage: one contiguous 512-byte row of
 // the tile per MFMA.
+//
+// Workgroup structure: 4 wavefronts x 2 tiles = 128 points per workgroup
+// pass.  Emulator weights are the bulk of the operand traffic (227 MFMAs per
+// tile and network, 132 KB of weights per network at D = 50), so a workgroup
+// stages them in LDS once per (bound, network) -- layer 1 first, then layers
+// 2-4 -- and all 8 tiles of the workgroup read their A operands from LDS
+// (conflict-free ds_read_b64); each wavefront shares every A operand between
+// its two tiles.  Measured: operand fetch from L2 was the bottleneck (12.9
+// TFLOP/s; 46.9 with the loads stubbed out).  The small ellipsoid factors are
+// read straight from L2.
 #include "nb_common.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -59,160 +69,180 @@ __device__ inline bool point_any(bool flag, int lane) {
   return ((b >> (lane & 15)) & 0x0001000100010001ull) != 0ull;
 }
 
-// y = B_inv (x - c) on the matrix cores plus the per-dimension box test.
-// Returns r2 = |y|^2 (replicated over the 4 lanes of a point); box_bad is set
-// if any coordinate violates the member's [lo, hi) limits.
+constexpr int TPW = 2;   // 16-point tiles per wavefront
+
+// y = B_inv (x - c) on the matrix cores plus the per-dimension box test, for
+// the TPW tiles of a wavefront (the A operand is shared).  r2 = |y|^2
+// (replicated over the 4 lanes of a point); box_bad is set if any coordinate
+// violates the member's [lo, hi) limits.
 template <int DT>
-__device__ __forceinline__ double ell_eval(const double* __restrict__ blk, int n_dim,
-                                  const double (&xin)[4 * DT], int lane,
-                                  double (&y)[4 * DT], bool& box_bad,
-                                  bool want_y) {
+__device__ __forceinline__ void ell_eval(const double* __restrict__ blk,
+                                         int n_dim,
+                                         const double (&xin)[TPW][4 * DT],
+                                         int lane, double (&y)[TPW][4 * DT],
+                                         bool (&box_bad)[TPW],
+                                         double (&r2)[TPW]) {
   constexpr int DP = 16 * DT;
-  const double* lo = blk + 1;
+  const double* lo = blk + 2;
   const double* hi = lo + DP;
   const double* c = hi + DP;
   const double* tiles = c + DP;
   const long long n_ell = ((const long long*)blk)[0];
   const int lg = lane >> 4;
 
-  double d[4 * DT];
-  bool bad = false;
+  double d[TPW][4 * DT];
+  bool bad[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) bad[t] = false;
 #pragma unroll
   for (int ks = 0; ks < 4 * DT; ++ks) {
     const int f = 4 * ks + lg;
-    const double xv = xin[ks];
-    bad |= !(xv >= lo[f] && xv < hi[f]);
-    d[ks] = xv - c[f];
+    const double lov = lo[f], hiv = hi[f], cv = c[f];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const double xv = xin[t][ks];
+      bad[t] |= !(xv >= lov && xv < hiv);
+      d[t][ks] = xv - cv;
+    }
   }
-  box_bad = point_any(bad, lane);
-
-  double part = 0.0;
+  double part[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    box_bad[t] = point_any(bad[t], lane);
+    part[t] = 0.0;
+  }
   if (n_ell > 0) {
 #pragma unroll
     for (int ht = 0; ht < DT; ++ht) {
       if (16 * ht < n_dim) {
-        nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        nb_d4 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 4 * (ht + 1); ++ks) {   // lower-triangular
           const int kt = ks >> 2, s = ks & 3;
           const double a = tiles[(kt * DT + ht) * NB_TILE + s * 64 + lane];
-          acc = MFMA(a, d[ks], acc);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = MFMA(a, d[t][ks], acc[t]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          y[4 * ht + r] = acc[r];
-          part += acc[r] * acc[r];
-        }
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            y[t][4 * ht + r] = acc[t][r];
+            part[t] += acc[t][r] * acc[t][r];
+          }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[4 * ht + r] = 0.0;
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[t][4 * ht + r] = 0.0;
       }
     }
-  } else if (want_y) {
+  } else {
 #pragma unroll
-    for (int ks = 0; ks < 4 * DT; ++ks) y[ks] = 0.0;
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4 * DT; ++ks) y[t][ks] = 0.0;
   }
-  return lane_group_sum(part);
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) r2[t] = lane_group_sum(part[t]);
 }
 
-// one dense layer on the matrix cores: out[h] = act(sum_k in[k] W[k][h]),
-// bias folded in as row k = K (the input carries a constant 1 there).
+// one dense layer on the matrix cores for both tiles of the wavefront:
+// out[h] = act(sum_k in[k] W[k][h]), bias folded in as row k = K (the input
+// carries a constant 1 there).  w points to LDS.
 template <int KSMAX, int HT, bool RELU>
-__device__ __forceinline__ void mlp_layer(const double* __restrict__ w,
-                                          int ks_n, const double* in, int lane,
-                                          double* out) {
+__device__ __forceinline__ void mlp_layer(const double* w, int ks_n,
+                                          const double* in0, const double* in1,
+                                          int lane, double* out0,
+                                          double* out1) {
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) {
-    nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
     for (int ks = 0; ks < KSMAX; ++ks) {
       if (ks < ks_n) {
         const int kt = ks >> 2, s = ks & 3;
+#ifdef NB_EXPERIMENT_NOLOAD
+        const double a = 1e-3 * (double)(lane + ks);   // dev experiment only
+#else
         const double a = w[(kt * HT + ht) * NB_TILE + s * 64 + lane];
-        acc = MFMA(a, in[ks], acc);
+#endif
+        acc0 = MFMA(a, in0[ks], acc0);
+        acc1 = MFMA(a, in1[ks], acc1);
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      out[4 * ht + r] = RELU ? fmax(acc[r], 0.0) : acc[r];
+    for (int r = 0; r < 4; ++r) {
+      out0[4 * ht + r] = RELU ? fmax(acc0[r], 0.0) : acc0[r];
+      out1[4 * ht + r] = RELU ? fmax(acc1[r], 0.0) : acc1[r];
+    }
   }
 }
 
-// Emulator score for the 16 points of the tile; y is the ellipsoid-frame
-// coordinate block.  Result valid in every lane (replicated per point).
+// cooperative global -> LDS copy by the whole workgroup (16 bytes per lane)
+__device__ __forceinline__ void stage_weights(const double* __restrict__ src,
+                                              double* dst, int n_doubles) {
+  for (int i = 2 * threadIdx.x; i < n_doubles; i += 2 * 256) {
+    const double2 v = *(const double2*)(src + i);
+    *(double2*)(dst + i) = v;
+  }
+}
+
+// B-operand block of the points: lane l holds feature 4*ks + (l >> 4) of
+// point (l & 15).  Re-read (L1/L2 hits) wherever it is needed instead of being
+// kept live across the emulator evaluation, which needs the registers.
 template <int DT>
-__device__ __forceinline__ double mlp_score(const double* __restrict__ nblk, int n_dim,
-                                   int n_net, int kt1, long long net_stride,
-                                   const double (&y)[4 * DT], int lane) {
-  constexpr int DP = 16 * DT;
-  constexpr int KS1MAX = 4 * DT + 1;
-  const double* mean = nblk + nb_ell_block_size(DT) + 1;
-  const double* scale = mean + DP;
-  const double* nets = scale + DP;
+__device__ __forceinline__ void load_points(const double* __restrict__ x,
+                                            const long long (&pt)[TPW],
+                                            const bool (&valid)[TPW],
+                                            int n_dim, int lane,
+                                            double (&xin)[TPW][4 * DT]) {
   const int lg = lane >> 4;
-  const int ks1 = (n_dim + 1 + 3) >> 2;
-
-  double t[KS1MAX];
 #pragma unroll
-  for (int ks = 0; ks < 4 * DT; ++ks) {
-    const int f = 4 * ks + lg;
-    t[ks] = (f < n_dim) ? (y[ks] - mean[f]) / scale[f]
-                        : ((f == n_dim) ? 1.0 : 0.0);
-  }
-  t[4 * DT] = (4 * (4 * DT) + lg == n_dim) ? 1.0 : 0.0;
-
-  double total = 0.0;
-  for (int e = 0; e < n_net; ++e) {
-    const double* w1 = nets + e * net_stride;
-    const double* w2 = w1 + kt1 * NB_HT1 * NB_TILE;
-    const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
-    const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
-    double h1[4 * NB_HT1], h2[4 * NB_HT2], h3[4 * NB_HT3], o[4];
-    mlp_layer<KS1MAX, NB_HT1, true>(w1, ks1, t, lane, h1);
-    if (lg == 0) h1[25] = 1.0;                       // bias unit 100
-    mlp_layer<26, NB_HT2, true>(w2, 26, h1, lane, h2);
-    if (lg == 2) h2[12] = 1.0;                       // bias unit 50
-    mlp_layer<13, NB_HT3, true>(w3, 13, h2, lane, h3);
-    if (lg == 0) h3[5] = 1.0;                        // bias unit 20
-    mlp_layer<6, 1, false>(w4, 6, h3, lane, o);
-    total += o[0];                                   // unit 0 lives in lg == 0
-  }
-  total = __shfl(total, lane & 15);                  // broadcast from lg == 0
-  return total / (double)n_net;
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4 * DT; ++ks) {
+      const int f = 4 * ks + lg;
+      xin[t][ks] = (valid[t] && f < n_dim) ? x[pt[t] * n_dim + f] : 0.0;
+    }
 }
 
 template <int DT>
 __global__ void __launch_bounds__(256)
 nb_eval_kernel(EvalArgs a) {
   constexpr int DP = 16 * DT;
+  constexpr int KS1MAX = 4 * DT + 1;
+  extern __shared__ __attribute__((aligned(16))) double wlds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = lane >> 4;
-  const long long n_tiles = (a.n + 15) >> 4;
-  const long long stride = (long long)gridDim.x * 4;
+  const long long n_super = (a.n + 16 * 4 * TPW - 1) / (16 * 4 * TPW);
   unsigned long long cnt_outer = 0, cnt_ell = 0, cnt_mlp = 0;
 
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles;
-       tile += stride) {
-    const long long pt = tile * 16 + (lane & 15);
-    const bool valid = pt < a.n;
+  const double* blob0 = a.blobs[0];
+  const int n_dim = (int)nb_hdr(blob0, NB_H_NDIM);
+  const int ks1 = (n_dim + 1 + 3) >> 2;
 
-    // geometry of the first blob gives n_dim (all blobs of a list agree)
-    const double* blob0 = a.blobs[0];
-    const int n_dim = (int)nb_hdr(blob0, NB_H_NDIM);
-
-    double xin[4 * DT];
+  for (long long sup = blockIdx.x; sup < n_super; sup += gridDim.x) {
+    long long pt[TPW];
+    bool valid[TPW];
 #pragma unroll
-    for (int ks = 0; ks < 4 * DT; ++ks) {
-      const int f = 4 * ks + lg;
-      xin[ks] = (valid && f < n_dim) ? a.x[pt * n_dim + f] : 0.0;
+    for (int t = 0; t < TPW; ++t) {
+      pt[t] = ((sup * 4 + wave) * TPW + t) * 16 + (lane & 15);
+      valid[t] = pt[t] < a.n;
     }
 
-    bool hit = false;       // MODE_ANY / ASSOC: some bound of the list contains
-    int hit_idx = -1;
-    unsigned char flags = 0;
-    int count_out = 0;
-    double r2_out = 0.0, score_out = 0.0;
+    bool hit[TPW];
+    int hit_idx[TPW], count_out[TPW];
+    unsigned char flags[TPW];
+    double r2_out[TPW], score_out[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      hit[t] = false; hit_idx[t] = -1; count_out[t] = 0; flags[t] = 0;
+      r2_out[t] = 0.0; score_out[t] = 0.0;
+    }
 
     for (int b = 0; b < a.nb; ++b) {
       const double* blob = a.blobs[b];
@@ -225,98 +255,204 @@ nb_eval_kernel(EvalArgs a) {
       const long long neural_stride = nb_hdr(blob, NB_H_NEURAL_STRIDE);
 
       // unit-cube clip of the union (union.py:287-288 / 313-314)
-      bool cbad = false;
+      bool in_cube[TPW], active[TPW];
+      int k_cnt[TPW];
+      {
+        double xin[TPW][4 * DT];
+        load_points<DT>(a.x, pt, valid, n_dim, lane, xin);
+        bool cbad[TPW];
 #pragma unroll
-      for (int ks = 0; ks < 4 * DT; ++ks) {
-        const int f = 4 * ks + lg;
-        cbad |= !(xin[ks] >= ulo[f] && xin[ks] < uhi[f]);
-      }
-      const bool in_cube = !point_any(cbad, lane);
-
-      const bool active = valid && !hit;
+        for (int t = 0; t < TPW; ++t) cbad[t] = false;
+#pragma unroll
+        for (int ks = 0; ks < 4 * DT; ++ks) {
+          const int f = 4 * ks + lg;
+          const double lov = ulo[f], hiv = uhi[f];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            cbad[t] |= !(xin[t][ks] >= lov && xin[t][ks] < hiv);
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          in_cube[t] = !point_any(cbad[t], lane);
+          active[t] = valid[t] && !hit[t];
+        }
 
       // ---- outer union: overlap count --------------------------------
-      int k_cnt = 0;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) k_cnt[t] = 0;
       const double* mblk = blob + nb_hdr(blob, NB_H_OFF_MEMBERS);
       if (a.mode == MODE_SAMPLE && K == 1) {
-        k_cnt = 1;            // drawn from the only member
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) k_cnt[t] = 1;   // drawn from the only member
       } else {
         for (int m = 0; m < K; ++m) {
-          double y[4 * DT];
-          bool box_bad;
-          const double r2 = ell_eval<DT>(mblk + m * ell_stride, n_dim, xin,
-                                         lane, y, box_bad, false);
-          k_cnt += (!box_bad && r2 < 1.0) ? 1 : 0;
+          double y[TPW][4 * DT], r2[TPW];
+          bool box_bad[TPW];
+          ell_eval<DT>(mblk + m * ell_stride, n_dim, xin, lane, y, box_bad,
+                       r2);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            k_cnt[t] += (!box_bad[t] && r2[t] < 1.0) ? 1 : 0;
         }
-        cnt_outer += (unsigned long long)K *
-                     __popcll(__ballot(active && lg == 0));
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          cnt_outer += (unsigned long long)K *
+                       __popcll(__ballot(active[t] && lg == 0));
       }
-      const bool outer_ok = in_cube && (K == 0 || k_cnt > 0);
-
-      // acceptance of the overlap-corrected union draw (union.py:318-319)
-      bool acc_outer = false;
-      if (a.mode == MODE_SAMPLE) {
-        double u0, u_acc;
-        nb_uniform_pair(a.seed, a.offset + (unsigned long long)pt, 0u,
-                        NB_TAG_CTRL, u0, u_acc);
-        acc_outer = in_cube && (u_acc > 1.0 - 1.0 / (double)k_cnt);
       }
 
-      // ---- neural bounds ----------------------------------------------
-      bool neural_ok = (M == 0);
-      bool want;
-      if (a.mode == MODE_SAMPLE) want = valid && acc_outer;
-      else if (a.mode == MODE_SCORE) want = valid;
-      else if (a.mode == MODE_COUNT) want = false;
-      else want = active && outer_ok;
-      if (M > 0 && __any(want)) {
+      bool outer_ok[TPW], acc_outer[TPW], neural_ok[TPW], want[TPW];
+      bool any_want = false;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        outer_ok[t] = in_cube[t] && (K == 0 || k_cnt[t] > 0);
+        // acceptance of the overlap-corrected union draw (union.py:318-319)
+        acc_outer[t] = false;
+        if (a.mode == MODE_SAMPLE) {
+          double u0, u_acc;
+          nb_uniform_pair(a.seed, a.offset + (unsigned long long)pt[t], 0u,
+                          NB_TAG_CTRL, u0, u_acc);
+          acc_outer[t] = in_cube[t] &&
+                         (u_acc > 1.0 - 1.0 / (double)k_cnt[t]);
+        }
+        neural_ok[t] = (M == 0);
+        if (a.mode == MODE_SAMPLE) want[t] = valid[t] && acc_outer[t];
+        else if (a.mode == MODE_SCORE) want[t] = valid[t];
+        else if (a.mode == MODE_COUNT) want[t] = false;
+        else want[t] = active[t] && outer_ok[t];
+        any_want |= want[t];
+      }
+
+      // ---- neural bounds (workgroup-uniform control flow) --------------
+      if (M > 0 && __syncthreads_or(any_want ? 1 : 0)) {
         const double* nblk = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
         const int kt1 = (int)nb_hdr(blob, NB_H_KT1);
         const long long net_stride = nb_hdr(blob, NB_H_NET_STRIDE);
+        const int n_a = kt1 * NB_HT1 * NB_TILE;                 // layer 1
+        const int n_b = (NB_HT1 * NB_HT2 + NB_HT2 * NB_HT3 + NB_HT3) * NB_TILE;
         for (int m = 0; m < M; ++m) {
           const double* nb_m = nblk + m * neural_stride;
-          double y[4 * DT];
-          bool box_bad;
-          const double r2 = ell_eval<DT>(nb_m, n_dim, xin, lane, y, box_bad,
-                                         true);
-          const bool inside_e = !box_bad && r2 < 1.0;
-          bool ok = inside_e;
-          const bool need = want && inside_e && !neural_ok;
-          cnt_ell += __popcll(__ballot(want && lg == 0));
-          cnt_mlp += (unsigned long long)E *
-                     __popcll(__ballot((need || (a.mode == MODE_SCORE && valid))
-                                       && lg == 0));
-          if (E > 0 && (a.mode == MODE_SCORE || __any(need))) {
-            const double thr = nb_m[nb_ell_block_size(DT)];
-            const double score = mlp_score<DT>(nb_m, n_dim, E, kt1,
-                                               net_stride, y, lane);
-            ok = inside_e && (score > thr);
-            if (m == 0) score_out = score;
+          double y[TPW][4 * DT], r2[TPW];
+          bool box_bad[TPW], inside_e[TPW], need[TPW];
+          {
+            double xin[TPW][4 * DT];
+            load_points<DT>(a.x, pt, valid, n_dim, lane, xin);
+            ell_eval<DT>(nb_m, n_dim, xin, lane, y, box_bad, r2);
           }
-          if (m == 0) r2_out = r2;
-          neural_ok |= ok;
+          bool wave_need = false;
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            inside_e[t] = !box_bad[t] && r2[t] < 1.0;
+            need[t] = want[t] && inside_e[t] && !neural_ok[t];
+            if (a.mode == MODE_SCORE) need[t] = valid[t];
+            cnt_ell += __popcll(__ballot(want[t] && lg == 0));
+            cnt_mlp += (unsigned long long)E *
+                       __popcll(__ballot(need[t] && lg == 0));
+            wave_need |= need[t];
+            if (m == 0) r2_out[t] = r2[t];
+          }
+          wave_need = __any(wave_need);
+          bool ok[TPW];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) ok[t] = inside_e[t];
+
+          if (E > 0 && __syncthreads_or(wave_need ? 1 : 0)) {
+            const double thr = nb_m[nb_ell_block_size(DT)];
+            const double* mean = nb_m + nb_ell_block_size(DT) + 2;
+            const double* scale = mean + DP;
+            const double* nets = scale + DP;
+            // standardised input (neural.py:115), constant 1 at column D
+            double tin[TPW][KS1MAX];
+#pragma unroll
+            for (int ks = 0; ks < 4 * DT; ++ks) {
+              const int f = 4 * ks + lg;
+              const double mv = mean[f], sv = scale[f];
+#pragma unroll
+              for (int t = 0; t < TPW; ++t)
+                tin[t][ks] = (f < n_dim) ? (y[t][ks] - mv) / sv
+                                         : ((f == n_dim) ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+              tin[t][4 * DT] = (16 * DT + lg == n_dim) ? 1.0 : 0.0;
+
+            double total[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) total[t] = 0.0;
+            for (int e = 0; e < E; ++e) {
+              const double* w1 = nets + e * net_stride;
+              double h1[TPW][4 * NB_HT1];
+              __syncthreads();                       // LDS free
+              stage_weights(w1, wlds, n_a);
+              __syncthreads();
+              if (wave_need) {
+                mlp_layer<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], tin[1],
+                                                lane, h1[0], h1[1]);
+                if (lg == 0) { h1[0][25] = 1.0; h1[1][25] = 1.0; }  // unit 100
+              }
+              __syncthreads();
+              stage_weights(w1 + n_a, wlds, n_b);
+              __syncthreads();
+              if (wave_need) {
+                const double* w2 = wlds;
+                const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
+                const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
+                double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
+                mlp_layer<26, NB_HT2, true>(w2, 26, h1[0], h1[1], lane, h2[0],
+                                            h2[1]);
+                if (lg == 2) { h2[0][12] = 1.0; h2[1][12] = 1.0; }  // unit 50
+                mlp_layer<13, NB_HT3, true>(w3, 13, h2[0], h2[1], lane, h3[0],
+                                            h3[1]);
+                if (lg == 0) { h3[0][5] = 1.0; h3[1][5] = 1.0; }    // unit 20
+                mlp_layer<6, 1, false>(w4, 6, h3[0], h3[1], lane, o[0], o[1]);
+                total[0] += o[0][0];               // unit 0 lives in lg == 0
+                total[1] += o[1][0];
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+              const double score =
+                  __shfl(total[t], lane & 15) / (double)E;
+              if (need[t]) ok[t] = inside_e[t] && (score > thr);
+              if (m == 0) score_out[t] = score;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) neural_ok[t] |= ok[t];
         }
       }
 
-      const bool contained = outer_ok && neural_ok;
+      bool all_done = true;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const bool contained = outer_ok[t] && neural_ok[t];
+        if (a.mode == MODE_ANY || a.mode == MODE_ASSOC) {
+          if (active[t] && contained) { hit[t] = true; hit_idx[t] = b; }
+          all_done &= (hit[t] || !valid[t]);
+        } else if (a.mode == MODE_SAMPLE) {
+          flags[t] = (acc_outer[t] ? 1 : 0) |
+                     ((acc_outer[t] && neural_ok[t]) ? 2 : 0);
+        } else if (a.mode == MODE_COUNT) {
+          count_out[t] = k_cnt[t];
+        }
+      }
       if (a.mode == MODE_ANY || a.mode == MODE_ASSOC) {
-        if (active && contained) { hit = true; hit_idx = b; }
-        if (__all(hit || !valid)) break;
-      } else if (a.mode == MODE_SAMPLE) {
-        flags = (acc_outer ? 1 : 0) | ((acc_outer && neural_ok) ? 2 : 0);
-      } else if (a.mode == MODE_COUNT) {
-        count_out = k_cnt;
+        if (__syncthreads_and(all_done ? 1 : 0)) break;
       }
     }
 
-    if (valid && lg == 0) {
-      if (a.mode == MODE_ANY) a.out_u8[pt] = hit ? 1 : 0;
-      else if (a.mode == MODE_ASSOC) a.out_i32[pt] = hit_idx;
-      else if (a.mode == MODE_SAMPLE) a.out_u8[pt] = flags;
-      else if (a.mode == MODE_COUNT) a.out_u8[pt] = (unsigned char)count_out;
-      else if (a.mode == MODE_SCORE) {
-        a.out_f64[2 * pt] = r2_out;
-        a.out_f64[2 * pt + 1] = score_out;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if (valid[t] && lg == 0) {
+        if (a.mode == MODE_ANY) a.out_u8[pt[t]] = hit[t] ? 1 : 0;
+        else if (a.mode == MODE_ASSOC) a.out_i32[pt[t]] = hit_idx[t];
+        else if (a.mode == MODE_SAMPLE) a.out_u8[pt[t]] = flags[t];
+        else if (a.mode == MODE_COUNT)
+          a.out_u8[pt[t]] = (unsigned char)count_out[t];
+        else if (a.mode == MODE_SCORE) {
+          a.out_f64[2 * pt[t]] = r2_out[t];
+          a.out_f64[2 * pt[t] + 1] = score_out[t];
+        }
       }
     }
   }
@@ -328,12 +464,29 @@ nb_eval_kernel(EvalArgs a) {
 }
 
 template <int DT>
-int launch_eval(const EvalArgs& a, hipStream_t stream) {
-  const long long n_tiles = (a.n + 15) >> 4;
-  long long blocks = (n_tiles + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
+  const int lds_tiles = (kt1_max * NB_HT1 > 38) ? kt1_max * NB_HT1 : 38;
+  const size_t lds = (size_t)lds_tiles * NB_TILE * sizeof(double);
+  static size_t lds_allowed = 0;
+  if (lds > lds_allowed) {
+    const hipError_t e = hipFuncSetAttribute(
+        (const void*)nb_eval_kernel<DT>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
+                   hipGetErrorString(e));
+      return NB_ERR_HIP;
+    }
+    lds_allowed = lds;
+  }
+  (void)hipGetLastError();
+  const long long n_super = (a.n + 16 * 4 * TPW - 1) / (16 * 4 * TPW);
+  // the kernel uses the whole register file (one wave per SIMD): one
+  // workgroup per CU, grid-stride over the 128-point super tiles
+  long long blocks = n_super;
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(nb_eval_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0,
+  hipLaunchKernelGGL(nb_eval_kernel<DT>, dim3((unsigned)blocks), dim3(256), lds,
                      stream, a);
   return NB_OK;
 }
@@ -354,19 +507,22 @@ int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
   a.seed = seed; a.offset = offset;
   a.counters = g_eval_counters;
   if (n <= 0 || nb <= 0) return NB_OK;
+  const int kt1 = dt + 1;     // upper limit of ceil((D + 1) / 16)
+  int rc = NB_OK;
   switch (dt) {
-    case 1: launch_eval<1>(a, stream); break;
-    case 2: launch_eval<2>(a, stream); break;
-    case 3: launch_eval<3>(a, stream); break;
-    case 4: launch_eval<4>(a, stream); break;
-    case 5: launch_eval<5>(a, stream); break;
-    case 6: launch_eval<6>(a, stream); break;
-    case 7: launch_eval<7>(a, stream); break;
-    case 8: launch_eval<8>(a, stream); break;
+    case 1: rc = launch_eval<1>(a, kt1, stream); break;
+    case 2: rc = launch_eval<2>(a, kt1, stream); break;
+    case 3: rc = launch_eval<3>(a, kt1, stream); break;
+    case 4: rc = launch_eval<4>(a, kt1, stream); break;
+    case 5: rc = launch_eval<5>(a, kt1, stream); break;
+    case 6: rc = launch_eval<6>(a, kt1, stream); break;
+    case 7: rc = launch_eval<7>(a, kt1, stream); break;
+    case 8: rc = launch_eval<8>(a, kt1, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;
   }
+  if (rc != NB_OK) return rc;
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;
 }

@@ -108,12 +108,19 @@ template <int DT>
 int launch(const double* cvec, const double* binv, int n_dim, const double* x,
            long long n, unsigned char* mask, hipStream_t stream) {
   const size_t lds = (size_t)4 * 64 * (n_dim | 1) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)nb_ell_stream_kernel<DT>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  static size_t lds_allowed = 0;
+  if (lds > lds_allowed) {
+    const hipError_t e = hipFuncSetAttribute(
+        (const void*)nb_ell_stream_kernel<DT>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
+                   hipGetErrorString(e));
+      return NB_ERR_HIP;
+    }
+    lds_allowed = lds;
   }
+  (void)hipGetLastError();
   const long long n_tiles = (n + 63) >> 6;
   long long blocks = (n_tiles + 3) / 4;
   const long long per_cu = (160 * 1024) / (long long)lds;

@@ -1,0 +1,186 @@
+"""Host-side logic of the product (no GPU): construction numerics against the
+oracle / golden vectors, Prior, pool wrapper, argument checking."""
+
+import numpy as np
+import pytest
+from scipy.stats import norm
+
+from conftest import load_golden
+
+
+@pytest.mark.parametrize('d', [3, 20, 50])
+def test_ellipsoid_construction_matches_reference(d):
+    from nautilus_amd import geometry
+    g = load_golden('ellipsoid_D%d' % d)
+    p = geometry.ellipsoid_params(g['points'], float(g['enlarge']))
+    assert np.allclose(p['c'], g['c'], rtol=0, atol=1e-9)
+    assert np.allclose(p['B'], g['B'], rtol=0, atol=1e-9)
+    assert np.allclose(p['B_inv'], g['B_inv'], rtol=1e-8, atol=1e-8)
+    assert np.all(np.triu(p['B_inv'], 1) == 0)
+    assert abs(geometry.ellipsoid_log_volume(p['B']) - float(g['log_v'])) < \
+        1e-8
+    # every input point is enclosed (basic.py:237-239)
+    y = (g['points'] - p['c']) @ p['B_inv'].T
+    assert np.all(np.sum(y**2, axis=1) < 1)
+
+
+def test_ellipsoid_volume_is_analytic():
+    # reference tests/test_bounds.py:136-145
+    from nautilus_amd import geometry
+    from scipy.special import gamma
+    d = 4
+    b = np.eye(d) * 0.3
+    assert np.isclose(geometry.ellipsoid_log_volume(b),
+                      np.log(0.3**d * np.pi**(d / 2) / gamma(d / 2 + 1)))
+
+
+def test_ellipsoid_errors():
+    from nautilus_amd import geometry
+    with pytest.raises(ValueError):
+        geometry.ellipsoid_params(np.random.random((3, 3)))
+    with pytest.raises(ValueError):
+        geometry.ellipsoid_params(np.random.random((30, 3)), 0.9)
+
+
+def test_mixture_construction_matches_reference():
+    from nautilus_amd import geometry
+    g = load_golden('mixture_D6')
+    dim_cube, ell = geometry.mixture_params(g['points'], 1.1)
+    assert np.array_equal(dim_cube, g['dim_cube'])
+    assert np.allclose(ell['B'], g['B'], rtol=0, atol=1e-9)
+    assert np.allclose(ell['c'], g['c'], rtol=0, atol=1e-9)
+
+
+def test_overlap_test_matches_oracle():
+    from nautilus_amd import geometry
+    from oracle import bounds_oracle as bo
+    rng = np.random.default_rng(0)
+    for shift in (0.05, 0.3, 3.0):
+        a = rng.normal(size=(200, 3)) * 0.1
+        b = rng.normal(size=(200, 3)) * 0.1 + shift
+        pa, pb = (geometry.ellipsoid_params(x, 1.0) for x in (a, b))
+        ea, eb = (bo.OEllipsoid.build(x, 1.0) for x in (a, b))
+        assert geometry.ellipsoids_overlap([pa, pb]) == \
+            bo.ellipsoids_overlap([ea, eb])
+    assert geometry.ellipsoids_overlap([pa, pb]) is False
+
+
+def test_glorot_init_is_sklearns():
+    from nautilus_amd import emulator
+    from oracle import mlp_oracle as mo
+    for seed in (0, 3):
+        c1, i1 = emulator._glorot(7, np.random.RandomState(seed))
+        c2, i2, _ = mo.glorot_init(7, seed)
+        for a, b in zip(c1 + i1, c2 + i2):
+            assert np.array_equal(a, b)
+
+
+def test_emulator_kwargs_translation():
+    from nautilus_amd import emulator
+    hp = emulator._hparams_from_kwargs(dict(learning_rate_init=1e-3,
+                                            max_iter=50, tol=1e-4))
+    assert hp == dict(lr=1e-3, max_iter=50, tol=1e-4)
+    assert emulator._hparams_from_kwargs(
+        dict(hidden_layer_sizes=(100, 50, 20), alpha=0)) == {}
+    with pytest.raises(NotImplementedError):
+        emulator._hparams_from_kwargs(dict(hidden_layer_sizes=(10, 10)))
+    with pytest.raises(NotImplementedError):
+        emulator._hparams_from_kwargs(dict(momentum=0.5))
+    with pytest.warns(Warning):
+        emulator._hparams_from_kwargs(dict(random_state=1))
+
+
+def test_prior_matches_reference_semantics():
+    # reference tests/test_prior.py
+    from nautilus_amd import Prior
+    prior = Prior()
+    prior.add_parameter('a')
+    prior.add_parameter('b', dist=(1, 3))
+    prior.add_parameter('c', dist=norm(loc=2.0, scale=0.5))
+    prior.add_parameter('d', dist=1.5)
+    prior.add_parameter('e', dist='a')
+    prior.add_parameter()
+    assert prior.keys[-1] == 'x_5'
+    assert prior.dimensionality() == 4
+    u = np.random.default_rng(0).random((10, 4))
+    phys = prior.unit_to_physical(u)
+    assert np.allclose(phys[:, 0], u[:, 0])
+    assert np.allclose(phys[:, 1], 1 + 2 * u[:, 1])
+    assert np.allclose(phys[:, 2], norm(loc=2.0, scale=0.5).ppf(u[:, 2]))
+    as_dict = prior.unit_to_dictionary(u)
+    assert np.all(as_dict['d'] == 1.5)
+    assert np.array_equal(as_dict['e'], as_dict['a'])
+    with pytest.raises(ValueError):
+        prior.unit_to_physical(u[:, :3])
+    with pytest.raises(ValueError):
+        prior.add_parameter('a')
+    with pytest.raises(TypeError):
+        prior.add_parameter(3)
+    with pytest.raises(ValueError):
+        prior.add_parameter('z', dist='nope')
+    with pytest.raises(TypeError):
+        prior.add_parameter('y', dist=[1, 2])
+
+
+def _square(x):
+    return x * x
+
+
+def test_pool_wrapper():
+    # reference nautilus/pool.py:65-107
+    from multiprocessing import Pool
+    from nautilus_amd import NautilusPool
+    p = NautilusPool(2)
+    try:
+        assert p.size == 2
+        assert p.map(_square, [1, 2, 3]) == [1, 4, 9]
+    finally:
+        p.pool.close()
+    with Pool(3) as raw:
+        assert NautilusPool(raw).size == 3
+
+    class Odd:
+        def map(self, f, it):
+            return map(f, it)
+    with pytest.raises(ValueError):
+        NautilusPool(Odd()).size
+
+
+def test_sampler_argument_errors():
+    from nautilus_amd import GaussianLikelihood, Prior, Sampler, unit_prior
+
+    def like(x):
+        return 0.0
+    with pytest.raises(ValueError):
+        Sampler(lambda x: x, like)                       # n_dim missing
+    with pytest.raises(ValueError):
+        Sampler(lambda x: x, like, n_dim=1)
+    with pytest.raises(NotImplementedError):
+        Sampler(lambda x: x, like, n_dim=2, filepath='x.hdf5')
+    dev_like = GaussianLikelihood(np.zeros(2) + 0.5, np.eye(2) * 0.01)
+    with pytest.raises(ValueError):
+        Sampler(lambda x: x, dev_like, n_dim=2)          # host prior
+    assert unit_prior.device is True
+    assert isinstance(Prior(), Prior)
+
+
+def test_shell_batch_prefix_rule_is_negative_binomial():
+    """The device driver stops at the n-th in-shell point of a block of
+    in-bound points; the reference loops with a shrinking deficit
+    (sampler.py:790-823).  Both must examine exactly the points up to and
+    including the n-th success."""
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        keep = rng.random(500) < 0.3
+        need = 20
+        # reference loop
+        pos, have, n_bound = 0, 0, 0
+        while have < need:
+            req = need - have
+            n_bound += req
+            have += int(keep[pos:pos + req].sum())
+            pos += req
+        # prefix rule
+        csum = np.cumsum(keep)
+        used = int(np.searchsorted(csum, need)) + 1
+        assert used == n_bound

