@@ -146,7 +146,7 @@ def test_bounds_protocol_like_reference_tests():
     sph = np.random.normal(size=(1000, 3))
     sph = sph / np.sqrt(np.sum(sph**2, axis=1))[:, None]
     sph *= np.random.uniform(size=1000)[:, None]**(1.0 / 3)
-    ell = Ellipsoid.compute(sph, enlarge_per_dim=1.0,
+    ell = Ellipsoid.compute(sph, enlarge_per_dim=1.0 + 1e-9,
                             rng=np.random.default_rng(0))
     assert np.all(ell.contains(sph))
     drawn = ell.sample(500)
