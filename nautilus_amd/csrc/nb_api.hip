@@ -204,7 +204,7 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   const bool single_full = (K == 1 && M == 0 && !d->unit_cube &&
                             d->members[0].n_ell == n_dim);
   const int64_t off_stream = off;
-  if (single_full) off += dp + (int64_t)dp * (dp + 1) / 2;
+  if (single_full) off += dp + (int64_t)dt * (dt + 1) / 2 * NB_TILE;
   const int64_t total = off;
 
   std::vector<double> buf((size_t)total, 0.0);
@@ -228,13 +228,25 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   put_i64(buf, NB_H_TOTAL, total);
   put_i64(buf, NB_H_OFF_STREAM, single_full ? off_stream : 0);
   if (single_full) {
+    // stream block: c, then lower-triangular tiles with the K permutation of
+    // nb_stream.hip (slot 4kt+s of lane group lg <-> feature
+    // 16kt + 8(s>>1) + 2lg + (s&1))
     const nb_member_desc& md = d->members[0];
-    for (int i = 0; i < n_dim; ++i) {
-      buf[off_stream + i] = md.c[i];
-      for (int j = 0; j <= i; ++j)
-        buf[off_stream + dp + (size_t)i * (i + 1) / 2 + j] =
-            md.B_inv[(size_t)i * n_dim + j];
-    }
+    for (int i = 0; i < n_dim; ++i) buf[off_stream + i] = md.c[i];
+    double* st = &buf[off_stream + dp];
+    for (int ht = 0; ht < dt; ++ht)
+      for (int kt = 0; kt <= ht; ++kt)
+        for (int s4 = 0; s4 < 4; ++s4)
+          for (int lg = 0; lg < 4; ++lg)
+            for (int li = 0; li < 16; ++li) {
+              const int k = 16 * kt + 8 * (s4 >> 1) + 2 * lg + (s4 & 1);
+              const int h = 16 * ht + li;
+              double v = 0.0;
+              if (h < n_dim && k < n_dim && k <= h)
+                v = md.B_inv[(size_t)h * n_dim + k];
+              st[((size_t)(ht * (ht + 1)) / 2 + kt) * NB_TILE + s4 * 64 +
+                 lg * 16 + li] = v;
+            }
   }
 
   // member CDF over softmax(log_v_all), union.py:308

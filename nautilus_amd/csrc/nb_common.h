@@ -33,7 +33,8 @@ typedef double nb_d4 __attribute__((ext_vector_type(4)));
 //   hdr[12] neural_stride   hdr[13] off_draw (K draw blocks)  hdr[14] draw_stride
 //   hdr[15] mlp_net_stride  hdr[16] KT1 (k-tiles of MLP layer 1 incl. bias row)
 //   hdr[17] total doubles   hdr[18] off_stream (single full ellipsoid only:
-//                           c[DP], B_inv packed lower-triangular row-major)
+//                           c[DP], then DT(DT+1)/2 K-permuted 16x16 tiles of
+//                           B_inv^T, see nb_stream.hip)
 //
 // Ell block (member of the outer union, or ellipsoid of a neural bound):
 //   [0]            n_ell (as int64 bits; 0 => pure cube member, no MFMA work)

@@ -3,152 +3,162 @@
 //     mask_i = | B_inv (x_i - c) |^2 < 1        (strict)
 //
 // Algorithmic traffic: 8*D bytes read + 1 byte written per point (SURVEY.md
-// section 8d).  B_inv is lower triangular (it is inv(cholesky(A^-1)),
-// basic.py:308-309), so a point costs D(D+1)/2 FMAs: at D = 50 that is 3.2
-// flop/byte, below the fp64 ridge of the chip (78.6 TF / 8 TB/s), i.e. the
-// kernel is HBM bound if the FMAs issue at >= ~50 % of peak.
+// section 8d); D(D+1) flop per point (B_inv is lower triangular: it is
+// inv(cholesky(A^-1)), basic.py:308-309).
 //
-// Design (CDNA4): one point per lane so the triangular mat-vec needs no
-// cross-lane traffic and wastes no flops on padding; the 64 x D tile of a
-// wavefront is fetched with coalesced 16-byte loads and transposed through LDS
-// (odd row stride => conflict-free ds_read_b64); B_inv and c are wave-uniform
-// and come in through scalar loads (SGPR operands of v_fma_f64), so the VALU
-// only issues FMAs.  The next tile's global loads are issued before the
-// current tile is computed.
+// Design (CDNA4).  Two VALU designs (one point per lane, B_inv through scalar
+// loads or LDS broadcasts) stalled at 20-26 % of HBM peak: 1275 distinct
+// matrix entries per 64 points cannot be fed to v_fma_f64 fast enough (SGPR
+// spills / LDS issue).  The matrix cores take the matrix as a *vector*
+// operand, so one 512-byte LDS read feeds 4 x 1024 FMAs:
+//  * a wavefront owns 4 (D <= 64) or 2 tiles of 16 points; rows of y = B_inv (x - c) are the
+//    MFMA rows, the points are the columns, K runs over the features;
+//  * B_inv lives in LDS as lower-triangular 16x16 tiles (20 KB at D = 50),
+//    loaded once per workgroup; every A operand is shared by the 4 tiles;
+//  * x is read exactly once with 16-byte loads: lane (li, lg) reads the pairs
+//    (8j + 2lg, 8j + 2lg + 1) of point li -- 64 contiguous bytes per point and
+//    instruction -- and the K index of the MFMA is permuted to match (the
+//    host packs the tiles with the same permutation), so no transpose is
+//    needed anywhere;
+//  * r^2 is reduced over the 4 lanes of a point with two xor-shuffles.
 #include "nb_common.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 namespace {
 
-template <int DT>
-__global__ void __launch_bounds__(256)
+template <int DT, int TPW>
+__global__ void __launch_bounds__(256, 2)
 nb_ell_stream_kernel(const double* __restrict__ cvec,
-                     const double* __restrict__ binv,   // packed lower, row-major
+                     const double* __restrict__ tiles,   // permuted, lower-tri
                      int n_dim, const double* __restrict__ x, long long n,
                      unsigned char* __restrict__ mask) {
-  constexpr int DP = 16 * DT;
-  constexpr int NQ = DP / 2;          // 16-byte loads per lane per tile (max)
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NT = DT * (DT + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double wl[NT * NB_TILE];
+  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 512)
+    *(double2*)(wl + i) = *(const double2*)(tiles + i);
+  __syncthreads();
+
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int S = n_dim | 1;            // odd row stride in doubles
-  double* tile_lds = lds + (size_t)wave * 64 * S;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const bool even = (n_dim & 1) == 0;
 
-  // (row, col) of element e = 2*lane inside a tile, advanced by 128 per step
-  const int row0 = (2 * lane) / n_dim;
-  const int col0 = (2 * lane) - row0 * n_dim;
-  const int drow = 128 / n_dim;
-  const int dcol = 128 - drow * n_dim;
-  const int nq = (64 * n_dim + 127) / 128;
-
-  const long long n_tiles = (n + 63) >> 6;
-  const long long n_rounds = (n_tiles + 4LL * gridDim.x - 1) / (4LL * gridDim.x);
-
-  for (long long it = 0; it < n_rounds; ++it) {
-    const long long tile = (it * gridDim.x + blockIdx.x) * 4 + wave;
-    const long long p0 = tile * 64;
-    long long cnt = (n - p0) * n_dim;              // elements left
-    if (cnt > 64LL * n_dim) cnt = 64LL * n_dim;
-    const double* src = x + p0 * n_dim;
-
-    // coalesced 16-byte loads of the contiguous 64 x D block
-    double2 stage[NQ];
+  // centre in the permuted K order: slot (2j + o) <-> feature 8j + 2lg + o
+  double cper[4 * DT];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const long long e = 2LL * (lane + 64 * q);
-      stage[q] = make_double2(0.0, 0.0);
-      if (q < nq && tile < n_tiles) {
-        if (e + 1 < cnt) stage[q] = *(const double2*)(src + e);
-        else if (e < cnt) stage[q].x = src[e];
+  for (int j = 0; j < 2 * DT; ++j) {
+    const int f = 8 * j + 2 * lg;
+    cper[2 * j] = cvec[f];              // cvec is zero padded to 16*DT
+    cper[2 * j + 1] = cvec[f + 1];
+  }
+
+  const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
+  for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_groups;
+       grp += (long long)gridDim.x * 4) {
+    // branch-free loads: out-of-range rows / columns are clamped to a valid
+    // address and zeroed by a select, so all loads of a group issue
+    // back to back
+    double d[TPW][4 * DT];
+    if (even) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const long long pt = (grp * TPW + t) * 16 + li;
+        const bool ok = pt < n;
+        const double* row = x + (ok ? pt : n - 1) * n_dim;
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) {
+          const int f = 8 * j + 2 * lg;
+          const bool in = ok && f < n_dim;
+          const double2 v = *(const double2*)(row + (f < n_dim ? f : n_dim - 2));
+          d[t][2 * j] = (in ? v.x : 0.0) - cper[2 * j];
+          d[t][2 * j + 1] = (in ? v.y : 0.0) - cper[2 * j + 1];
+        }
       }
-    }
-    __syncthreads();                  // previous tile fully consumed
-    {
-      int row = row0, col = col0;
+    } else {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (q < nq) {
-          if (row < 64) tile_lds[row * S + col] = stage[q].x;
-          int rw2 = row, c2 = col + 1;
-          if (c2 == n_dim) { c2 = 0; ++rw2; }
-          if (rw2 < 64) tile_lds[rw2 * S + c2] = stage[q].y;
-          row += drow; col += dcol;
-          if (col >= n_dim) { col -= n_dim; ++row; }
+      for (int t = 0; t < TPW; ++t) {
+        const long long pt = (grp * TPW + t) * 16 + li;
+        const bool ok = pt < n;
+        const double* row = x + (ok ? pt : n - 1) * n_dim;
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) {
+          const int f = 8 * j + 2 * lg;
+          const double v0 = row[f < n_dim ? f : n_dim - 1];
+          const double v1 = row[f + 1 < n_dim ? f + 1 : n_dim - 1];
+          d[t][2 * j] = ((ok && f < n_dim) ? v0 : 0.0) - cper[2 * j];
+          d[t][2 * j + 1] = ((ok && f + 1 < n_dim) ? v1 : 0.0) - cper[2 * j + 1];
         }
       }
     }
-    __syncthreads();
 
-    // one point per lane: d = x - c, y_i = sum_{j<=i} Binv[i][j] d_j
-    double d[DP];
+    double part[TPW];
 #pragma unroll
-    for (int j = 0; j < DP; ++j)
-      d[j] = (j < n_dim) ? tile_lds[lane * S + j] - cvec[j] : 0.0;
-    double r2 = 0.0;
+    for (int t = 0; t < TPW; ++t) part[t] = 0.0;
 #pragma unroll
-    for (int i = 0; i < DP; ++i) {
-      if (i < n_dim) {
-        const double* brow = binv + (i * (i + 1)) / 2;
-        double y0 = 0.0, y1 = 0.0;
+    for (int ht = 0; ht < DT; ++ht) {
+      if (16 * ht < n_dim) {
+        nb_d4 acc[TPW];
 #pragma unroll
-        for (int j = 0; j + 1 <= i; j += 2) {
-          y0 = fma(brow[j], d[j], y0);
-          y1 = fma(brow[j + 1], d[j + 1], y1);
+        for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4 * (ht + 1); ++ks) {     // lower-triangular
+          const int kt = ks >> 2, s = ks & 3;
+          const double a =
+              wl[((ht * (ht + 1)) / 2 + kt) * NB_TILE + s * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = MFMA(a, d[t][ks], acc[t]);
         }
-        if ((i & 1) == 0) y0 = fma(brow[i], d[i], y0);
-        const double y = y0 + y1;
-        r2 = fma(y, y, r2);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[t] = fma(acc[t][r], acc[t][r], part[t]);
       }
     }
-    const long long pt = p0 + lane;
-    if (pt < n) mask[pt] = (r2 < 1.0) ? 1 : 0;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      double r2 = part[t];
+      r2 += __shfl_xor(r2, 16);
+      r2 += __shfl_xor(r2, 32);
+      const long long pt = (grp * TPW + t) * 16 + li;
+      if (lg == 0 && pt < n) mask[pt] = (r2 < 1.0) ? 1 : 0;
+    }
   }
 }
 
 template <int DT>
-int launch(const double* cvec, const double* binv, int n_dim, const double* x,
+int launch(const double* cvec, const double* tiles, int n_dim, const double* x,
            long long n, unsigned char* mask, hipStream_t stream) {
-  const size_t lds = (size_t)4 * 64 * (n_dim | 1) * sizeof(double);
-  static size_t lds_allowed = 0;
-  if (lds > lds_allowed) {
-    const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_ell_stream_kernel<DT>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
-                   hipGetErrorString(e));
-      return NB_ERR_HIP;
-    }
-    lds_allowed = lds;
-  }
-  (void)hipGetLastError();
-  const long long n_tiles = (n + 63) >> 6;
-  long long blocks = (n_tiles + 3) / 4;
-  const long long per_cu = (160 * 1024) / (long long)lds;
-  const long long cap = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-  if (blocks > cap) blocks = cap;
+  // 4 tiles per wavefront while the operands fit the register file
+  constexpr int TPW = (DT <= 4) ? 4 : 2;
+  const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
+  long long blocks = (n_groups + 3) / 4;
+  if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(nb_ell_stream_kernel<DT>, dim3((unsigned)blocks),
-                     dim3(256), lds, stream, cvec, binv, n_dim, x, n, mask);
+  hipLaunchKernelGGL((nb_ell_stream_kernel<DT, TPW>), dim3((unsigned)blocks),
+                     dim3(256), 0, stream, cvec, tiles, n_dim, x, n, mask);
   return NB_OK;
 }
 
 }  // namespace
 
-// cvec / binv point into the stream block of the blob (nb_common.h hdr[18]).
-int nb_launch_ell_stream(const double* cvec, const double* binv, int n_dim,
+// cvec / tiles point into the stream block of the blob (nb_common.h hdr[18]):
+// c zero padded to 16*DT, then DT(DT+1)/2 lower-triangular 16x16 tiles of
+// W0[k][h] = B_inv[h][k] with the K permutation described above.
+int nb_launch_ell_stream(const double* cvec, const double* tiles, int n_dim,
                          const double* x, long long n, unsigned char* mask,
                          hipStream_t stream) {
   if (n <= 0) return NB_OK;
   const int dt = (n_dim + 15) / 16;
   switch (dt) {
-    case 1: launch<1>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 2: launch<2>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 3: launch<3>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 4: launch<4>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 5: launch<5>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 6: launch<6>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 7: launch<7>(cvec, binv, n_dim, x, n, mask, stream); break;
-    case 8: launch<8>(cvec, binv, n_dim, x, n, mask, stream); break;
+    case 1: launch<1>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 2: launch<2>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 3: launch<3>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 4: launch<4>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 5: launch<5>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 6: launch<6>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 7: launch<7>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 8: launch<8>(cvec, tiles, n_dim, x, n, mask, stream); break;
     default:
       nb_set_error("n_dim > 128 unsupported");
       return NB_ERR_UNSUPPORTED;
