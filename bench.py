@@ -44,8 +44,11 @@ def parse():
     p.add_argument('--warmup', type=int, default=3)
     p.add_argument('--dim', type=int, default=50)
     p.add_argument('--n-live', type=int, default=2000)
-    p.add_argument('--n-batch', type=int, default=8192,
-                   help='shell points per step and GPU')
+    p.add_argument('--n-batch', type=int, default=65536,
+                   help='shell points per timed step and GPU')
+    p.add_argument('--n-batch-setup', type=int, default=8192,
+                   help='batch size while the bounds are built and every '
+                        'shell receives its first batch (untimed setup)')
     p.add_argument('--n-networks', type=int, default=4)
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -179,8 +182,9 @@ def main():
     d = args.dim
     like = GaussianLikelihood(np.full(d, 0.5), np.eye(d) * 0.05**2)
     sampler = Sampler(unit_prior, like, n_dim=d, n_live=args.n_live,
-                      n_networks=args.n_networks, n_batch=args.n_batch,
-                      vectorized=True, seed=args.seed, comm=comm)
+                      n_networks=args.n_networks,
+                      n_batch=args.n_batch_setup, vectorized=True,
+                      seed=args.seed, comm=comm)
 
     # ---- setup: build the bound hierarchy (exploration, untimed) ---------
     t_setup = time.time()
@@ -195,7 +199,7 @@ def main():
         comm.assert_identical([sampler.log_z or 0.0, sampler.n_like,
                                len(sampler.bounds)], 'cuda',
                               'exploration state')
-        sampler.n_batch = args.n_batch * world
+        sampler.n_batch = args.n_batch_setup * world
 
     def step():
         if np.any(sampler.shell_n < 1):
@@ -214,6 +218,7 @@ def main():
         step()
     torch.cuda.synchronize()
     fill_s = time.time() - t_fill
+    sampler.n_batch = args.n_batch * world       # batch of the timed steps
     for _ in range(args.warmup):
         step()
 
@@ -266,6 +271,7 @@ def main():
                              'prior, sampling-phase add_samples steps' % d,
                     n_dim=d, n_live=args.n_live, n_networks=e,
                     n_batch_per_gpu=args.n_batch,
+                    n_batch_setup=args.n_batch_setup,
                     n_batch_global=args.n_batch * world,
                     discard_exploration=True, seed=args.seed),
         log_z=float(sampler.log_z), abs_dlogz=abs(float(sampler.log_z)),

@@ -176,10 +176,14 @@ int nb_trainer_set_hparams(nb_trainer* t, double lr, double beta1,
                            int32_t max_iter, int32_t n_iter_no_change,
                            double tol);
 /* Run up to n_epochs epochs; perm_dev holds n_networks*n_epochs*n_rows int32
- * row orders (network-major).  status_host[e] receives n_iter so far, or
- * -n_iter when network e has stopped.                                       */
+ * row orders (network-major) and must stay alive until the work has finished.
+ * status_host[e] receives n_iter so far, or -n_iter when network e has
+ * stopped; with status_host == NULL the call only enqueues (asynchronous).   */
 int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
                    int32_t* status_host, void* stream);
+/* Wait for the launches enqueued by nb_trainer_run(..., status_host = NULL)
+ * and read the per-network status (same encoding).                          */
+int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream);
 int nb_trainer_loss_curve(nb_trainer* t, int32_t net, double* out_host,
                           int32_t max_len);
 int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs_host,

@@ -80,6 +80,7 @@ _SIGNATURES = {
                                          C.c_int32, C.c_int32, C.c_double]),
     'nb_trainer_run': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
                                  c_int32_p, C.c_void_p]),
+    'nb_trainer_status': (C.c_int, [C.c_void_p, c_int32_p, C.c_void_p]),
     'nb_trainer_loss_curve': (C.c_int, [C.c_void_p, C.c_int32, c_double_p,
                                         C.c_int32]),
     'nb_trainer_weights': (C.c_int, [C.c_void_p, C.c_int32,

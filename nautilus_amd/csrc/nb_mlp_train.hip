@@ -110,13 +110,119 @@ __device__ __forceinline__ void put_stash(double* __restrict__ base, int ld,
 //   nb_train_g_kernel   grid (weight tiles, networks), 1 wave
 // and one nb_train_epoch_kernel per epoch for the stopping rule.
 // ---------------------------------------------------------------------------
+// ---- FB: forward + backward deltas of one 16-row tile ---------------------
+// Four wavefronts share the tile: every layer's output tiles are split over
+// the wavefronts and the activations / deltas are exchanged through LDS in
+// [unit][row] layout (the B operand of the next layer is then one contiguous
+// 512-byte read), which cuts the dependent MFMA chain of a tile from ~340 to
+// ~100 instructions.
+constexpr int LS = 17;   // LDS row stride (odd: conflict-free both ways)
+
+template <int NREG>
+__device__ __forceinline__ void lds_operand(const double* act, int lane,
+                                            double* in) {
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < NREG; ++ks) in[ks] = act[(4 * ks + lg) * LS + li];
+}
+
+// cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows)
+__device__ __forceinline__ void flush_stash(const double* act, double* dst,
+                                            int ld, int n_unit, int tile) {
+  for (int i = threadIdx.x; i < 16 * n_unit; i += 256) {
+    const int r = i / n_unit, u = i - r * n_unit;
+    dst[(long long)(tile * 16 + r) * ld + u] = act[u * LS + r];
+  }
+}
+
+// A operands of one forward output tile, loaded up front
+template <int KSMAX>
+__device__ __forceinline__ void load_fwd(const double* __restrict__ w, int ht_n,
+                                         int ht, int ks_n, int lane,
+                                         double* wr) {
+#pragma unroll
+  for (int ks = 0; ks < KSMAX; ++ks)
+    wr[ks] = (ks < ks_n)
+        ? w[((ks >> 2) * ht_n + ht) * NB_TILE + (ks & 3) * 64 + lane] : 0.0;
+}
+
+// A operands of one backward output tile (transposed access)
+template <int HS>
+__device__ __forceinline__ void load_bwd(const double* __restrict__ w, int ht_n,
+                                         int kt, int lane, double* wr) {
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int hs = 0; hs < HS; ++hs) {
+    const int h0 = 4 * hs;
+    wr[hs] = w[(kt * ht_n + (h0 >> 4)) * NB_TILE + li * 16 + (h0 & 15) + lg];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ nb_d4 mma(const double* wr, const double* in) {
+  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+  for (int k = 0; k + 1 < N; k += 2) {
+    acc0 = MFMA(wr[k], in[k], acc0);
+    acc1 = MFMA(wr[k + 1], in[k + 1], acc1);
+  }
+  if (N & 1) acc0 = MFMA(wr[N - 1], in[N - 1], acc0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+  return acc0;
+}
+
+// forward output tile `ht`: acc = sum_ks W[ks][ht] * in[ks]
+template <int KSMAX>
+__device__ __forceinline__ nb_d4 fwd_tile(const double* __restrict__ w,
+                                          int ht_n, int ht, int ks_n,
+                                          const double* in, int lane) {
+  nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < KSMAX; ++ks) {
+    if (ks < ks_n) {
+      const double a = w[((ks >> 2) * ht_n + ht) * NB_TILE + (ks & 3) * 64 + lane];
+      acc = MFMA(a, in[ks], acc);
+    }
+  }
+  return acc;
+}
+
+// backward output tile `kt`: acc = sum_hs W[kt][hs]^T * dout[hs]
+template <int HS>
+__device__ __forceinline__ nb_d4 bwd_tile(const double* __restrict__ w,
+                                          int ht_n, int kt, const double* dout,
+                                          int lane) {
+  const int li = lane & 15, lg = lane >> 4;
+  nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int hs = 0; hs < HS; ++hs) {
+    const int h0 = 4 * hs;
+    const double a = w[(kt * ht_n + (h0 >> 4)) * NB_TILE + li * 16 +
+                       (h0 & 15) + lg];
+    acc = MFMA(a, dout[hs], acc);
+  }
+  return acc;
+}
+
 template <int DT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   constexpr int KS1MAX = 4 * DT + 1;
+  constexpr int LD0MAX = 16 * (DT + 1);
+  // activations / deltas of the tile in [unit][row] layout
+  __shared__ __attribute__((aligned(16))) double sA0[LD0MAX * LS];
+  __shared__ __attribute__((aligned(16))) double sA1[LD1 * LS];
+  __shared__ __attribute__((aligned(16))) double sA2[LD2 * LS];
+  __shared__ __attribute__((aligned(16))) double sA3[LD3 * LS];
+  __shared__ __attribute__((aligned(16))) double sD4[LD4 * LS];
+  __shared__ __attribute__((aligned(16))) double sD3[LD3 * LS];
+  __shared__ __attribute__((aligned(16))) double sD2[LD2 * LS];
+
   const NetState st = a.nets[blockIdx.y];
   if (st.scal[4] != 0.0) return;                 // network already stopped
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int D = a.n_dim, kt1 = a.kt1;
   const int ld0 = 16 * kt1;
@@ -142,56 +248,166 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   const bool valid = pt < nb;
   const long long row = valid ? perm[start + pt] : 0;
 
-  double t[KS1MAX];
+  // ---- every weight operand this wavefront will need, loaded up front: the
+  // loads do not depend on the other wavefronts, so their latency overlaps
+  // with the input gather instead of being paid after every barrier --------
+  double w1r[2][KS1MAX], w2r[26], w3r[13], w4r[6], b4r[1], b3r[5], b2r[2][13];
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
+    load_fwd<KS1MAX>(W1, NB_HT1, ht, ks1, lane, w1r[rep]);
+    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
+  }
+  load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
+  load_fwd<13>(W3, NB_HT3, wave & 1, 13, lane, w3r);
+  load_fwd<6>(W4, 1, 0, 6, lane, w4r);
+  load_bwd<1>(W4, 1, wave & 1, lane, b4r);
+  load_bwd<5>(W3, NB_HT3, wave, lane, b3r);
+
+  // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
+  // (all of it: rows >= ld0 are multiplied by zero weights and must not
+  // hold NaN bit patterns)
+  for (int i = threadIdx.x; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
+  __syncthreads();
 #pragma unroll
   for (int ks = 0; ks < KS1MAX; ++ks) {
-    const int f = 4 * ks + lg;
-    t[ks] = (f < D) ? (valid ? a.X[row * D + f] : 0.0)
-                    : ((f == D) ? 1.0 : 0.0);
+    if ((ks & 3) == wave && 4 * ks < ld0) {
+      const int f = 4 * ks + lg;
+      const double v = (f < D) ? (valid ? a.X[row * D + f] : 0.0)
+                               : ((f == D) ? 1.0 : 0.0);
+      sA0[f * LS + li] = v;
+    }
   }
-#pragma unroll
-  for (int ks = 0; ks < KS1MAX; ++ks)
-    if (4 * ks < ld0) A0[(long long)pt * ld0 + 4 * ks + lg] = t[ks];
+  __syncthreads();
 
-  // forward; every layer's activations go to the stash for the G kernel
-  double h1[4 * NB_HT1], h2[4 * NB_HT2], h3[4 * NB_HT3], o[4];
-  fwd_layer<KS1MAX, NB_HT1>(W1, ks1, t, lane, h1, true);
-  if (lg == 0) h1[25] = 1.0;
-  put_stash<4 * NB_HT1>(A1, LD1, pt, lane, h1);
-  fwd_layer<26, NB_HT2>(W2, 26, h1, lane, h2, true);
-  if (lg == 2) h2[12] = 1.0;
-  put_stash<4 * NB_HT2>(A2, LD2, pt, lane, h2);
-  fwd_layer<13, NB_HT3>(W3, 13, h2, lane, h3, true);
-  if (lg == 0) h3[5] = 1.0;
-  put_stash<4 * NB_HT3>(A3, LD3, pt, lane, h3);
-  fwd_layer<6, 1>(W4, 6, h3, lane, o, false);
+  // ---- layer 1: output tiles wave, wave + 4 ------------------------------
+  {
+    double in[KS1MAX];
+    lds_operand<KS1MAX>(sA0, lane, in);
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int ht = wave + 4 * rep;
+      if (ht < NB_HT1) {
+        const nb_d4 acc = mma<KS1MAX>(w1r[rep], in);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = fmax(acc[r], 0.0);
+          const int unit = 16 * ht + 4 * r + lg;
+          if (unit == NB_H1) v = 1.0;                    // bias unit
+          sA1[unit * LS + li] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
 
-  // output delta (sklearn :365) and the squared-loss partial of this tile
-  double d4[4] = {0.0, 0.0, 0.0, 0.0};
-  if (lg == 0 && valid) d4[0] = o[0] - a.y[row];
-  put_stash<4>(D4, LD4, pt, lane, d4);
-  double lp = 0.5 * d4[0] * d4[0];
-  for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
-  if (lane == 0) st.scal[8 + tile] = lp;
+  // ---- layer 2: output tile = wave ----------------------------------------
+  {
+    double in[26];
+    lds_operand<26>(sA1, lane, in);
+    const nb_d4 acc = mma<26>(w2r, in);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = fmax(acc[r], 0.0);
+      const int unit = 16 * wave + 4 * r + lg;
+      if (unit == NB_H2) v = 1.0;
+      sA2[unit * LS + li] = v;
+    }
+  }
+  __syncthreads();
 
-  // backward (ReLU mask = activation == 0, sklearn inplace_relu_derivative;
-  // the bias units carry no delta)
-  double d3[4 * NB_HT3], d2[4 * NB_HT2], d1[4 * NB_HT1];
-  bwd_layer<NB_HT3, 1, 1>(W4, d4, lane, d3);
+  // ---- layer 3: two output tiles ------------------------------------------
+  if (wave < NB_HT3) {
+    double in[13];
+    lds_operand<13>(sA2, lane, in);
+    const nb_d4 acc = mma<13>(w3r, in);
 #pragma unroll
-  for (int j = 0; j < 4 * NB_HT3; ++j) if (h3[j] == 0.0) d3[j] = 0.0;
-  if (lg == 0) d3[5] = 0.0;
-  put_stash<4 * NB_HT3>(D3, LD3, pt, lane, d3);
-  bwd_layer<NB_HT2, NB_HT3, 5>(W3, d3, lane, d2);
+    for (int r = 0; r < 4; ++r) {
+      double v = fmax(acc[r], 0.0);
+      const int unit = 16 * wave + 4 * r + lg;
+      if (unit == NB_H3) v = 1.0;
+      sA3[unit * LS + li] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
+  if (wave == 0) {
+    double in[6];
+    lds_operand<6>(sA3, lane, in);
+    const nb_d4 acc = mma<6>(w4r, in);
+    double d40 = 0.0;
+    if (lg == 0 && valid) d40 = acc[0] - a.y[row];   // sklearn :365
 #pragma unroll
-  for (int j = 0; j < 4 * NB_HT2; ++j) if (h2[j] == 0.0) d2[j] = 0.0;
-  if (lg == 2) d2[12] = 0.0;
-  put_stash<4 * NB_HT2>(D2, LD2, pt, lane, d2);
-  bwd_layer<NB_HT1, NB_HT2, 13>(W2, d2, lane, d1);
+    for (int r = 0; r < 4; ++r) {
+      const int unit = 4 * r + lg;
+      const double v = (unit == 0) ? d40 : 0.0;
+      sD4[unit * LS + li] = v;
+    }
+    double lp = 0.5 * d40 * d40;
+    for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
+    if (lane == 0) st.scal[8 + tile] = lp;
+  }
+  __syncthreads();
+
+  // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
+  if (wave < NB_HT3) {
+    double dout[1];
+    lds_operand<1>(sD4, lane, dout);
+    const nb_d4 acc = mma<1>(b4r, dout);
 #pragma unroll
-  for (int j = 0; j < 4 * NB_HT1; ++j) if (h1[j] == 0.0) d1[j] = 0.0;
-  if (lg == 0) d1[25] = 0.0;
-  put_stash<4 * NB_HT1>(D1, LD1, pt, lane, d1);
+    for (int r = 0; r < 4; ++r) {
+      const int unit = 16 * wave + 4 * r + lg;
+      double v = acc[r];
+      if (sA3[unit * LS + li] == 0.0 || unit == NB_H3) v = 0.0;
+      sD3[unit * LS + li] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- delta 2 --------------------------------------------------------------
+  {
+    double dout[5];
+    lds_operand<5>(sD3, lane, dout);
+    const nb_d4 acc = mma<5>(b3r, dout);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int unit = 16 * wave + 4 * r + lg;
+      double v = acc[r];
+      if (sA2[unit * LS + li] == 0.0 || unit == NB_H2) v = 0.0;
+      sD2[unit * LS + li] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- delta 1 --------------------------------------------------------------
+  {
+    double dout[13];
+    lds_operand<13>(sD2, lane, dout);
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int kt = wave + 4 * rep;
+      if (kt < NB_HT1) {
+        const nb_d4 acc = mma<13>(b2r[rep], dout);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = 16 * kt + 4 * r + lg;
+          double v = acc[r];
+          if (sA1[unit * LS + li] == 0.0 || unit == NB_H1) v = 0.0;
+          D1[(long long)pt * LD1 + unit] = v;
+        }
+      }
+    }
+  }
+
+  // ---- stash for the G kernel, written once and coalesced ------------------
+  flush_stash(sA0, A0, ld0, ld0, tile);
+  flush_stash(sA1, A1, LD1, LD1, tile);
+  flush_stash(sA2, A2, LD2, LD2, tile);
+  flush_stash(sA3, A3, LD3, LD3, tile);
+  flush_stash(sD4, D4, LD4, LD4, tile);
+  flush_stash(sD3, D3, LD3, LD3, tile);
+  flush_stash(sD2, D2, LD2, LD2, tile);
 }
 
 __global__ void __launch_bounds__(64)
@@ -243,19 +459,26 @@ nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
     kt = g; ht = 0; As = A3; lda = LD3; Bs = D4; ldb = LD4;
     woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
   }
-  // dW tile = act^T delta over the rows of the minibatch (fixed order)
-  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  // dW tile = act^T delta over the rows of the minibatch (fixed order).  All
+  // operand loads are issued before the first MFMA (one memory latency per
+  // tile instead of one per k-step).
   const double* ap = As + (long long)lg * lda + 16 * kt + li;
   const double* bp = Bs + (long long)lg * ldb + 16 * ht + li;
   const int n_steps = n_tiles * 4;
-  int s = 0;
-  for (; s + 1 < n_steps; s += 2) {
-    acc0 = MFMA(ap[0], bp[0], acc0);
-    acc1 = MFMA(ap[4 * lda], bp[4 * ldb], acc1);
-    ap += 8 * lda;
-    bp += 8 * ldb;
+  constexpr int MAXS = MAXB / 4;
+  double av[MAXS], bv[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const bool on = s < n_steps;
+    av[s] = on ? ap[(long long)s * 4 * lda] : 0.0;
+    bv[s] = on ? bp[(long long)s * 4 * ldb] : 0.0;
   }
-  if (s < n_steps) acc0 = MFMA(ap[0], bp[0], acc0);
+  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+  for (int s = 0; s < MAXS; s += 2) {
+    acc0 = MFMA(av[s], bv[s], acc0);
+    acc1 = MFMA(av[s + 1], bv[s + 1], acc1);
+  }
 
   // Adam (sklearn _stochastic_optimizers.py:255-287), in place
   const double lr_t = a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
@@ -426,17 +649,17 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
     for (int sidx = 0; sidx < steps_per_epoch; ++sidx) {
       const long long start = (long long)sidx * a.batch;
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
-      const dim3 gfb((nb + 15) / 16, t->E), gg(n_gt, t->E), blk(64);
+      const dim3 gfb((nb + 15) / 16, t->E), gg(n_gt, t->E), blk(64), blk_fb(256);
       t->t_adam += 1;
       switch (t->dt) {
-        case 1: hipLaunchKernelGGL(nb_train_fb_kernel<1>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 2: hipLaunchKernelGGL(nb_train_fb_kernel<2>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 3: hipLaunchKernelGGL(nb_train_fb_kernel<3>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 4: hipLaunchKernelGGL(nb_train_fb_kernel<4>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 5: hipLaunchKernelGGL(nb_train_fb_kernel<5>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 6: hipLaunchKernelGGL(nb_train_fb_kernel<6>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 7: hipLaunchKernelGGL(nb_train_fb_kernel<7>, gfb, blk, 0, s, a, ep, start, nb); break;
-        case 8: hipLaunchKernelGGL(nb_train_fb_kernel<8>, gfb, blk, 0, s, a, ep, start, nb); break;
+        case 1: hipLaunchKernelGGL(nb_train_fb_kernel<1>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 2: hipLaunchKernelGGL(nb_train_fb_kernel<2>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 3: hipLaunchKernelGGL(nb_train_fb_kernel<3>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 4: hipLaunchKernelGGL(nb_train_fb_kernel<4>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 5: hipLaunchKernelGGL(nb_train_fb_kernel<5>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 6: hipLaunchKernelGGL(nb_train_fb_kernel<6>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 7: hipLaunchKernelGGL(nb_train_fb_kernel<7>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+        case 8: hipLaunchKernelGGL(nb_train_fb_kernel<8>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
         default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
       }
       hipLaunchKernelGGL(nb_train_g_kernel, gg, blk, 0, s, a, nb, t->t_adam);
@@ -445,15 +668,18 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
                        t->t_adam);
   }
   NB_HIP_CHECK(hipGetLastError());
-  if (status_host != nullptr) {
-    NB_HIP_CHECK(hipStreamSynchronize(s));
-    for (int i = 0; i < t->E; ++i) {
-      double scal[8];
-      NB_HIP_CHECK(hipMemcpy(scal, t->nets_host[i].scal, sizeof scal,
-                             hipMemcpyDeviceToHost));
-      const int n_iter = (int)scal[3];
-      status_host[i] = (scal[4] != 0.0) ? -n_iter : n_iter;
-    }
+  if (status_host != nullptr) return nb_trainer_status(t, status_host, stream);
+  return NB_OK;
+}
+
+int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream) {
+  NB_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < t->E; ++i) {
+    double scal[8];
+    NB_HIP_CHECK(hipMemcpy(scal, t->nets_host[i].scal, sizeof scal,
+                           hipMemcpyDeviceToHost));
+    const int n_iter = (int)scal[3];
+    status_host[i] = (scal[4] != 0.0) ? -n_iter : n_iter;
   }
   return NB_OK;
 }

@@ -96,8 +96,17 @@ class Trainer:
             self._h, C.c_void_p(perms_dev.data_ptr()), perms.shape[1],
             status if sync else None,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        self._perms = perms_dev
+        self._perms = getattr(self, '_perms', [])[-1:] + [perms_dev]
         return np.array(status[:]) if sync else None
+
+    def status(self):
+        """Wait for the enqueued epochs; per-network n_iter (negative once
+        the network has stopped)."""
+        status = (C.c_int32 * self.e)()
+        _lib.check(self._lib.nb_trainer_status(
+            self._h, status,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return np.array(status[:])
 
     def loss_curve(self, net, n):
         out = np.zeros(max(1, n))
@@ -224,23 +233,36 @@ def train_networks(xs, y, seeds, hparams=None, permutations=None,
     orders = [np.arange(n) for _ in range(e)]
     status = np.zeros(e, dtype=int)
     done_epochs = 0
-    while done_epochs < max_iter and np.any(status >= 0):
+    in_flight = False
+    while True:
+        # the shuffles of the next chunk are drawn on the host while the GPU
+        # is still training on the previous chunk
         chunk = min(EPOCH_CHUNK, max_iter - done_epochs)
-        perms = np.zeros((e, chunk, n), dtype=np.int32)
-        for i in range(e):
-            for ep in range(chunk):
-                if permutations is not None:
-                    orders[i] = np.asarray(
-                        permutations[i][done_epochs + ep])
-                elif status[i] >= 0:
-                    # sklearn.utils.shuffle: permutations compose
-                    # (_multilayer_perceptron.py:700-704)
-                    idx = np.arange(n)
-                    states[i].shuffle(idx)
-                    orders[i] = orders[i][idx]
-                perms[i, ep] = orders[i]
-        status = trainer.run(perms)
+        perms = None
+        if chunk > 0:
+            perms = np.zeros((e, chunk, n), dtype=np.int32)
+            for i in range(e):
+                for ep in range(chunk):
+                    if permutations is not None:
+                        orders[i] = np.asarray(
+                            permutations[i][done_epochs + ep])
+                    elif status[i] >= 0:
+                        # sklearn.utils.shuffle: permutations compose
+                        # (_multilayer_perceptron.py:700-704)
+                        idx = np.arange(n)
+                        states[i].shuffle(idx)
+                        orders[i] = orders[i][idx]
+                    perms[i, ep] = orders[i]
+        if in_flight:
+            status = trainer.status()
+            in_flight = False
+        if perms is None or not np.any(status >= 0):
+            break
+        trainer.run(perms, sync=False)
+        in_flight = True
         done_epochs += chunk
+    if in_flight:
+        status = trainer.status()
     networks = []
     for i in range(e):
         n_iter = abs(int(status[i]))
