@@ -54,6 +54,11 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=20.0)
     p.add_argument('--explore-timeout', type=float, default=1500.0)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--backend', default='nccl',
+                   help="torch.distributed backend ('nccl' = RCCL; 'gloo' "
+                        "only for functional tests)")
+    p.add_argument('--same-device', action='store_true',
+                   help='functional test: all ranks share cuda:0')
     return p.parse_args()
 
 
@@ -167,12 +172,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(
-            'cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(
+                'cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
         from nautilus_amd.parallel import ShardedComm
         comm = ShardedComm()
 

@@ -47,24 +47,36 @@ class ShardedComm:
         rows = rows.contiguous()
         out = torch.empty((self.world * rows.shape[0],) + tuple(rows.shape[1:]),
                           dtype=rows.dtype, device=rows.device)
-        dist.all_gather_into_tensor(out, rows, group=self.group)
+        if rows.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # functional-test path (gloo has no device all-gather)
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, rows.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, rows, group=self.group)
         return out
 
     def sum_ints(self, values, device):
         """Element-wise sum of a short list of python ints over all ranks."""
-        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        t = torch.tensor(list(values), dtype=torch.int64,
+                         device=self._dev(device))
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [int(v) for v in t.cpu()]
 
+    def _dev(self, device):
+        return 'cpu' if dist.get_backend(self.group) == 'gloo' else device
+
     def max_float(self, value, device):
-        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        t = torch.tensor([float(value)], dtype=torch.float64,
+                         device=self._dev(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.cpu()[0])
 
     def assert_identical(self, values, device, what='state'):
         """All ranks must hold bit-identical float values (replicated
         exploration)."""
-        t = torch.tensor(list(values), dtype=torch.float64, device=device)
+        t = torch.tensor(list(values), dtype=torch.float64,
+                         device=self._dev(device))
         lo, hi = t.clone(), t.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
