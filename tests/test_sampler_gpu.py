@@ -218,3 +218,30 @@ def test_nautilus_bound_two_peaks():
                       atol=0.1)
     assert np.mean(like(pts) > -1) > 0.9
     assert b.n_net == 2
+
+
+def test_two_rank_sharded_run_on_one_gpu():
+    """The N > 1 path of bench.py end to end on real kernels: two processes
+    share cuda:0 and talk over gloo (RCCL needs one GPU per rank; the 8-GPU run
+    is the driver's).  Checks: replicated exploration identical on both ranks
+    (bench.py asserts it), one all-gather + all-reduce per batch, evidence."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29700 + os.getpid() % 200),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4',
+           '--warmup', '1', '--dim', '6', '--n-live', '300', '--n-batch',
+           '2048', '--n-batch-setup', '512', '--backend', 'gloo',
+           '--same-device']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak'
+    assert res['config']['n_batch_global'] == 4096
+    assert abs(res['log_z']) < 0.05          # analytic log Z = 0
+    assert res['value'] > 0
