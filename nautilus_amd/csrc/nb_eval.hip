@@ -209,12 +209,20 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
     }
 }
 
-template <int DT>
+// COMPACT: the points of the workgroup that need the emulator are gathered
+// into dense 16-point tiles through LDS before the MLP (shell exclusion and
+// association only need it for a minority of the points; without the
+// gather a wavefront evaluates all 32 of its points if one needs it).
+template <int DT, bool COMPACT>
 __global__ void __launch_bounds__(256)
-nb_eval_kernel(EvalArgs a) {
+nb_eval_kernel(EvalArgs a, int w_doubles) {
   constexpr int DP = 16 * DT;
   constexpr int KS1MAX = 4 * DT + 1;
+  constexpr int TS = 4 * KS1MAX + 1;        // LDS row stride of a gathered point
   extern __shared__ __attribute__((aligned(16))) double wlds[];
+  __shared__ int wcnt[4];
+  double* tlds = wlds + w_doubles;          // [128][TS] gathered inputs
+  double* slds = tlds + 128 * TS;           // [128] scores
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = lane >> 4;
@@ -356,7 +364,25 @@ nb_eval_kernel(EvalArgs a) {
 #pragma unroll
           for (int t = 0; t < TPW; ++t) ok[t] = inside_e[t];
 
-          if (E > 0 && __syncthreads_or(wave_need ? 1 : 0)) {
+          // workgroup census of the points that need the emulator
+          unsigned long long bal[TPW];
+          int cnt_w = 0;
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            bal[t] = __ballot(need[t] && lg == 0);
+            cnt_w += __popcll(bal[t]);
+          }
+          __syncthreads();
+          if (lane == 0) wcnt[wave] = cnt_w;
+          __syncthreads();
+          int base = 0, n_need = 0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            if (w < wave) base += wcnt[w];
+            n_need += wcnt[w];
+          }
+
+          if (E > 0 && n_need > 0) {
             const double thr = nb_m[nb_ell_block_size(DT)];
             const double* mean = nb_m + nb_ell_block_size(DT) + 2;
             const double* scale = mean + DP;
@@ -376,6 +402,37 @@ nb_eval_kernel(EvalArgs a) {
             for (int t = 0; t < TPW; ++t)
               tin[t][4 * DT] = (16 * DT + lg == n_dim) ? 1.0 : 0.0;
 
+            bool wave_mlp = wave_need;
+            int cidx[TPW];
+            if (COMPACT) {
+              // gather: point -> dense slot base + rank
+              int off = base;
+#pragma unroll
+              for (int t = 0; t < TPW; ++t) {
+                const unsigned long long below =
+                    bal[t] & ((1ull << (lane & 15)) - 1ull);
+                cidx[t] = off + __popcll(below);
+                off += __popcll(bal[t]);
+                if (need[t]) {
+#pragma unroll
+                  for (int ks = 0; ks < KS1MAX; ++ks)
+                    tlds[cidx[t] * TS + 4 * ks + lg] = tin[t][ks];
+                }
+              }
+              __syncthreads();
+              const int n_ct = (n_need + 15) >> 4;     // dense tiles
+#pragma unroll
+              for (int t = 0; t < TPW; ++t) {
+                const int q = wave + 4 * t;
+                const int slot = 16 * q + (lane & 15);
+                const bool on = q < n_ct && slot < n_need;
+#pragma unroll
+                for (int ks = 0; ks < KS1MAX; ++ks)
+                  tin[t][ks] = on ? tlds[slot * TS + 4 * ks + lg] : 0.0;
+              }
+              wave_mlp = wave < n_ct;
+            }
+
             double total[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) total[t] = 0.0;
@@ -385,7 +442,7 @@ nb_eval_kernel(EvalArgs a) {
               __syncthreads();                       // LDS free
               stage_weights(w1, wlds, n_a);
               __syncthreads();
-              if (wave_need) {
+              if (wave_mlp) {
                 mlp_layer<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], tin[1],
                                                 lane, h1[0], h1[1]);
                 if (lg == 0) { h1[0][25] = 1.0; h1[1][25] = 1.0; }  // unit 100
@@ -393,7 +450,7 @@ nb_eval_kernel(EvalArgs a) {
               __syncthreads();
               stage_weights(w1 + n_a, wlds, n_b);
               __syncthreads();
-              if (wave_need) {
+              if (wave_mlp) {
                 const double* w2 = wlds;
                 const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
                 const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
@@ -409,12 +466,27 @@ nb_eval_kernel(EvalArgs a) {
                 total[1] += o[1][0];
               }
             }
+            if (COMPACT) {
+              // scatter the scores back to the owners of the points
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-              const double score =
-                  __shfl(total[t], lane & 15) / (double)E;
-              if (need[t]) ok[t] = inside_e[t] && (score > thr);
-              if (m == 0) score_out[t] = score;
+              for (int t = 0; t < TPW; ++t)
+                if (lg == 0) slds[16 * (wave + 4 * t) + (lane & 15)] = total[t];
+              __syncthreads();
+#pragma unroll
+              for (int t = 0; t < TPW; ++t) {
+                const double score =
+                    need[t] ? slds[cidx[t]] / (double)E : 0.0;
+                if (need[t]) ok[t] = inside_e[t] && (score > thr);
+                if (m == 0) score_out[t] = score;
+              }
+            } else {
+#pragma unroll
+              for (int t = 0; t < TPW; ++t) {
+                const double score =
+                    __shfl(total[t], lane & 15) / (double)E;
+                if (need[t]) ok[t] = inside_e[t] && (score > thr);
+                if (m == 0) score_out[t] = score;
+              }
             }
           }
 #pragma unroll
@@ -463,14 +535,16 @@ nb_eval_kernel(EvalArgs a) {
   }
 }
 
-template <int DT>
-int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
-  const int lds_tiles = (kt1_max * NB_HT1 > 38) ? kt1_max * NB_HT1 : 38;
-  const size_t lds = (size_t)lds_tiles * NB_TILE * sizeof(double);
+template <int DT, bool COMPACT>
+int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
+  constexpr int TS = 4 * (4 * DT + 1) + 1;
+  const int w_doubles = lds_tiles * NB_TILE;
+  const size_t lds = ((size_t)w_doubles + (COMPACT ? 128 * TS + 128 : 0)) *
+                     sizeof(double);
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_kernel<DT>,
+        (const void*)nb_eval_kernel<DT, COMPACT>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -486,9 +560,21 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   long long blocks = n_super;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(nb_eval_kernel<DT>, dim3((unsigned)blocks), dim3(256), lds,
-                     stream, a);
+  hipLaunchKernelGGL((nb_eval_kernel<DT, COMPACT>), dim3((unsigned)blocks),
+                     dim3(256), lds, stream, a, w_doubles);
   return NB_OK;
+}
+
+template <int DT>
+int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
+  const int lds_tiles = (kt1_max * NB_HT1 > 38) ? kt1_max * NB_HT1 : 38;
+  constexpr int TS = 4 * (4 * DT + 1) + 1;
+  // gather emulator inputs through LDS when weights + 128 gathered points fit
+  const size_t need = ((size_t)lds_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
+  const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC);
+  if (sparse_mode && need <= 160 * 1024)
+    return launch_eval_impl<DT, true>(a, lds_tiles, stream);
+  return launch_eval_impl<DT, false>(a, lds_tiles, stream);
 }
 
 }  // namespace
