@@ -70,6 +70,14 @@ inline void put_i64(std::vector<double>& buf, size_t at, int64_t v) {
   std::memcpy(&buf[at], &v, sizeof v);
 }
 
+// K permutation of the ellipsoid stage (nb_eval.hip / nb_stream.hip): slot
+// (ks, lg) <-> feature 8*(ks>>1) + 2*lg + (ks&1).
+inline int slot_of_feature(int f) {
+  const int j = f >> 3, r = f & 7;
+  const int lg = r >> 1, o = r & 1;
+  return 4 * (2 * j + o) + lg;
+}
+
 // fills one ell block at buf[at ...]; returns false on invalid input
 bool fill_ell_block(std::vector<double>& buf, size_t at, int n_dim, int dt,
                     const nb_member_desc& m, bool is_neural) {
@@ -95,11 +103,12 @@ bool fill_ell_block(std::vector<double>& buf, size_t at, int n_dim, int dt,
   }
   for (int f = 0; f < dp; ++f) {
     const bool boxed = f < n_dim && !is_ell[f] && !m.free_dims && !is_neural;
-    lo[f] = boxed ? 0.0 : -INF;
-    hi[f] = boxed ? 1.0 : INF;
-    c[f] = 0.0;
+    const int sl = slot_of_feature(f);
+    lo[sl] = boxed ? 0.0 : -INF;
+    hi[sl] = boxed ? 1.0 : INF;
+    c[sl] = 0.0;
   }
-  for (int i = 0; i < m.n_ell; ++i) c[idx[i]] = m.c[i];
+  for (int i = 0; i < m.n_ell; ++i) c[slot_of_feature(idx[i])] = m.c[i];
   for (int i = 0; i < m.n_ell; ++i) {
     for (int j = 0; j < m.n_ell; ++j) {
       const double v = m.B_inv[(size_t)i * m.n_ell + j];
@@ -110,9 +119,13 @@ bool fill_ell_block(std::vector<double>& buf, size_t at, int n_dim, int dt,
         }
         continue;
       }
-      const int h = idx[i], k = idx[j];       // W0[k][h] = B_inv[h][k]
-      tiles[((size_t)(k >> 4) * dt + (h >> 4)) * NB_TILE + (k & 15) * 16 +
-            (h & 15)] = v;
+      // W0[k][h] = B_inv[h][k]; the K index of the tile is stored in slot
+      // order: tile (kt, ht), k-step s, lane (li, lg) at s*64 + lg*16 + li
+      const int h = idx[i], k = idx[j];
+      const int sl = slot_of_feature(k);          // = 4*ks + lg
+      const int ks = sl >> 2, lgk = sl & 3;
+      tiles[((size_t)(ks >> 2) * dt + (h >> 4)) * NB_TILE + (ks & 3) * 64 +
+            lgk * 16 + (h & 15)] = v;
     }
   }
   return true;
@@ -269,8 +282,8 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   }
   for (int f = 0; f < dp; ++f) {
     const bool boxed = d->unit_cube && f < n_dim;
-    buf[off_ulo + f] = boxed ? 0.0 : -INF;
-    buf[off_uhi + f] = boxed ? 1.0 : INF;
+    buf[off_ulo + slot_of_feature(f)] = boxed ? 0.0 : -INF;
+    buf[off_uhi + slot_of_feature(f)] = boxed ? 1.0 : INF;
   }
 
   for (int m = 0; m < K; ++m) {

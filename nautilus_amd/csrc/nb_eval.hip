@@ -76,7 +76,7 @@ constexpr int TPW = 2;   // 16-point tiles per wavefront
 // (replicated over the 4 lanes of a point); box_bad is set if any coordinate
 // violates the member's [lo, hi) limits.
 template <int DT>
-__device__ __forceinline__ void ell_eval(const double* __restrict__ blk,
+__device__ __forceinline__ void ell_eval(const double* blk,
                                          int n_dim,
                                          const double (&xin)[TPW][4 * DT],
                                          int lane, double (&y)[TPW][4 * DT],
@@ -96,7 +96,7 @@ __device__ __forceinline__ void ell_eval(const double* __restrict__ blk,
   for (int t = 0; t < TPW; ++t) bad[t] = false;
 #pragma unroll
   for (int ks = 0; ks < 4 * DT; ++ks) {
-    const int f = 4 * ks + lg;
+    const int f = 4 * ks + lg;               // slot index (host permuted)
     const double lov = lo[f], hiv = hi[f], cv = c[f];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -181,6 +181,31 @@ __device__ __forceinline__ void mlp_layer(const double* w, int ks_n,
   }
 }
 
+// same for a single tile (the gather left this wavefront only one)
+template <int KSMAX, int HT, bool RELU>
+__device__ __forceinline__ void mlp_layer1(const double* w, int ks_n,
+                                           const double* in0, int lane,
+                                           double* out0) {
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks) {
+      if (ks < ks_n) {
+        const int kt = ks >> 2, s = ks & 3;
+        const double a = w[(kt * HT + ht) * NB_TILE + s * 64 + lane];
+        if (ks & 1) acc1 = MFMA(a, in0[ks], acc1);
+        else acc0 = MFMA(a, in0[ks], acc0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = acc0[r] + acc1[r];
+      out0[4 * ht + r] = RELU ? fmax(v, 0.0) : v;
+    }
+  }
+}
+
 // cooperative global -> LDS copy by the whole workgroup (16 bytes per lane)
 __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
                                               double* dst, int n_doubles) {
@@ -193,20 +218,50 @@ __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
 // B-operand block of the points: lane l holds feature 4*ks + (l >> 4) of
 // point (l & 15).  Re-read (L1/L2 hits) wherever it is needed instead of being
 // kept live across the emulator evaluation, which needs the registers.
+// K permutation shared with nb_stream.hip: slot ks of lane group lg holds
+// feature perm(ks, lg) = 8*(ks>>1) + 2*lg + (ks&1), so that a lane reads its
+// slots (2j, 2j+1) with one 16-byte load and a point is covered by 64
+// contiguous bytes per instruction.  The per-dimension vectors (lo, hi, c) and
+// the K index of the ellipsoid tiles are stored in slot order by the host.
 template <int DT>
 __device__ __forceinline__ void load_points(const double* __restrict__ x,
                                             const long long (&pt)[TPW],
                                             const bool (&valid)[TPW],
-                                            int n_dim, int lane,
+                                            int n_dim, long long n, int lane,
                                             double (&xin)[TPW][4 * DT]) {
   const int lg = lane >> 4;
+  const bool even = (n_dim & 1) == 0;
+  // the loads are loop invariant across the bounds of a list; laundering the
+  // base pointer keeps the compiler from hoisting them (and the registers
+  // they occupy) out of the bound loop
+  asm volatile("" : "+s"(x));
+  if (even) {
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
+    for (int t = 0; t < TPW; ++t) {
+      const double* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
 #pragma unroll
-    for (int ks = 0; ks < 4 * DT; ++ks) {
-      const int f = 4 * ks + lg;
-      xin[t][ks] = (valid[t] && f < n_dim) ? x[pt[t] * n_dim + f] : 0.0;
+      for (int j = 0; j < 2 * DT; ++j) {
+        const int f = 8 * j + 2 * lg;
+        const bool in = valid[t] && f < n_dim;
+        const double2 v = *(const double2*)(row + (f < n_dim ? f : n_dim - 2));
+        xin[t][2 * j] = in ? v.x : 0.0;
+        xin[t][2 * j + 1] = in ? v.y : 0.0;
+      }
     }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const double* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+#pragma unroll
+      for (int j = 0; j < 2 * DT; ++j) {
+        const int f = 8 * j + 2 * lg;
+        const double v0 = row[f < n_dim ? f : n_dim - 1];
+        const double v1 = row[f + 1 < n_dim ? f + 1 : n_dim - 1];
+        xin[t][2 * j] = (valid[t] && f < n_dim) ? v0 : 0.0;
+        xin[t][2 * j + 1] = (valid[t] && f + 1 < n_dim) ? v1 : 0.0;
+      }
+    }
+  }
 }
 
 // COMPACT: the points of the workgroup that need the emulator are gathered
@@ -267,7 +322,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       int k_cnt[TPW];
       {
         double xin[TPW][4 * DT];
-        load_points<DT>(a.x, pt, valid, n_dim, lane, xin);
+        load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin);
         bool cbad[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) cbad[t] = false;
@@ -296,8 +351,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
         for (int m = 0; m < K; ++m) {
           double y[TPW][4 * DT], r2[TPW];
           bool box_bad[TPW];
-          ell_eval<DT>(mblk + m * ell_stride, n_dim, xin, lane, y, box_bad,
-                       r2);
+          // the member's limits, centre and B_inv tiles are staged in LDS and
+          // shared by the 8 tiles of the workgroup
+          __syncthreads();
+          stage_weights(mblk + m * ell_stride, wlds, nb_ell_block_size(DT));
+          __syncthreads();
+          ell_eval<DT>(wlds, n_dim, xin, lane, y, box_bad, r2);
 #pragma unroll
           for (int t = 0; t < TPW; ++t)
             k_cnt[t] += (!box_bad[t] && r2[t] < 1.0) ? 1 : 0;
@@ -344,8 +403,11 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           bool box_bad[TPW], inside_e[TPW], need[TPW];
           {
             double xin[TPW][4 * DT];
-            load_points<DT>(a.x, pt, valid, n_dim, lane, xin);
-            ell_eval<DT>(nb_m, n_dim, xin, lane, y, box_bad, r2);
+            load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin);
+            __syncthreads();
+            stage_weights(nb_m, wlds, nb_ell_block_size(DT));
+            __syncthreads();
+            ell_eval<DT>(wlds, n_dim, xin, lane, y, box_bad, r2);
           }
           bool wave_need = false;
 #pragma unroll
@@ -403,6 +465,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               tin[t][4 * DT] = (16 * DT + lg == n_dim) ? 1.0 : 0.0;
 
             bool wave_mlp = wave_need;
+            bool two_tiles = true;
             int cidx[TPW];
             if (COMPACT) {
               // gather: point -> dense slot base + rank
@@ -431,6 +494,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                   tin[t][ks] = on ? tlds[slot * TS + 4 * ks + lg] : 0.0;
               }
               wave_mlp = wave < n_ct;
+              two_tiles = wave + 4 < n_ct;
             }
 
             double total[TPW];
@@ -443,8 +507,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               stage_weights(w1, wlds, n_a);
               __syncthreads();
               if (wave_mlp) {
-                mlp_layer<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], tin[1],
-                                                lane, h1[0], h1[1]);
+                if (two_tiles)
+                  mlp_layer<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], tin[1],
+                                                  lane, h1[0], h1[1]);
+                else
+                  mlp_layer1<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], lane,
+                                                   h1[0]);
                 if (lg == 0) { h1[0][25] = 1.0; h1[1][25] = 1.0; }  // unit 100
               }
               __syncthreads();
@@ -455,15 +523,24 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                 const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
                 const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
                 double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
-                mlp_layer<26, NB_HT2, true>(w2, 26, h1[0], h1[1], lane, h2[0],
-                                            h2[1]);
-                if (lg == 2) { h2[0][12] = 1.0; h2[1][12] = 1.0; }  // unit 50
-                mlp_layer<13, NB_HT3, true>(w3, 13, h2[0], h2[1], lane, h3[0],
-                                            h3[1]);
-                if (lg == 0) { h3[0][5] = 1.0; h3[1][5] = 1.0; }    // unit 20
-                mlp_layer<6, 1, false>(w4, 6, h3[0], h3[1], lane, o[0], o[1]);
+                if (two_tiles) {
+                  mlp_layer<26, NB_HT2, true>(w2, 26, h1[0], h1[1], lane,
+                                              h2[0], h2[1]);
+                  if (lg == 2) { h2[0][12] = 1.0; h2[1][12] = 1.0; }  // 50
+                  mlp_layer<13, NB_HT3, true>(w3, 13, h2[0], h2[1], lane,
+                                              h3[0], h3[1]);
+                  if (lg == 0) { h3[0][5] = 1.0; h3[1][5] = 1.0; }    // 20
+                  mlp_layer<6, 1, false>(w4, 6, h3[0], h3[1], lane, o[0],
+                                         o[1]);
+                  total[1] += o[1][0];
+                } else {
+                  mlp_layer1<26, NB_HT2, true>(w2, 26, h1[0], lane, h2[0]);
+                  if (lg == 2) h2[0][12] = 1.0;
+                  mlp_layer1<13, NB_HT3, true>(w3, 13, h2[0], lane, h3[0]);
+                  if (lg == 0) h3[0][5] = 1.0;
+                  mlp_layer1<6, 1, false>(w4, 6, h3[0], lane, o[0]);
+                }
                 total[0] += o[0][0];               // unit 0 lives in lg == 0
-                total[1] += o[1][0];
               }
             }
             if (COMPACT) {
@@ -567,7 +644,8 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
 
 template <int DT>
 int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
-  const int lds_tiles = (kt1_max * NB_HT1 > 38) ? kt1_max * NB_HT1 : 38;
+  int lds_tiles = (kt1_max * NB_HT1 > 38) ? kt1_max * NB_HT1 : 38;
+  if (lds_tiles < DT * DT + 1) lds_tiles = DT * DT + 1;   // one ell block
   constexpr int TS = 4 * (4 * DT + 1) + 1;
   // gather emulator inputs through LDS when weights + 128 gathered points fit
   const size_t need = ((size_t)lds_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
