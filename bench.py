@@ -59,6 +59,14 @@ def parse():
                         "only for functional tests)")
     p.add_argument('--same-device', action='store_true',
                    help='functional test: all ranks share cuda:0')
+    p.add_argument('--force-comm', action='store_true',
+                   help='functional test: run the collective code path even '
+                        'with a single rank')
+    p.add_argument('--broadcast-state', action='store_true',
+                   help='build the bounds on rank 0 only and broadcast the '
+                        'sampler (default: every rank repeats the '
+                        'deterministic exploration; the broadcast is also the '
+                        'automatic fallback if the replicas disagree)')
     return p.parse_args()
 
 
@@ -176,13 +184,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    if world > 1 or args.force_comm:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
+        wait = datetime.timedelta(seconds=args.explore_timeout + 1800)
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device(
-                'cuda', local_rank))
+            dist.init_process_group('nccl', timeout=wait,
+                                    device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=wait)
         from nautilus_amd.parallel import ShardedComm
         comm = ShardedComm()
 
@@ -198,17 +208,44 @@ def main():
 
     # ---- setup: build the bound hierarchy (exploration, untimed) ---------
     t_setup = time.time()
-    sampler.run(n_eff=0, n_shell=0, discard_exploration=True,
-                timeout=args.explore_timeout)
-    torch.cuda.synchronize()
+
+    def explore():
+        sampler.run(n_eff=0, n_shell=0, discard_exploration=True,
+                    timeout=args.explore_timeout)
+        torch.cuda.synchronize()
+        if not sampler.explored:
+            raise SystemExit('exploration did not finish within %.0f s' %
+                             args.explore_timeout)
+
+    def broadcast_from_rank0(s):
+        box = [s if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        if rank != 0:
+            s = box[0]
+            s.comm = comm
+        return s
+
+    if comm is None:
+        explore()
+    elif args.broadcast_state:
+        if rank == 0:
+            explore()
+        sampler = broadcast_from_rank0(sampler)
+    else:
+        # bound construction is "replicas only": identical seeds and
+        # deterministic kernels give identical bounds on every rank
+        explore()
+        try:
+            comm.assert_identical([sampler.log_z or 0.0, sampler.n_like,
+                                   len(sampler.bounds)], 'cuda',
+                                  'exploration state')
+        except RuntimeError as err:
+            if rank == 0:
+                print('replicas differ (%s); broadcasting rank 0' % err,
+                      file=sys.stderr)
+            sampler = broadcast_from_rank0(sampler)
     setup_s = time.time() - t_setup
-    if not sampler.explored:
-        raise SystemExit('exploration did not finish within %.0f s' %
-                         args.explore_timeout)
     if comm is not None:
-        comm.assert_identical([sampler.log_z or 0.0, sampler.n_like,
-                               len(sampler.bounds)], 'cuda',
-                              'exploration state')
         sampler.n_batch = args.n_batch_setup * world
 
     def step():

@@ -63,6 +63,11 @@ typedef struct {
   nb_member_desc ellipsoid;     /* NeuralBound.outer_bound (n_ell == n_dim)  */
   const nb_mlp_desc* mlp;       /* NULL when n_networks == 0                 */
   double score_predict_min;     /* NeuralBound.score_predict_min             */
+  double radius2;               /* >= largest squared semi-axis of the
+                                   ellipsoid (sigma_max(B)^2), used to skip
+                                   bounds whose ellipsoids cannot contain any
+                                   point of a workgroup; <= 0: derive a
+                                   conservative value from B                 */
 } nb_neural_desc;
 
 /* Any bound of the reference as one description:

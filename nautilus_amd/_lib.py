@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnautilus_hip.so')
+LIB_PATH = os.environ.get('NAUTILUS_HIP_LIB') or os.path.join(
+    _HERE, 'lib', 'libnautilus_hip.so')
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -28,7 +29,7 @@ class MlpDesc(C.Structure):
 
 class NeuralDesc(C.Structure):
     _fields_ = [('ellipsoid', MemberDesc), ('mlp', C.POINTER(MlpDesc)),
-                ('score_predict_min', C.c_double)]
+                ('score_predict_min', C.c_double), ('radius2', C.c_double)]
 
 
 class BoundDesc(C.Structure):

@@ -88,6 +88,15 @@ class _Fifo:
         self.buf = self.buf[:0]
         self.head = 0
 
+    def __getstate__(self):
+        return dict(n_dim=self.n_dim,
+                    rows=self.buf[self.head:].cpu().numpy())
+
+    def __setstate__(self, state):
+        self.n_dim = state['n_dim']
+        self.buf = torch.from_numpy(state['rows']).cuda()
+        self.head = 0
+
 
 class _DeviceBoundBase:
     """Shared contains / upload plumbing."""

@@ -319,6 +319,28 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
     if (!fill_ell_block(buf, at, n_dim, dt, nd.ellipsoid, true))
       return NB_ERR_ARG;
     buf[at + ell_size] = nd.score_predict_min - 1e-9;   // bounds/neural.py:125
+    {
+      // bounding sphere of the ellipsoid: x inside => |x - c|^2 <= radius2
+      double r2 = nd.radius2;
+      if (!(r2 > 0.0)) {
+        // conservative fallback: lambda_max(B B^T) <= min(Gershgorin, ||B||_F^2)
+        const int n = nd.ellipsoid.n_ell;
+        const double* B = nd.ellipsoid.B;
+        double fro = 0.0, ger = 0.0;
+        for (int i = 0; i < n * n; ++i) fro += B[i] * B[i];
+        for (int i = 0; i < n; ++i) {
+          double rowsum = 0.0;
+          for (int j = 0; j < n; ++j) {
+            double aij = 0.0;
+            for (int k = 0; k < n; ++k) aij += B[i * n + k] * B[j * n + k];
+            rowsum += std::fabs(aij);
+          }
+          ger = std::fmax(ger, rowsum);
+        }
+        r2 = std::fmin(fro, ger) * (1.0 + 1e-9);
+      }
+      buf[at + 1] = r2;
+    }
     double* mean = &buf[at + ell_size + 2];
     double* scale = mean + dp;
     for (int f = 0; f < dp; ++f) { mean[f] = 0.0; scale[f] = 1.0; }

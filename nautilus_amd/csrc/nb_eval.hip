@@ -34,6 +34,8 @@
 // read straight from L2.
 #include "nb_common.h"
 
+#include <cstdlib>
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 namespace {
@@ -323,6 +325,38 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       {
         double xin[TPW][4 * DT];
         load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin);
+
+        // Bounding-sphere pre-test (shell exclusion / association): a point
+        // of a bound with neural bounds lies inside one of their ellipsoids,
+        // hence within sqrt(radius2) of that centre.  If no undecided point
+        // of the workgroup passes this test the whole bound is skipped --
+        // for nested bounds in high dimension all but the next few bounds.
+        if ((a.mode == MODE_ANY || a.mode == MODE_ASSOC) && M > 0) {
+          const double* nblk0 = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
+          bool maybe = false;
+          for (int m = 0; m < M; ++m) {
+            const double* nb_m = nblk0 + m * neural_stride;
+            const double rad2 = nb_m[1];
+            const double* cc = nb_m + 2 + 2 * DP;
+            double d2[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) d2[t] = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < 4 * DT; ++ks) {
+              const double cv = cc[4 * ks + lg];
+#pragma unroll
+              for (int t = 0; t < TPW; ++t) {
+                const double dv = xin[t][ks] - cv;
+                d2[t] = fma(dv, dv, d2[t]);
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+              maybe |= valid[t] && !hit[t] && lane_group_sum(d2[t]) <= rad2;
+          }
+          if (!__syncthreads_or(maybe ? 1 : 0)) continue;
+        }
+
         bool cbad[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) cbad[t] = false;
@@ -415,6 +449,9 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             inside_e[t] = !box_bad[t] && r2[t] < 1.0;
             need[t] = want[t] && inside_e[t] && !neural_ok[t];
             if (a.mode == MODE_SCORE) need[t] = valid[t];
+#ifdef NB_DBG_NO_MLP
+            need[t] = false;                       // dev experiment only
+#endif
             cnt_ell += __popcll(__ballot(want[t] && lg == 0));
             cnt_mlp += (unsigned long long)E *
                        __popcll(__ballot(need[t] && lg == 0));
@@ -649,7 +686,8 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   constexpr int TS = 4 * (4 * DT + 1) + 1;
   // gather emulator inputs through LDS when weights + 128 gathered points fit
   const size_t need = ((size_t)lds_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
-  const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC);
+  const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC) &&
+                           getenv("NB_EVAL_NO_GATHER") == nullptr;
   if (sparse_mode && need <= 160 * 1024)
     return launch_eval_impl<DT, true>(a, lds_tiles, stream);
   return launch_eval_impl<DT, false>(a, lds_tiles, stream);

@@ -91,6 +91,9 @@ class DeviceBound:
         for nd, src in zip(n_arr, neural):
             fill_member(nd.ellipsoid, src['ellipsoid'])
             nd.score_predict_min = float(src.get('score_predict_min', 0.0))
+            # largest squared semi-axis (exact, with a safety margin)
+            nd.radius2 = float(np.linalg.norm(src['ellipsoid']['B'], 2)**2 *
+                               (1.0 + 1e-9))
             mlp = src.get('mlp')
             if mlp is None:
                 nd.mlp = None

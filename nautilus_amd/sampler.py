@@ -64,6 +64,13 @@ class _Grow:
         self.data = kept.clone()
         self.n = kept.shape[0]
 
+    def __getstate__(self):
+        return dict(data=self.data[:self.n].cpu().numpy(), n=self.n)
+
+    def __setstate__(self, state):
+        self.data = torch.from_numpy(state['data']).cuda()
+        self.n = state['n']
+
 
 class Sampler:
     """Drop-in for ``nautilus.Sampler`` (constructor signature and public
@@ -177,6 +184,24 @@ class Sampler:
         self.timing = dict(add_bound=0.0, sample_shell=0.0, likelihood=0.0,
                            bookkeeping=0.0)
         self.n_proposals = 0     # raw proposal evaluations (outer draws)
+
+    # ------------------------------------------------------------------
+    # pickling (the reference's sampler is picklable; device handles and
+    # caches are rebuilt lazily, tensors travel as numpy arrays)
+    # ------------------------------------------------------------------
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_later'] = {}
+        state['comm'] = None
+        state['_pts_t'] = self._pts_t.cpu().numpy()
+        for b in state['bounds']:
+            if hasattr(b, '_fifo') and b._fifo is not None:
+                pass
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._pts_t = torch.from_numpy(state['_pts_t']).cuda()
 
     # ------------------------------------------------------------------
     # public views
@@ -498,7 +523,7 @@ class Sampler:
                     torch.from_numpy(self.log_l_t[idx_t]).cuda())
                 self.log_l[-1] = np.concatenate(
                     (self.log_l[-1], self.log_l_t[idx_t]))
-        elif self.comm is not None and self.comm.world > 1 and self.explored:
+        elif self.comm is not None and self.explored:
             pts, log_l, log_l_dev, n_bound = self._sharded_batch(shell)
         else:
             pts, n_bound = self.sample_shell(shell)
