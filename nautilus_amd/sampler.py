@@ -396,8 +396,10 @@ class Sampler:
             if transfer or later is None:
                 n_req = need             # every drawn point is in the shell
             else:
+                # in-shell fraction seen so far (exploration points count
+                # even when they are discarded from the estimate)
                 n_s = self.shell_n_sample[s_idx]
-                frac = (self.shell_n[s_idx] + 1.0) / (n_s + 2.0) \
+                frac = (len(self.log_l[s_idx]) + 1.0) / (n_s + 2.0) \
                     if n_s > 0 else 0.5
                 n_req = int(min(4 * device_block(), need / frac * 1.15 + 256))
             x = bound.sample_device(n_req)
