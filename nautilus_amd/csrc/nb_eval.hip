@@ -208,6 +208,19 @@ __device__ __forceinline__ void mlp_layer1(const double* w, int ks_n,
   }
 }
 
+// asynchronous global -> LDS copy (global_load_lds_dwordx4): every wavefront
+// moves 1 KB chunks (LDS destination = wave-uniform base + lane * 16); the
+// data is complete after s_waitcnt vmcnt(0) + workgroup barrier
+typedef const void __attribute__((address_space(1))) * nb_gptr;
+typedef void __attribute__((address_space(3))) * nb_lptr;
+__device__ __forceinline__ void dma_weights(const double* __restrict__ src,
+                                            double* dst, int n_doubles,
+                                            int wave, int lane) {
+  for (int c = wave * 128; c < n_doubles; c += 4 * 128)
+    __builtin_amdgcn_global_load_lds((nb_gptr)(src + c + 2 * lane),
+                                     (nb_lptr)(dst + c), 16, 0, 0);
+}
+
 // cooperative global -> LDS copy by the whole workgroup (16 bytes per lane)
 __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
                                               double* dst, int n_doubles) {
@@ -270,9 +283,11 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
 // into dense 16-point tiles through LDS before the MLP (shell exclusion and
 // association only need it for a minority of the points; without the
 // gather a wavefront evaluates all 32 of its points if one needs it).
-template <int DT, bool COMPACT>
+template <int DT, int VARIANT>   // 0 gather, 1 dense + DMA double buffer, 2 dense
 __global__ void __launch_bounds__(256)
 nb_eval_kernel(EvalArgs a, int w_doubles) {
+  constexpr bool COMPACT = (VARIANT == 0);
+  constexpr bool DBUF = (VARIANT == 1);
   constexpr int DP = 16 * DT;
   constexpr int KS1MAX = 4 * DT + 1;
   constexpr int TS = 4 * KS1MAX + 1;        // LDS row stride of a gathered point
@@ -537,8 +552,50 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             double total[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) total[t] = 0.0;
-            for (int e = 0; e < E; ++e) {
-              const double* w1 = nets + e * net_stride;
+            if constexpr (DBUF) {
+              // dense path: layer-1 weights live in region A, layers 2-4 in
+              // region B; each region is refilled by DMA while the other one
+              // feeds the matrix cores (two barriers per network)
+              double* reg_a = wlds;
+              double* reg_b = tlds;
+              __syncthreads();
+              dma_weights(nets, reg_a, n_a, wave, lane);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __syncthreads();
+              for (int e = 0; e < E; ++e) {
+                const double* w1 = nets + e * net_stride;
+                double h1[TPW][4 * NB_HT1];
+                dma_weights(w1 + n_a, reg_b, n_b, wave, lane);
+                if (wave_mlp) {
+                  mlp_layer<KS1MAX, NB_HT1, true>(reg_a, ks1, tin[0], tin[1],
+                                                  lane, h1[0], h1[1]);
+                  if (lg == 0) { h1[0][25] = 1.0; h1[1][25] = 1.0; }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (e + 1 < E)
+                  dma_weights(w1 + net_stride, reg_a, n_a, wave, lane);
+                if (wave_mlp) {
+                  const double* w2 = reg_b;
+                  const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
+                  const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
+                  double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
+                  mlp_layer<26, NB_HT2, true>(w2, 26, h1[0], h1[1], lane,
+                                              h2[0], h2[1]);
+                  if (lg == 2) { h2[0][12] = 1.0; h2[1][12] = 1.0; }
+                  mlp_layer<13, NB_HT3, true>(w3, 13, h2[0], h2[1], lane,
+                                              h3[0], h3[1]);
+                  if (lg == 0) { h3[0][5] = 1.0; h3[1][5] = 1.0; }
+                  mlp_layer<6, 1, false>(w4, 6, h3[0], h3[1], lane, o[0],
+                                         o[1]);
+                  total[0] += o[0][0];
+                  total[1] += o[1][0];
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+              }
+            } else {
+            for (int e = 0; e < E; ++e) {              const double* w1 = nets + e * net_stride;
               double h1[TPW][4 * NB_HT1];
               __syncthreads();                       // LDS free
               stage_weights(w1, wlds, n_a);
@@ -579,6 +636,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                 }
                 total[0] += o[0][0];               // unit 0 lives in lg == 0
               }
+            }
             }
             if (COMPACT) {
               // scatter the scores back to the owners of the points
@@ -649,16 +707,21 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   }
 }
 
-template <int DT, bool COMPACT>
+template <int DT, int VARIANT>
 int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
+  constexpr bool COMPACT = (VARIANT == 0);
   constexpr int TS = 4 * (4 * DT + 1) + 1;
   const int w_doubles = lds_tiles * NB_TILE;
-  const size_t lds = ((size_t)w_doubles + (COMPACT ? 128 * TS + 128 : 0)) *
+  // gather variant: [weights stage][128 gathered inputs][128 scores];
+  // dense variant:  [region A: layer 1 / ellipsoid block][region B: layers 2-4]
+  const size_t lds = ((size_t)w_doubles +
+                      (COMPACT ? 128 * TS + 128
+                               : (VARIANT == 1 ? 38 * NB_TILE : 0))) *
                      sizeof(double);
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_kernel<DT, COMPACT>,
+        (const void*)nb_eval_kernel<DT, VARIANT>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -674,7 +737,7 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   long long blocks = n_super;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_eval_kernel<DT, COMPACT>), dim3((unsigned)blocks),
+  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT>), dim3((unsigned)blocks),
                      dim3(256), lds, stream, a, w_doubles);
   return NB_OK;
 }
@@ -689,8 +752,10 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC) &&
                            getenv("NB_EVAL_NO_GATHER") == nullptr;
   if (sparse_mode && need <= 160 * 1024)
-    return launch_eval_impl<DT, true>(a, lds_tiles, stream);
-  return launch_eval_impl<DT, false>(a, lds_tiles, stream);
+    return launch_eval_impl<DT, 0>(a, lds_tiles, stream);
+  if (((size_t)lds_tiles + 38) * NB_TILE * 8 <= 160 * 1024)
+    return launch_eval_impl<DT, 1>(a, lds_tiles, stream);
+  return launch_eval_impl<DT, 2>(a, lds_tiles, stream);
 }
 
 }  // namespace
