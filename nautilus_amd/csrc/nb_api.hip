@@ -205,7 +205,7 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   const int64_t ell_size = nb_ell_block_size(dt);
   const int64_t net_stride = (int64_t)nb_net_tiles(kt1) * NB_TILE;
   const int64_t neural_stride = ell_size + 2 + 2 * dp + (int64_t)E * net_stride;
-  const int64_t draw_stride = 2 + 3 * dp + (int64_t)dp * (dp + 1) / 2;
+  const int64_t draw_stride = 2 + 4 * dp + (int64_t)dp * (dp + 1) / 2;
 
   int64_t off = NB_HDR;
   const int64_t off_cdf = off; off += ((K > 0 ? K : 1) + 1) / 2 * 2;
@@ -304,11 +304,19 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
     }
     put_i64(buf, at, md.n_ell);
     put_i64(buf, at + 1, nc);
+    // slot of every column: ellipsoid dims first, then the cube dims
+    {
+      int cube_slot = md.n_ell;
+      for (int f = 0; f < n_dim; ++f)
+        if (!is_ell[f]) put_i64(buf, at + 2 + 2 * dp + f, cube_slot++);
+    }
     for (int i = 0; i < md.n_ell; ++i) {
-      put_i64(buf, at + 2 + i, md.idx_ell ? md.idx_ell[i] : i);
-      buf[at + 2 + 2 * dp + i] = md.c[i];
+      const int f = md.idx_ell ? md.idx_ell[i] : i;
+      put_i64(buf, at + 2 + i, f);
+      put_i64(buf, at + 2 + 2 * dp + f, i);
+      buf[at + 2 + 3 * dp + i] = md.c[i];
       for (int j = 0; j <= i; ++j)
-        buf[at + 2 + 3 * dp + (size_t)i * (i + 1) / 2 + j] =
+        buf[at + 2 + 4 * dp + (size_t)i * (i + 1) / 2 + j] =
             md.B[(size_t)i * md.n_ell + j];
     }
   }

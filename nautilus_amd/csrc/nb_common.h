@@ -50,8 +50,8 @@ typedef double nb_d4 __attribute__((ext_vector_type(4)));
 //   E nets, each: L1 tiles [KT1][7], L2 [7][4], L3 [4][2], L4 [2][1]
 //   (weights W_l[k][h] with the bias stored as row k = K_l; zero padded)
 // Draw block (compact, for the per-proposal VALU draw kernel):
-//   n_ell, n_cube, idx_ell[DP], idx_cube[DP] (as int64 bits), c[n_ell->DP],
-//   B packed lower-triangular row-major [DP*(DP+1)/2]
+//   n_ell, n_cube, idx_ell[DP], idx_cube[DP], slot_of_column[DP] (as int64
+//   bits), c[n_ell->DP], B packed lower-triangular row-major [DP*(DP+1)/2]
 // ---------------------------------------------------------------------------
 #define NB_HDR 32
 

@@ -9,16 +9,22 @@ namespace {
 //                     same distribution as multinomial + shuffle)
 //   basic.py:376-381  z ~ N(0,I); z /= |z|; z *= u^(1/D); x = B z + c
 //   basic.py:85, 633-640  cube columns ~ U[0,1)
-// z lives in LDS in column layout z[j][lane] (bank-conflict free).
+// z lives in LDS in column layout z[slot][lane]; x = B z + c is formed in place
+// (last row first) and the 64 x D block of the wavefront is then written with
+// fully coalesced stores.
 // ---------------------------------------------------------------------------
+constexpr int ZS = 65;     // LDS row stride (odd: transposed reads conflict-free)
+
 __global__ void __launch_bounds__(64)
 nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
                unsigned long long offset, long long n,
                double* __restrict__ x_out) {
-  extern __shared__ __attribute__((aligned(16))) double zs[];
+  extern __shared__ __attribute__((aligned(16))) double zs[];   // [slot][ZS]
+  __shared__ int member_of[64];
   const int lane = threadIdx.x;
-  const long long i = (long long)blockIdx.x * 64 + lane;
-  if (i >= n) return;
+  const long long i0 = (long long)blockIdx.x * 64;
+  const long long i = i0 + lane;
+  const bool on = i < n;
   const unsigned long long g = offset + (unsigned long long)i;
 
   const int n_dim = (int)nb_hdr(blob, NB_H_NDIM);
@@ -33,52 +39,87 @@ nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
   nb_uniform_pair(seed, g, 1u, NB_TAG_CTRL, u_radius, u_spare);
 
   int m = 0;
-  for (int j = 0; j < K; ++j) m += (cdf[j] <= u_member) ? 1 : 0;
-  if (m > K - 1) m = K - 1;
+  if (K > 1) {
+    for (int j = 0; j < K; ++j) m += (cdf[j] <= u_member) ? 1 : 0;
+    if (m > K - 1) m = K - 1;
+  }
+  member_of[lane] = m;
 
-  const double* blk = draw + m * draw_stride;
+  // K == 1: the member block is wave uniform (scalar loads feed the FMAs)
+  const double* blk = (K == 1) ? draw : draw + m * draw_stride;
   const long long* iblk = (const long long*)blk;
   const int ne = (int)iblk[0];
   const int nc = (int)iblk[1];
-  const long long* idx_ell = iblk + 2;
-  const long long* idx_cube = idx_ell + dp;
-  const double* c = blk + 2 + 2 * dp;
+  const double* c = blk + 2 + 3 * dp;
   const double* B = c + dp;
 
-  double* row = x_out + i * n_dim;
-
-  if (ne > 0) {
-    double norm2 = 0.0;
-    for (int j = 0; 2 * j < ne; ++j) {
-      double u0, u1;
-      nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_NORMAL, u0, u1);
-      const double r = sqrt(-2.0 * log(1.0 - u0));
-      double sn, cs;
-      sincos(2.0 * M_PI * u1, &sn, &cs);
-      const double z0 = r * cs, z1 = r * sn;
-      zs[(2 * j) * 64 + lane] = z0;
-      norm2 += z0 * z0;
-      if (2 * j + 1 < ne) {
-        zs[(2 * j + 1) * 64 + lane] = z1;
-        norm2 += z1 * z1;
+  if (on) {
+    // ellipsoid part: slots 0..ne-1 (basic.py:376-381)
+    if (ne > 0) {
+      double norm2 = 0.0;
+      for (int j = 0; 2 * j < ne; ++j) {
+        double u0, u1;
+        nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_NORMAL, u0, u1);
+        const double r = sqrt(-2.0 * log(1.0 - u0));
+        double sn, cs;
+        sincos(2.0 * M_PI * u1, &sn, &cs);
+        const double z0 = r * cs, z1 = r * sn;
+        zs[(2 * j) * ZS + lane] = z0;
+        norm2 += z0 * z0;
+        if (2 * j + 1 < ne) {
+          zs[(2 * j + 1) * ZS + lane] = z1;
+          norm2 += z1 * z1;
+        }
+      }
+      const double nrm = sqrt(norm2);
+      const double rad = pow(u_radius, 1.0 / (double)ne);
+      for (int j = 0; j < ne; ++j)
+        zs[j * ZS + lane] = (zs[j * ZS + lane] / nrm) * rad;
+      // x = B z + c in place, last row first (row r only needs z_0..z_r)
+      for (int r = ne - 1; r >= 0; --r) {
+        const double* brow = B + (long long)r * (r + 1) / 2;
+        // fixed summation order j = 0..r (the oracle's), 8 independent
+        // operand loads in flight per trip
+        double acc = 0.0;
+        int j = 0;
+        for (; j + 8 <= r + 1; j += 8) {
+          double bv[8], zv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            bv[u] = brow[j + u];
+            zv[u] = zs[(j + u) * ZS + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += bv[u] * zv[u];
+        }
+        for (; j <= r; ++j) acc += brow[j] * zs[j * ZS + lane];
+        zs[r * ZS + lane] = acc + c[r];
       }
     }
-    const double nrm = sqrt(norm2);
-    const double rad = pow(u_radius, 1.0 / (double)ne);
-    for (int j = 0; j < ne; ++j)
-      zs[j * 64 + lane] = (zs[j * 64 + lane] / nrm) * rad;
-    for (int r = 0; r < ne; ++r) {
-      const double* brow = B + (long long)r * (r + 1) / 2;
-      double acc = 0.0;
-      for (int j = 0; j <= r; ++j) acc += brow[j] * zs[j * 64 + lane];
-      row[idx_ell[r]] = acc + c[r];
+    // cube part: slots ne..ne+nc-1 (basic.py:85, 633-640)
+    for (int j = 0; 2 * j < nc; ++j) {
+      double u0, u1;
+      nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_CUBE, u0, u1);
+      zs[(ne + 2 * j) * ZS + lane] = u0;
+      if (2 * j + 1 < nc) zs[(ne + 2 * j + 1) * ZS + lane] = u1;
     }
   }
-  for (int j = 0; 2 * j < nc; ++j) {
-    double u0, u1;
-    nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_CUBE, u0, u1);
-    row[idx_cube[2 * j]] = u0;
-    if (2 * j + 1 < nc) row[idx_cube[2 * j + 1]] = u1;
+  __syncthreads();
+
+  // coalesced store of the wavefront's contiguous 64 x D block; every row
+  // maps its columns to slots through its member's table
+  long long rows = n - i0;
+  if (rows > 64) rows = 64;
+  const int total = (int)rows * n_dim;
+  int row = lane / n_dim, col = lane - row * n_dim;
+  const int drow = 64 / n_dim, dcol = 64 - drow * n_dim;
+  double* dst = x_out + i0 * n_dim;
+  for (int e = lane; e < total; e += 64) {
+    const long long* sl = (const long long*)(draw + member_of[row] *
+                                             draw_stride) + 2 + 2 * dp;
+    dst[e] = zs[(int)sl[col] * ZS + row];
+    row += drow; col += dcol;
+    if (col >= n_dim) { col -= n_dim; ++row; }
   }
 }
 
@@ -285,7 +326,7 @@ int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
                    hipStream_t stream) {
   if (n <= 0) return NB_OK;
   const long long blocks = (n + 63) / 64;
-  const size_t lds = (size_t)n_dim * 64 * sizeof(double);
+  const size_t lds = (size_t)n_dim * 65 * sizeof(double);
   hipLaunchKernelGGL(nb_draw_kernel, dim3((unsigned)blocks), dim3(64), lds,
                      stream, blob_dev, seed, offset, n, x_out);
   NB_HIP_CHECK(hipGetLastError());
