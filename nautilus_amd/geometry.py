@@ -164,6 +164,35 @@ def ellipsoids_overlap(params):
     return False
 
 
+N_INIT = 10          # bounds/union.py:186
+_GMM_POOL = None
+
+
+def _fit_one(args):
+    from sklearn.mixture import GaussianMixture
+    points_t, seed = args
+    with threadpool_limits(limits=1):
+        return GaussianMixture(n_components=2, n_init=1,
+                               random_state=seed).fit(points_t)
+
+
+def _best_of_inits(points_t, random_state):
+    """Best of N_INIT EM runs of a two-component mixture.  The reference runs
+    them sequentially inside one ``GaussianMixture(n_init=10)`` call; here the
+    restarts get seeds derived from ``random_state`` and run concurrently on
+    host threads (numpy releases the GIL inside BLAS), which keeps the host
+    part of bound construction short.  Same estimator, same selection rule
+    (largest lower bound), deterministic for a given ``random_state``."""
+    global _GMM_POOL
+    from concurrent.futures import ThreadPoolExecutor
+    seeds = np.random.RandomState(random_state).randint(2**31 - 1,
+                                                        size=N_INIT)
+    if _GMM_POOL is None:
+        _GMM_POOL = ThreadPoolExecutor(max_workers=N_INIT)
+    fits = list(_GMM_POOL.map(_fit_one, [(points_t, int(sd)) for sd in seeds]))
+    return max(fits, key=lambda g: g.lower_bound_)
+
+
 def two_component_labels(points_t, n_points_min, random_state):
     """Hard assignment of points to the two components of a full-covariance
     Gaussian mixture, re-balanced so that both clusters keep at least
@@ -171,9 +200,7 @@ def two_component_labels(points_t, n_points_min, random_state):
     scikit-learn's ``GaussianMixture`` -- the reference's own dependency for
     this step."""
     from scipy.stats import multivariate_normal
-    from sklearn.mixture import GaussianMixture
-    gmm = GaussianMixture(n_components=2, n_init=10,
-                          random_state=random_state).fit(points_t)
+    gmm = _best_of_inits(points_t, random_state)
     logp = np.vstack([multivariate_normal.logpdf(
         points_t, mean=gmm.means_[i], cov=gmm.covariances_[i]) +
         np.log(gmm.weights_[i]) for i in range(2)]).T
