@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
 
 typedef struct nb_bound nb_bound;          /* opaque bound living in HBM     */
 typedef struct nb_boundlist nb_boundlist;  /* device array of bound pointers */
@@ -84,6 +84,12 @@ typedef struct {
   int32_t unit_cube;
   int32_t n_neural;
   const nb_neural_desc* neural;
+  /* NautilusBound.shift (bounds/periodic.py:6-19, nautilus.py:91-96): the
+   * periodic dimensions and their centres; contains() recentres the points
+   * first (nautilus.py:162-163).  n_periodic = 0: no shift.                 */
+  int32_t n_periodic;
+  const int32_t* periodic;      /* [n_periodic] PhaseShift.periodic          */
+  const double* centers;        /* [n_periodic] PhaseShift.centers           */
 } nb_bound_desc;
 
 int nb_abi_version(void);
@@ -209,6 +215,14 @@ int nb_set_eval_counters(uint64_t* counters_dev);
 /* fp64 MFMA issue-rate microbenchmark (peak calibration for bench.py):
  * returns achieved TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64.          */
 int nb_mfma_f64_peak(int32_t iters, double* tflops_host);
+
+/* PhaseShift.transform (bounds/periodic.py:50-72), in place on device rows:
+ * x[:, periodic[i]] = (x[:, periodic[i]] -/+ (0.5 - centers[i])) mod 1
+ * (inverse != 0 undoes the shift, nautilus.py:241-243).  `periodic` and
+ * `centers` are host arrays.                                                */
+int nb_phase_shift(double* x_dev, int64_t n, int32_t n_dim, int32_t n_periodic,
+                   const int32_t* periodic, const double* centers,
+                   int32_t inverse, void* stream);
 
 /* The roofline kernel: single-ellipsoid contains (basic.py:344-360) with the
  * points streamed once from HBM.  Same result as nb_contains.               */

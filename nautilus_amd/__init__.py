@@ -13,6 +13,7 @@ _LAZY = {
     'UnitCube': 'bounds', 'Ellipsoid': 'bounds',
     'UnitCubeEllipsoidMixture': 'bounds', 'Union': 'bounds',
     'NeuralBound': 'bounds', 'NautilusBound': 'bounds',
+    'PhaseShift': 'bounds',
     'NeuralNetworkEmulator': 'emulator',
     'GaussianLikelihood': 'likelihoods',
     'GaussianMixtureLikelihood': 'likelihoods', 'unit_prior': 'likelihoods',

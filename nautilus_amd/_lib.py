@@ -36,7 +36,9 @@ class BoundDesc(C.Structure):
     _fields_ = [('n_dim', C.c_int32), ('n_members', C.c_int32),
                 ('members', C.POINTER(MemberDesc)), ('log_v_all', c_double_p),
                 ('unit_cube', C.c_int32), ('n_neural', C.c_int32),
-                ('neural', C.POINTER(NeuralDesc))]
+                ('neural', C.POINTER(NeuralDesc)),
+                ('n_periodic', C.c_int32), ('periodic', c_int32_p),
+                ('centers', c_double_p)]
 
 
 _SIGNATURES = {
@@ -93,6 +95,9 @@ _SIGNATURES = {
                                     C.c_void_p]),
     'nb_set_eval_counters': (C.c_int, [C.c_void_p]),
     'nb_mfma_f64_peak': (C.c_int, [C.c_int32, c_double_p]),
+    'nb_phase_shift': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                 c_int32_p, c_double_p, C.c_int32,
+                                 C.c_void_p]),
     'nb_ellipsoid_contains_stream': (C.c_int, [C.c_void_p, C.c_void_p,
                                                C.c_int64, C.c_void_p,
                                                C.c_void_p]),
@@ -117,7 +122,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.nb_abi_version() != 1:
+    if lib.nb_abi_version() != 2:
         raise RuntimeError('nautilus_amd: ABI version mismatch')
     _lib = lib
     return lib

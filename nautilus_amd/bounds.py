@@ -347,7 +347,12 @@ class _RejectionSampler(_DeviceBoundBase):
             rows, counts = self.device_bound().sample_launch(seed, off, n_draw)
             c = counts.cpu().numpy()
             self._account(n_draw, int(c[0]), int(c[1]))
-            q.push(rows[:int(c[1])])
+            rows = rows[:int(c[1])]
+            shift = getattr(self, 'shift', None)
+            if shift is not None:      # back to the sampler's frame (:241-243)
+                device.phase_shift_(rows, shift.periodic, shift.centers,
+                                    inverse=True)
+            q.push(rows)
 
     def sample_device(self, n_points=100):
         self._fill(n_points)
@@ -577,6 +582,52 @@ class NeuralBound(_DeviceBoundBase):
         return _to_numpy_mask(self.contains_device(pts), points)
 
 
+class PhaseShift:
+    """Recentring of periodic dimensions (reference bounds/periodic.py:6-72):
+    the largest gap between the points of a periodic dimension is moved onto
+    the boundary of the unit interval."""
+
+    @classmethod
+    def compute(cls, points, periodic):
+        """periodic.py:21-46.  ``points``: host array or cuda tensor of the
+        live points; only the ``len(periodic)`` columns are sorted."""
+        self = cls()
+        self.periodic = np.asarray(periodic)
+        self.centers = np.zeros(len(self.periodic))
+        if isinstance(points, torch.Tensor):
+            cols = torch.sort(points[:, torch.as_tensor(
+                self.periodic, device=points.device, dtype=torch.long)],
+                dim=0).values.cpu().numpy()
+        else:
+            cols = np.sort(np.asarray(points)[:, self.periodic], axis=0)
+        for i in range(len(self.periodic)):
+            x = cols[:, i]
+            gaps = np.append(np.diff(x), x[0] - (x[-1] - 1))
+            self.centers[i] = (x[np.argmax(gaps)] + np.amax(gaps) / 2.0 +
+                               0.5) % 1
+        return self
+
+    @classmethod
+    def from_params(cls, periodic, centers):
+        self = cls()
+        self.periodic = np.asarray(periodic)
+        self.centers = np.asarray(centers, float)
+        return self
+
+    def transform_device(self, x, inverse=False):
+        """New cuda tensor with the shift applied (``nb_phase_shift``)."""
+        out = device.as_device_points(x, None).clone()
+        return device.phase_shift_(out, self.periodic, self.centers, inverse)
+
+    def transform(self, points, inverse=False):
+        """periodic.py:50-72; numpy in -> numpy out, tensor in -> tensor."""
+        out = self.transform_device(points, inverse)
+        return out if isinstance(points, torch.Tensor) else out.cpu().numpy()
+
+    def params(self):
+        return self.periodic, self.centers
+
+
 def transform_device(ellipsoid, x):
     """B_inv (x - c) for a cuda tensor of points (reference basic.py:340).
     A one-off per bound construction; expressed as a dense product."""
@@ -596,18 +647,18 @@ class NautilusBound(_RejectionSampler):
                 enlarge_per_dim=1.1, n_points_min=None, split_threshold=100,
                 periodic=None, n_networks=4, neural_network_kwargs={},
                 pool=None, rng=None):
-        if periodic is not None:
-            raise NotImplementedError(
-                'periodic parameters are not supported by the device path '
-                'yet (SURVEY.md section 8 row f4)')
         self = cls()
         t0 = time()
         log_l = np.asarray(log_l)
         x = device.as_device_points(points)
         self.n_dim = x.shape[1]
-        self.shift = None
         self._init_sampling(rng)
-        live = x[torch.from_numpy(log_l >= log_l_min).cuda()].cpu().numpy()
+        is_live = torch.from_numpy(log_l >= log_l_min).cuda()
+        self.shift = None
+        if periodic is not None:                          # nautilus.py:91-96
+            self.shift = PhaseShift.compute(x[is_live], periodic)
+            x = self.shift.transform_device(x)
+        live = x[is_live].cpu().numpy()
 
         # non-overlapping ellipsoids -> one neural bound each (:100-114)
         multi = Union.compute(live, enlarge_per_dim=enlarge_per_dim,
@@ -646,10 +697,10 @@ class NautilusBound(_RejectionSampler):
         return self
 
     @classmethod
-    def from_parts(cls, outer_bound, neural_bounds, rng=None):
+    def from_parts(cls, outer_bound, neural_bounds, rng=None, shift=None):
         self = cls()
         self.n_dim = outer_bound.n_dim
-        self.shift = None
+        self.shift = shift
         self.outer_bound = outer_bound
         self.neural_bounds = list(neural_bounds)
         self._init_sampling(rng)
@@ -659,7 +710,8 @@ class NautilusBound(_RejectionSampler):
         u = self.outer_bound
         return device.DeviceBound(
             self.n_dim, [b._member() for b in u.bounds], u.log_v_all,
-            u.cube is not None, [nb._neural() for nb in self.neural_bounds])
+            u.cube is not None, [nb._neural() for nb in self.neural_bounds],
+            shift=None if self.shift is None else self.shift.params())
 
     def _acceptance(self):
         a = 1.0

@@ -33,6 +33,9 @@ int nb_launch_philox(unsigned long long seed, unsigned long long offset,
                      unsigned block, unsigned tag, long long n, double* u,
                      hipStream_t stream);
 int nb_run_mfma_peak(int iters, double* tflops);
+int nb_launch_phase_shift(double* x, long long n, int n_dim, const double* s,
+                          const unsigned char* on, int inverse,
+                          hipStream_t stream);
 int nb_launch_ell_stream(const double* cvec, const double* binv, int n_dim,
                          const double* x, long long n, unsigned char* mask,
                          hipStream_t stream);
@@ -218,6 +221,13 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
                             d->members[0].n_ell == n_dim);
   const int64_t off_stream = off;
   if (single_full) off += dp + (int64_t)dt * (dt + 1) / 2 * NB_TILE;
+  if (d->n_periodic < 0 || d->n_periodic > n_dim ||
+      (d->n_periodic > 0 && (d->periodic == nullptr || d->centers == nullptr))) {
+    nb_set_error("bad periodic description");
+    return NB_ERR_ARG;
+  }
+  const int64_t off_shift = off;
+  if (d->n_periodic > 0) off += 2 * dp;
   const int64_t total = off;
 
   std::vector<double> buf((size_t)total, 0.0);
@@ -240,6 +250,17 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   put_i64(buf, NB_H_KT1, kt1);
   put_i64(buf, NB_H_TOTAL, total);
   put_i64(buf, NB_H_OFF_STREAM, single_full ? off_stream : 0);
+  put_i64(buf, NB_H_OFF_SHIFT, d->n_periodic > 0 ? off_shift : 0);
+  for (int i = 0; i < d->n_periodic; ++i) {
+    const int f = d->periodic[i];
+    if (f < 0 || f >= n_dim) {
+      nb_set_error("periodic index %d out of range", f);
+      return NB_ERR_ARG;
+    }
+    // periodic.py:69-71: the forward shift adds (-center + 0.5)
+    buf[off_shift + slot_of_feature(f)] = -d->centers[i] + 0.5;
+    buf[off_shift + dp + slot_of_feature(f)] = 1.0;
+  }
   if (single_full) {
     // stream block: c, then lower-triangular tiles with the K permutation of
     // nb_stream.hip (slot 4kt+s of lane group lg <-> feature
@@ -532,6 +553,28 @@ int nb_set_eval_counters(uint64_t* counters_dev) {
 
 int nb_mfma_f64_peak(int32_t iters, double* tflops) {
   return nb_run_mfma_peak(iters, tflops);
+}
+
+int nb_phase_shift(double* x, int64_t n, int32_t n_dim, int32_t n_periodic,
+                   const int32_t* periodic, const double* centers,
+                   int32_t inverse, void* stream) {
+  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT || n_periodic < 0 ||
+      (n_periodic > 0 && (periodic == nullptr || centers == nullptr))) {
+    nb_set_error("bad phase shift arguments");
+    return NB_ERR_ARG;
+  }
+  double s[16 * NB_MAX_DT] = {0.0};
+  unsigned char on[16 * NB_MAX_DT] = {0};
+  for (int i = 0; i < n_periodic; ++i) {
+    if (periodic[i] < 0 || periodic[i] >= n_dim) {
+      nb_set_error("periodic index %d out of range", periodic[i]);
+      return NB_ERR_ARG;
+    }
+    s[periodic[i]] = -centers[i] + 0.5;
+    on[periodic[i]] = 1;
+  }
+  if (n <= 0 || n_periodic == 0) return NB_OK;
+  return nb_launch_phase_shift(x, n, n_dim, s, on, inverse, as_stream(stream));
 }
 
 int nb_ellipsoid_contains_stream(const nb_bound* b, const double* x, int64_t n,

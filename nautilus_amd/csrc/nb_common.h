@@ -35,6 +35,9 @@ typedef double nb_d4 __attribute__((ext_vector_type(4)));
 //   hdr[17] total doubles   hdr[18] off_stream (single full ellipsoid only:
 //                           c[DP], then DT(DT+1)/2 K-permuted 16x16 tiles of
 //                           B_inv^T, see nb_stream.hip)
+//   hdr[19] off_shift (0 = no periodic dimensions): shift[DP], on[DP] in slot
+//                           order; contains() tests frac(x + shift) where on
+//                           (bounds/periodic.py:50-72)
 //
 // Ell block (member of the outer union, or ellipsoid of a neural bound):
 //   [0]            n_ell (as int64 bits; 0 => pure cube member, no MFMA work)
@@ -59,7 +62,7 @@ enum {
   NB_H_NDIM = 0, NB_H_DT, NB_H_K, NB_H_USECUBE, NB_H_M, NB_H_E, NB_H_OFF_CDF,
   NB_H_OFF_ULO, NB_H_OFF_UHI, NB_H_OFF_MEMBERS, NB_H_ELL_STRIDE,
   NB_H_OFF_NEURAL, NB_H_NEURAL_STRIDE, NB_H_OFF_DRAW, NB_H_DRAW_STRIDE,
-  NB_H_NET_STRIDE, NB_H_KT1, NB_H_TOTAL, NB_H_OFF_STREAM
+  NB_H_NET_STRIDE, NB_H_KT1, NB_H_TOTAL, NB_H_OFF_STREAM, NB_H_OFF_SHIFT
 };
 
 __host__ __device__ inline int64_t nb_hdr(const double* blob, int i) {

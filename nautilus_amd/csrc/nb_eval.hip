@@ -243,7 +243,8 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
                                             const long long (&pt)[TPW],
                                             const bool (&valid)[TPW],
                                             int n_dim, long long n, int lane,
-                                            double (&xin)[TPW][4 * DT]) {
+                                            double (&xin)[TPW][4 * DT],
+                                            const double* shift = nullptr) {
   const int lg = lane >> 4;
   const bool even = (n_dim & 1) == 0;
   // the loads are loop invariant across the bounds of a list; laundering the
@@ -274,6 +275,21 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
         const double v1 = row[f + 1 < n_dim ? f + 1 : n_dim - 1];
         xin[t][2 * j] = (valid[t] && f < n_dim) ? v0 : 0.0;
         xin[t][2 * j + 1] = (valid[t] && f + 1 < n_dim) ? v1 : 0.0;
+      }
+    }
+  }
+  // periodic dimensions are recentred before the test (nautilus.py:162-163,
+  // periodic.py:69-71): x <- (x + (0.5 - centre)) mod 1
+  if (shift != nullptr) {
+    constexpr int DP = 16 * DT;
+#pragma unroll
+    for (int ks = 0; ks < 4 * DT; ++ks) {
+      const double sv = shift[4 * ks + lg];
+      const bool on = shift[DP + 4 * ks + lg] != 0.0;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const double v = xin[t][ks] + sv;
+        xin[t][ks] = on ? v - floor(v) : xin[t][ks];
       }
     }
   }
@@ -333,13 +349,19 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       const double* uhi = blob + nb_hdr(blob, NB_H_OFF_UHI);
       const long long ell_stride = nb_hdr(blob, NB_H_ELL_STRIDE);
       const long long neural_stride = nb_hdr(blob, NB_H_NEURAL_STRIDE);
+      // contains() of a bound with periodic dimensions sees recentred points;
+      // proposals (SAMPLE / COUNT / SCORE) already live in the shifted frame
+      const long long off_shift = nb_hdr(blob, NB_H_OFF_SHIFT);
+      const double* shift =
+          (off_shift != 0 && (a.mode == MODE_ANY || a.mode == MODE_ASSOC))
+              ? blob + off_shift : nullptr;
 
       // unit-cube clip of the union (union.py:287-288 / 313-314)
       bool in_cube[TPW], active[TPW];
       int k_cnt[TPW];
       {
         double xin[TPW][4 * DT];
-        load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin);
+        load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
 
         // Bounding-sphere pre-test (shell exclusion / association): a point
         // of a bound with neural bounds lies inside one of their ellipsoids,
@@ -452,7 +474,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           bool box_bad[TPW], inside_e[TPW], need[TPW];
           {
             double xin[TPW][4 * DT];
-            load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin);
+            load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
             __syncthreads();
             stage_weights(nb_m, wlds, nb_ell_block_size(DT));
             __syncthreads();

@@ -407,3 +407,43 @@ int nb_run_mfma_peak(int iters, double* tflops) {
   (void)hipFree(sink);
   return NB_OK;
 }
+
+// ---------------------------------------------------------------------------
+// PhaseShift.transform (bounds/periodic.py:50-72), in place.  numpy's
+// ``v % 1`` for doubles is fmod(v, 1), plus 1 if that is negative; for the
+// values that occur (|v| < 2) this equals v - floor(v) bit for bit.
+// ---------------------------------------------------------------------------
+namespace {
+struct ShiftArgs {
+  double s[16 * NB_MAX_DT];
+  unsigned char on[16 * NB_MAX_DT];
+};
+
+__global__ void __launch_bounds__(256)
+nb_phase_shift_kernel(double* __restrict__ x, long long total, int n_dim,
+                      ShiftArgs a, int inverse) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+       e < total; e += stride) {
+    const int col = (int)(e % n_dim);
+    if (a.on[col]) {
+      const double v = inverse ? x[e] - a.s[col] : x[e] + a.s[col];
+      x[e] = v - floor(v);
+    }
+  }
+}
+}  // namespace
+
+int nb_launch_phase_shift(double* x, long long n, int n_dim, const double* s,
+                          const unsigned char* on, int inverse,
+                          hipStream_t stream) {
+  ShiftArgs a;
+  for (int i = 0; i < 16 * NB_MAX_DT; ++i) { a.s[i] = s[i]; a.on[i] = on[i]; }
+  const long long total = n * n_dim;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nb_phase_shift_kernel, dim3((unsigned)blocks), dim3(256),
+                     0, stream, x, total, n_dim, a, inverse);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}

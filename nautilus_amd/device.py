@@ -63,7 +63,9 @@ class DeviceBound:
     """One bound (any type of the reference) uploaded to HBM."""
 
     def __init__(self, n_dim, members=(), log_v_all=None, unit_cube=False,
-                 neural=()):
+                 neural=(), shift=None):
+        """``shift``: optional (periodic indices, centers) of the bound's
+        PhaseShift (reference bounds/nautilus.py:91-96)."""
         lib = _lib.load()
         self.n_dim = int(n_dim)
         self.n_members = len(members)
@@ -126,6 +128,14 @@ class DeviceBound:
         desc.unit_cube = 1 if unit_cube else 0
         desc.n_neural = self.n_neural
         desc.neural = n_arr
+        desc.n_periodic = 0
+        if shift is not None and len(shift[0]) > 0:
+            per = np.ascontiguousarray(shift[0], dtype=np.int32)
+            cen = _f64(shift[1])
+            keep += [per, cen]
+            desc.n_periodic = len(per)
+            desc.periodic = per.ctypes.data_as(_lib.c_int32_p)
+            desc.centers = _dp(cen)
         handle = C.c_void_p()
         _lib.check(lib.nb_bound_create(C.byref(desc), C.byref(handle)))
         self._h = handle
@@ -228,6 +238,22 @@ class DeviceBoundList:
         _lib.check(self._lib.nb_first_containing(self._h, _ptr(x), x.shape[0],
                                                  _ptr(idx), _stream()))
         return idx
+
+
+def phase_shift_(x, periodic, centers, inverse=False):
+    """PhaseShift.transform (reference bounds/periodic.py:50-72) applied in
+    place to the rows of the cuda tensor ``x``."""
+    lib = _lib.load()
+    if x.shape[0] == 0 or len(periodic) == 0:
+        return x
+    assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+    per = np.ascontiguousarray(periodic, dtype=np.int32)
+    cen = _f64(centers)
+    _lib.check(lib.nb_phase_shift(
+        _ptr(x), x.shape[0], x.shape[1], len(per),
+        per.ctypes.data_as(_lib.c_int32_p), _dp(cen), 1 if inverse else 0,
+        _stream()))
+    return x
 
 
 def compact_rows(x, flags, mask=1, want_index=False):

@@ -90,9 +90,6 @@ class Sampler:
                 '(SURVEY.md section 8 row f3)')
         if blobs_dtype is not None:
             raise NotImplementedError('blobs are not supported yet')
-        if periodic is not None:
-            raise NotImplementedError('periodic parameters are not supported '
-                                      'yet (SURVEY.md section 8 row f4)')
 
         self._device_likelihood = bool(getattr(likelihood, 'device', False))
         self._prior_is_identity = getattr(prior, '__name__', '') == \
@@ -130,7 +127,7 @@ class Sampler:
         self.n_points_min = (self.n_dim + 50 if n_points_min is None
                              else n_points_min)
         self.split_threshold = split_threshold
-        self.periodic = None
+        self.periodic = periodic
         self.n_networks = n_networks
         self.neural_network_kwargs = neural_network_kwargs
         self.vectorized = vectorized
@@ -614,6 +611,7 @@ class Sampler:
                         enlarge_per_dim=self.enlarge_per_dim,
                         n_points_min=self.n_points_min,
                         split_threshold=self.split_threshold,
+                        periodic=self.periodic,
                         n_networks=self.n_networks,
                         neural_network_kwargs=self.neural_network_kwargs,
                         pool=self.pool_s, rng=self.rng)

@@ -500,16 +500,55 @@ class ONeural:
         return ok
 
 
+class OPhaseShift:
+    """Recentring of periodic dimensions, nautilus/bounds/periodic.py:6-72."""
+
+    @classmethod
+    def build(cls, points, periodic):
+        """periodic.py:21-46: put the largest gap across the boundary."""
+        self = cls()
+        self.periodic = periodic
+        self.centers = np.zeros(len(periodic))
+        for i, dim in enumerate(periodic):
+            x = np.sort(points[:, dim])
+            gaps = np.append(np.diff(x), x[0] - (x[-1] - 1))
+            self.centers[i] = (x[np.argmax(gaps)] + np.amax(gaps) / 2.0 +
+                               0.5) % 1
+        return self
+
+    @classmethod
+    def from_params(cls, periodic, centers):
+        self = cls()
+        self.periodic = np.asarray(periodic)
+        self.centers = np.asarray(centers, float)
+        return self
+
+    def transform(self, points, inverse=False):
+        """periodic.py:50-72."""
+        out = np.copy(points)
+        sign = -1 if inverse else +1
+        for i, dim in enumerate(self.periodic):
+            out[:, dim] = (out[:, dim] + sign * (-self.centers[i] + 0.5)) % 1
+        return out
+
+
 class ONautilus:
-    """Composite bound, nautilus/bounds/nautilus.py:13-398 (periodic=None)."""
+    """Composite bound, nautilus/bounds/nautilus.py:13-398."""
+
+    shift = None
 
     @classmethod
     def build(cls, points, log_l, log_l_min, log_v_target,
               enlarge_per_dim=1.1, n_points_min=None, split_threshold=100,
-              n_networks=4, neural_network_kwargs={}, pool=None, rng=None):
+              periodic=None, n_networks=4, neural_network_kwargs={},
+              pool=None, rng=None):
         """nautilus.py:88-144."""
         self = cls()
         self.n_dim = points.shape[1]
+        if periodic is not None:                                # :91-96
+            self.shift = OPhaseShift.build(points[log_l >= log_l_min],
+                                           periodic)
+            points = self.shift.transform(points)
         self.neural_bounds = []
         live = points[log_l >= log_l_min]
 
@@ -544,9 +583,10 @@ class ONautilus:
         return self
 
     @classmethod
-    def from_parts(cls, outer_bound, neural_bounds, rng=None):
+    def from_parts(cls, outer_bound, neural_bounds, rng=None, shift=None):
         self = cls()
         self.n_dim = outer_bound.n_dim
+        self.shift = shift
         self.outer_bound = outer_bound
         self.neural_bounds = list(neural_bounds)
         self.rng = _rng(rng)
@@ -560,6 +600,8 @@ class ONautilus:
 
     def contains(self, x):
         """nautilus.py:162-169."""
+        if self.shift is not None:
+            x = self.shift.transform(x)
         ok = self.outer_bound.contains(x)
         if len(self.neural_bounds) > 0:
             ok = ok & self.neural_contains(x)
@@ -597,6 +639,8 @@ class ONautilus:
         if return_points:
             out = self.points[:n]
             self.points = self.points[n:]
+            if self.shift is not None:                          # :241-243
+                out = self.shift.transform(out, inverse=True)
             return out
 
     @property

@@ -4,8 +4,8 @@
 
 TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  Only the features the
 BASELINE configs use are restated: identity-style callable prior or none,
-``vectorized`` likelihood (or per-point), no blobs, no checkpointing, no
-periodic parameters, ``pool=None``.
+``vectorized`` likelihood (or per-point), no blobs, no checkpointing,
+``pool=None``.
 """
 
 from time import time
@@ -62,8 +62,10 @@ class OSampler:
     def __init__(self, prior, likelihood, n_dim, n_live=2000, n_update=None,
                  enlarge_per_dim=1.1, n_points_min=None, split_threshold=100,
                  n_networks=4, neural_network_kwargs={}, n_batch=None,
-                 n_like_new_bound=None, vectorized=False, seed=None):
+                 n_like_new_bound=None, vectorized=False, seed=None,
+                 periodic=None):
         self.prior = prior
+        self.periodic = periodic
         self.likelihood = likelihood
         self.n_dim = n_dim
         if n_dim <= 1:
@@ -312,6 +314,7 @@ class OSampler:
                         enlarge_per_dim=self.enlarge_per_dim,
                         n_points_min=self.n_points_min,
                         split_threshold=self.split_threshold,
+                        periodic=self.periodic,
                         n_networks=self.n_networks,
                         neural_network_kwargs=self.neural_network_kwargs,
                         rng=self.rng)

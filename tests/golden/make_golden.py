@@ -202,6 +202,78 @@ def neural_and_nautilus_case():
             for k, v in neural_arrays(nb_i, 'nb%d_' % i).items()})
 
 
+def periodic_cases():
+    """PhaseShift (bounds/periodic.py) alone, inside a NautilusBound, and in a
+    full run (the reference's tests/test_bounds.py:314-327 and
+    tests/test_sampler.py:395-416 cover the same ground)."""
+    np.random.seed(0)
+    pts_all, centers, fwd, back = [], [], [], []
+    for i in range(20):
+        pts = (np.random.random(size=(10, 4)) * 0.1 +
+               np.random.random(size=4)) % 1
+        shift = bounds.PhaseShift.compute(pts, np.array([0, 2]))
+        pts_all.append(pts)
+        centers.append(shift.centers)
+        fwd.append(shift.transform(pts))
+        back.append(shift.transform(fwd[-1], inverse=True))
+    save('phaseshift', points=np.array(pts_all), periodic=np.array([0, 2]),
+         centers=np.array(centers), forward=np.array(fwd),
+         inverse=np.array(back))
+
+    rng = np.random.default_rng(11)
+    pts = rng.random((600, 3))
+    delta = np.abs(pts - np.array([0.03, 0.5, 0.97]))
+    delta = np.minimum(delta, 1 - delta)            # periodic distance
+    log_l = -np.linalg.norm(delta, axis=1)
+    log_l_min = np.median(log_l)
+    periodic = np.array([0, 2])
+    full = bounds.NautilusBound.compute(
+        pts, log_l, log_l_min, np.log(0.5), n_networks=1, periodic=periodic,
+        rng=np.random.default_rng(0))
+    full.reset(np.random.default_rng(3))
+    drawn = full.sample(2000)
+    test = np.random.default_rng(2).random((2048, 3))
+    save('nautilusbound_periodic_D3', points=pts, log_l=log_l,
+         log_l_min=log_l_min, log_v_target=np.log(0.5), sample=drawn,
+         n_sample=full.n_sample, n_reject=full.n_reject,
+         outer_n_sample=full.outer_bound.n_sample,
+         outer_n_reject=full.outer_bound.n_reject, log_v=full.log_v,
+         test=test, contains=full.contains(test),
+         periodic=periodic, centers=full.shift.centers,
+         n_neural=len(full.neural_bounds),
+         n_outer=len(full.outer_bound.bounds),
+         K=len(full.outer_bound.bounds), unit=True,
+         log_v_all=full.outer_bound.log_v_all,
+         **member_arrays(full.outer_bound),
+         **{k: v for i, nb_i in enumerate(full.neural_bounds)
+            for k, v in neural_arrays(nb_i, 'nb%d_' % i).items()})
+
+    def wrapped(x):
+        return -0.5 * np.sum((np.abs(x - 0.5) - 0.5)**2, axis=-1) / 0.1
+
+    rows = []
+    for per, n_networks in [(True, 0), (False, 0), (True, 1)]:
+        s = nautilus.Sampler(lambda x: x, wrapped, n_dim=2, n_live=400,
+                             periodic=np.arange(2) if per else None,
+                             n_networks=n_networks, vectorized=True, seed=0)
+        s.run(n_eff=2000, discard_exploration=True)
+        p, log_w, _ = s.posterior()
+        rows.append(dict(
+            periodic=per, n_networks=n_networks, seed=0, n_live=400,
+            n_eff_target=2000, log_z=float(s.log_z), n_eff=float(s.n_eff),
+            n_like=int(s.n_like), n_bounds=len(s.bounds),
+            n_neural_per_bound=[len(b.neural_bounds) for b in s.bounds[1:]],
+            shell_n=s.shell_n.tolist(),
+            shell_log_v=s.shell_log_v.tolist(),
+            shell_log_l=s.shell_log_l.tolist()))
+        print('periodic e2e', per, n_networks, rows[-1]['log_z'],
+              rows[-1]['n_neural_per_bound'][-3:])
+    with open(os.path.join(HERE, 'e2e_periodic.json'), 'w') as f:
+        json.dump(dict(problem='2-D Gaussian wrapped around the corners of '
+                               'the unit square: -0.5 * |abs(x - 0.5) - 0.5|^2'
+                               ' / 0.1', runs=rows), f, indent=1)
+
+
 def gauss3(x):
     return -0.5 * np.sum(((x - np.array([0.4, 0.5, 0.6])) / 0.1)**2, axis=-1)
 
@@ -255,6 +327,9 @@ def e2e_cases():
 
 
 if __name__ == '__main__':
+    if '--periodic-only' in sys.argv:
+        periodic_cases()
+        sys.exit(0)
     if '--neural-only' in sys.argv:
         neural_and_nautilus_case()
         sys.exit(0)
@@ -266,4 +341,5 @@ if __name__ == '__main__':
     emulator_case(5, 1000, 1, 21)
     emulator_case(20, 600, 2, 22)
     neural_and_nautilus_case()
+    periodic_cases()
     e2e_cases()

@@ -38,7 +38,9 @@ def upload(bound):
         return device.DeviceBound(
             bound.n_dim, [member_from_oracle(m) for m in u.bounds],
             u.log_v_all, u.cube is not None,
-            [neural_from_oracle(nb) for nb in bound.neural_bounds])
+            [neural_from_oracle(nb) for nb in bound.neural_bounds],
+            shift=None if bound.shift is None else
+            (bound.shift.periodic, bound.shift.centers))
     if isinstance(bound, bo.OUnion):
         return device.DeviceBound(
             bound.n_dim, [member_from_oracle(m) for m in bound.bounds],
@@ -99,4 +101,7 @@ def nautilus_from_golden(g):
     outer = union_from_golden(g, True)
     neural = [neural_from_golden(g, 'nb%d_' % i)
               for i in range(int(g['n_neural']))]
-    return bo.ONautilus.from_parts(outer, neural)
+    shift = None
+    if 'centers' in g:
+        shift = bo.OPhaseShift.from_params(g['periodic'], g['centers'])
+    return bo.ONautilus.from_parts(outer, neural, shift=shift)

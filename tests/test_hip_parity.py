@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from helpers import upload, near_boundary
+from helpers import upload, near_boundary, nautilus_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -222,6 +222,91 @@ def test_nautilus_bound_contains_and_sample(dev, nautilus_d4):
     log_v = (np.logaddexp.reduce(ob.outer_bound.log_v_all) +
              np.log(c[1] / n))
     assert abs(log_v - float(g['log_v'])) < 0.1
+
+
+def test_phase_shift_bit_exact(dev):
+    """bounds/periodic.py on the device: centres, forward and inverse
+    transform are bit-identical to the reference's (golden fixture)."""
+    from nautilus_amd.bounds import PhaseShift
+    g = load_golden('phaseshift')
+    for pts, centers, fwd, back in zip(g['points'], g['centers'],
+                                       g['forward'], g['inverse']):
+        shift = PhaseShift.compute(pts, g['periodic'])
+        assert np.array_equal(shift.centers, centers)
+        import torch
+        shift_t = PhaseShift.compute(torch.from_numpy(pts).cuda(),
+                                     g['periodic'])
+        assert np.array_equal(shift_t.centers, centers)
+        out = shift.transform(pts)
+        assert np.array_equal(out, fwd)
+        assert np.array_equal(shift.transform(out, inverse=True), back)
+    # wrap-around edge values: exactly on the boundary, tiny negative sums
+    shift = PhaseShift.from_params([0, 1], [0.5, 0.25])
+    x = np.array([[0.0, 0.75], [1.0 - 2**-53, 0.75 - 1e-20], [0.5, 0.0],
+                  [0.25, 1.0 - 2**-53]])
+    from oracle import bounds_oracle as bo
+    o = bo.OPhaseShift.from_params([0, 1], [0.5, 0.25])
+    assert np.array_equal(shift.transform(x), o.transform(x))
+    assert np.array_equal(shift.transform(x, inverse=True),
+                          o.transform(x, inverse=True))
+
+
+def test_periodic_nautilus_bound(dev):
+    """NautilusBound with a PhaseShift (nautilus.py:91-96, 162-163, 241-243):
+    contains() recentres, sample() returns points in the sampler's frame."""
+    from nautilus_amd import bounds as nb
+    from oracle import philox
+    g = load_golden('nautilusbound_periodic_D3')
+    ob = nautilus_from_golden(g)
+    assert ob.shift is not None
+    assert np.array_equal(ob.contains(g['test']), g['contains'])
+    b = upload(ob)
+    # points hugging the periodic seam as well
+    rng = np.random.default_rng(8)
+    seam = rng.random((4096, 3))
+    seam[:, 0] = (rng.normal(size=4096) * 0.02) % 1
+    x = np.vstack([g['test'], seam, g['sample']])
+    want = ob.contains(x)
+    got = b.contains(x).cpu().numpy()
+    assert (got != want).sum() <= 1
+    assert got[-len(g['sample']):].all()
+    # in a list (shell exclusion) every bound applies its own shift
+    ob_plain = nautilus_from_golden(load_golden('nautilusbound_D4'))
+    del ob_plain
+    lst = dev.DeviceBoundList([b])
+    assert np.array_equal(lst.contains_any(x).cpu().numpy(), got)
+    assert np.array_equal(lst.first_containing(x).cpu().numpy() == 0, got)
+
+    # sampling: same proposals as the oracle's Philox pipeline, shifted back
+    seed, offset, n = 9, 7 * 10**9, 20000
+    pts_o, cnt_o = philox.nautilus_sample(ob, seed, offset, n)
+    pts_o = ob.shift.transform(pts_o, inverse=True)
+    outer = nb.Union.from_members(
+        [nb.UnitCubeEllipsoidMixture.from_params(
+            m.dim_cube, None if m.ellipsoid is None else
+            nb.Ellipsoid.from_params(m.ellipsoid.c, m.ellipsoid.B,
+                                     m.ellipsoid.B_inv, m.ellipsoid.A))
+         for m in ob.outer_bound.bounds], unit=True)
+    outer.log_v_all = ob.outer_bound.log_v_all
+    neural = []
+    for o in ob.neural_bounds:
+        from nautilus_amd.emulator import NeuralNetworkEmulator, Network
+        emu = NeuralNetworkEmulator.from_weights(
+            o.emulator.mean, o.emulator.scale,
+            [Network(n_.coefs, n_.intercepts) for n_ in o.emulator.networks])
+        neural.append(nb.NeuralBound.from_parts(
+            nb.Ellipsoid.from_params(o.outer_bound.c, o.outer_bound.B,
+                                     o.outer_bound.B_inv, o.outer_bound.A),
+            emu, o.score_predict_min))
+    full = nb.NautilusBound.from_parts(
+        outer, neural, rng=np.random.default_rng(1),
+        shift=nb.PhaseShift.from_params(g['periodic'], g['centers']))
+    full._stream.seed, full._stream.offset = seed, offset
+    drawn = full.sample(len(pts_o) // 2)
+    assert np.allclose(drawn, pts_o[:len(drawn)], rtol=0, atol=1e-12)
+    assert np.all((drawn >= 0) & (drawn < 1))
+    assert ob.contains(drawn).mean() > 0.999
+    assert abs(full.log_v - float(g['log_v'])) < 0.1
 
 
 def test_shell_exclusion_and_association(dev, nautilus_d4, neural_d4):

@@ -198,3 +198,59 @@ def test_full_run_reproduces_reference(row):
     assert s.shell_n_sample.tolist() == ref['shell_n_sample']
     assert np.isclose(s.log_z, ref['log_z'], rtol=0, atol=1e-9)
     assert np.isclose(s.n_eff, ref['n_eff'], rtol=1e-9)
+
+
+def test_phase_shift_matches_reference():
+    """bounds/periodic.py; also the reference's own assertions
+    (tests/test_bounds.py:314-327) on the round trip."""
+    g = load_golden('phaseshift')
+    for pts, centers, fwd, back in zip(g['points'], g['centers'],
+                                       g['forward'], g['inverse']):
+        shift = bo.OPhaseShift.build(pts, g['periodic'])
+        assert np.array_equal(shift.centers, centers)
+        assert np.array_equal(shift.transform(pts), fwd)
+        assert np.array_equal(shift.transform(fwd, inverse=True), back)
+        assert np.amin(fwd[:, g['periodic']]) >= 0.45
+        assert np.amax(fwd[:, g['periodic']]) <= 0.55
+        assert np.allclose(back, pts, rtol=0, atol=1e-12)
+
+
+def test_periodic_nautilus_bound_matches_reference():
+    g = load_golden('nautilusbound_periodic_D3')
+    b = bo.ONautilus.build(g['points'], g['log_l'], float(g['log_l_min']),
+                           float(g['log_v_target']), n_networks=1,
+                           periodic=g['periodic'],
+                           rng=np.random.default_rng(0))
+    assert np.array_equal(b.shift.centers, g['centers'])
+    assert len(b.neural_bounds) == int(g['n_neural'])
+    assert len(b.outer_bound.bounds) == int(g['n_outer'])
+    b.reset(np.random.default_rng(3))
+    assert np.array_equal(b.sample(2000), g['sample'])
+    assert (b.n_sample, b.n_reject) == (g['n_sample'], g['n_reject'])
+    assert b.log_v == g['log_v']
+    assert np.array_equal(b.contains(g['test']), g['contains'])
+
+
+def _wrapped(x):
+    return -0.5 * np.sum((np.abs(x - 0.5) - 0.5)**2, axis=-1) / 0.1
+
+
+@pytest.mark.parametrize('row', [0, 1, 2])
+def test_periodic_run_reproduces_reference(row):
+    """reference tests/test_sampler.py:395-416: with periodic parameters the
+    mode wrapped around the corners is not split."""
+    with open(os.path.join(GOLDEN, 'e2e_periodic.json')) as f:
+        ref = json.load(f)['runs'][row]
+    s = so.OSampler(lambda x: x, _wrapped, n_dim=2, n_live=ref['n_live'],
+                    n_networks=ref['n_networks'], vectorized=True,
+                    seed=ref['seed'],
+                    periodic=np.arange(2) if ref['periodic'] else None)
+    s.run(n_eff=ref['n_eff_target'], discard_exploration=True)
+    assert s.n_like == ref['n_like']
+    assert len(s.bounds) == ref['n_bounds']
+    assert [len(b.neural_bounds) for b in s.bounds[1:]] == \
+        ref['n_neural_per_bound']
+    assert s.shell_n.tolist() == ref['shell_n']
+    assert np.isclose(s.log_z, ref['log_z'], rtol=0, atol=1e-9)
+    for b in s.bounds[1:]:
+        assert len(b.neural_bounds) == (1 if ref['periodic'] else 4)

@@ -313,3 +313,39 @@ def test_ragged_and_empty_inputs(n):
     rows, counts, _ = device.compact_rows(xt, flags, 1)
     assert int(counts[1]) == want.sum()
     assert np.array_equal(rows[:int(counts[1])].cpu().numpy(), x[want])
+
+
+def _wrapped(x):
+    return -0.5 * np.sum((np.abs(x - 0.5) - 0.5)**2, axis=-1) / 0.1
+
+
+@pytest.mark.parametrize('periodic', [False, True])
+def test_sampler_periodic(periodic):
+    """reference tests/test_sampler.py:395-416: a mode wrapped around the
+    corners of the unit square is one neural bound with periodic parameters
+    and four without; the evidence agrees with the reference's runs of the
+    same problem (tests/golden/e2e_periodic.json)."""
+    from nautilus_amd import Sampler
+    with open(os.path.join(GOLDEN, 'e2e_periodic.json')) as f:
+        runs = json.load(f)['runs']
+    s = Sampler(lambda u: u, _wrapped, n_dim=2, n_live=400,
+                periodic=np.arange(2) if periodic else None, n_networks=1,
+                vectorized=True, seed=0)
+    s.run(n_eff=4000, discard_exploration=True)
+    for bound in s.bounds[1:]:
+        assert len(bound.neural_bounds) == (1 if periodic else 4)
+        assert (bound.shift is not None) == periodic
+    # analytic: four quarter Gaussians of variance 0.1 per axis
+    from scipy.stats import norm
+    analytic = 2 * np.log(np.sqrt(2 * np.pi * 0.1) *
+                          (2 * norm.cdf(0.5 / np.sqrt(0.1)) - 1))
+    assert abs(s.log_z - analytic) < 0.05
+    ref = [r['log_z'] for r in runs]
+    assert min(ref) - 0.1 < s.log_z < max(ref) + 0.1
+    pts, log_w, log_l = s.posterior()
+    assert np.all((pts >= 0) & (pts < 1))
+    w = np.exp(log_w)
+    # symmetric problem: each corner quadrant carries a quarter of the mass
+    for qx in (pts[:, 0] < 0.5, pts[:, 0] >= 0.5):
+        for qy in (pts[:, 1] < 0.5, pts[:, 1] >= 0.5):
+            assert abs(np.sum(w[qx & qy]) - 0.25) < 0.04
