@@ -208,7 +208,7 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   const int64_t ell_size = nb_ell_block_size(dt);
   const int64_t net_stride = (int64_t)nb_net_tiles(kt1) * NB_TILE;
   const int64_t neural_stride = ell_size + 2 + 2 * dp + (int64_t)E * net_stride;
-  const int64_t draw_stride = 2 + 4 * dp + (int64_t)dp * (dp + 1) / 2;
+  const int64_t draw_stride = 2 + 4 * dp + (int64_t)dp * (dp + 1) / 2 + 16;
 
   int64_t off = NB_HDR;
   const int64_t off_cdf = off; off += ((K > 0 ? K : 1) + 1) / 2 * 2;

@@ -4,27 +4,63 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// Proposal draw: one thread per proposal, one wavefront per workgroup.
+// Proposal draw: 64 proposals per workgroup of four wavefronts; lane = proposal
+// in every wavefront, the wavefronts split the work of a proposal:
 //   union.py:308-312  member ~ softmax(log_v_all)  (inverse CDF per proposal,
 //                     same distribution as multinomial + shuffle)
 //   basic.py:376-381  z ~ N(0,I); z /= |z|; z *= u^(1/D); x = B z + c
 //   basic.py:85, 633-640  cube columns ~ U[0,1)
-// z lives in LDS in column layout z[slot][lane]; x = B z + c is formed in place
-// (last row first) and the 64 x D block of the wavefront is then written with
-// fully coalesced stores.
+// Wavefront w draws the Box-Muller pairs j = w, w+4, ... (the Philox rounds
+// and the fp64 log / sincos are the bulk of the kernel), then rows r = w,
+// w+4, ... of the triangular product.  The row index is wave uniform, so for a
+// single-member bound the B operands arrive through scalar loads.  z lives in
+// LDS as z[slot][proposal]; x = B z + c overwrites it four rows at a time from
+// the last row up (row r only needs z_0..z_r), and the 64 x D block is then
+// written with fully coalesced stores.  Splitting a proposal over wavefronts
+// instead of giving each wavefront its own 64 proposals keeps the LDS
+// footprint per wavefront at a quarter: 24 wavefronts per CU instead of 6
+// hide the latency of the dependent fp64 chains.
 // ---------------------------------------------------------------------------
 constexpr int ZS = 65;     // LDS row stride (odd: transposed reads conflict-free)
+constexpr int DW = 4;      // wavefronts per workgroup
+constexpr int RB = 8;      // terms of a row product per trip
 
-__global__ void __launch_bounds__(64)
+// sum_{j <= r} B[r][j] z_j for the proposal of this lane, in the fixed order
+// j = 0..r, RB terms per trip; the last trip is padded with zero weights
+// (reads stay inside the row-packed B, which the host pads by RB doubles, and
+// inside the z slots 0..r).  With a wave-uniform B the operands are scalar
+// loads.
+__device__ __forceinline__ double draw_row(const double* __restrict__ B,
+                                           const double* zs, int r, int lane) {
+  const double* brow = B + (long long)r * (r + 1) / 2;
+  double acc = 0.0;
+  for (int j = 0; j <= r; j += RB) {
+    double bv[RB], zv[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int jj = j + u;
+      const double b = brow[jj];           // unconditional: B is padded
+      bv[u] = (jj <= r) ? b : 0.0;
+      zv[u] = zs[(jj <= r ? jj : r) * ZS + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) acc += bv[u] * zv[u];
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(64 * DW)
 nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
                unsigned long long offset, long long n,
                double* __restrict__ x_out) {
   extern __shared__ __attribute__((aligned(16))) double zs[];   // [slot][ZS]
   __shared__ int member_of[64];
-  const int lane = threadIdx.x;
+  __shared__ double norm_part[DW][64];
+  __shared__ double radius_of[64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long i0 = (long long)blockIdx.x * 64;
   const long long i = i0 + lane;
-  const bool on = i < n;
   const unsigned long long g = offset + (unsigned long long)i;
 
   const int n_dim = (int)nb_hdr(blob, NB_H_NDIM);
@@ -34,16 +70,15 @@ nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
   const double* draw = blob + nb_hdr(blob, NB_H_OFF_DRAW);
   const long long draw_stride = nb_hdr(blob, NB_H_DRAW_STRIDE);
 
-  double u_member, u_accept, u_radius, u_spare;
-  nb_uniform_pair(seed, g, 0u, NB_TAG_CTRL, u_member, u_accept);
-  nb_uniform_pair(seed, g, 1u, NB_TAG_CTRL, u_radius, u_spare);
-
+  // every wavefront needs the member of its proposals
   int m = 0;
   if (K > 1) {
+    double u_member, u_accept;
+    nb_uniform_pair(seed, g, 0u, NB_TAG_CTRL, u_member, u_accept);
     for (int j = 0; j < K; ++j) m += (cdf[j] <= u_member) ? 1 : 0;
     if (m > K - 1) m = K - 1;
   }
-  member_of[lane] = m;
+  if (wave == 0) member_of[lane] = m;
 
   // K == 1: the member block is wave uniform (scalar loads feed the FMAs)
   const double* blk = (K == 1) ? draw : draw + m * draw_stride;
@@ -53,68 +88,84 @@ nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
   const double* c = blk + 2 + 3 * dp;
   const double* B = c + dp;
 
-  if (on) {
-    // ellipsoid part: slots 0..ne-1 (basic.py:376-381)
-    if (ne > 0) {
-      double norm2 = 0.0;
-      for (int j = 0; 2 * j < ne; ++j) {
-        double u0, u1;
-        nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_NORMAL, u0, u1);
-        const double r = sqrt(-2.0 * log(1.0 - u0));
-        double sn, cs;
-        sincos(2.0 * M_PI * u1, &sn, &cs);
-        const double z0 = r * cs, z1 = r * sn;
-        zs[(2 * j) * ZS + lane] = z0;
-        norm2 += z0 * z0;
-        if (2 * j + 1 < ne) {
-          zs[(2 * j + 1) * ZS + lane] = z1;
-          norm2 += z1 * z1;
-        }
-      }
-      const double nrm = sqrt(norm2);
-      const double rad = pow(u_radius, 1.0 / (double)ne);
-      for (int j = 0; j < ne; ++j)
-        zs[j * ZS + lane] = (zs[j * ZS + lane] / nrm) * rad;
-      // x = B z + c in place, last row first (row r only needs z_0..z_r)
-      for (int r = ne - 1; r >= 0; --r) {
-        const double* brow = B + (long long)r * (r + 1) / 2;
-        // fixed summation order j = 0..r (the oracle's), 8 independent
-        // operand loads in flight per trip
-        double acc = 0.0;
-        int j = 0;
-        for (; j + 8 <= r + 1; j += 8) {
-          double bv[8], zv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            bv[u] = brow[j + u];
-            zv[u] = zs[(j + u) * ZS + lane];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc += bv[u] * zv[u];
-        }
-        for (; j <= r; ++j) acc += brow[j] * zs[j * ZS + lane];
-        zs[r * ZS + lane] = acc + c[r];
-      }
+  if (wave == DW - 1) {
+    // radius: the last wavefront has the fewest Box-Muller pairs
+    double u_radius, u_spare;
+    nb_uniform_pair(seed, g, 1u, NB_TAG_CTRL, u_radius, u_spare);
+    radius_of[lane] = (ne > 0) ? pow(u_radius, 1.0 / (double)ne) : 0.0;
+  }
+
+  // normals: slots 0..ne-1 (basic.py:376-381)
+  double part = 0.0;
+  for (int j = wave; 2 * j < ne; j += DW) {
+    double u0, u1;
+    nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_NORMAL, u0, u1);
+    const double r = sqrt(-2.0 * log(1.0 - u0));
+    double sn, cs;
+    sincospi(2.0 * u1, &sn, &cs);      // angle 2 pi u1, exact range reduction
+    const double z0 = r * cs, z1 = r * sn;
+    zs[(2 * j) * ZS + lane] = z0;
+    part += z0 * z0;
+    if (2 * j + 1 < ne) {
+      zs[(2 * j + 1) * ZS + lane] = z1;
+      part += z1 * z1;
     }
-    // cube part: slots ne..ne+nc-1 (basic.py:85, 633-640)
-    for (int j = 0; 2 * j < nc; ++j) {
-      double u0, u1;
-      nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_CUBE, u0, u1);
-      zs[(ne + 2 * j) * ZS + lane] = u0;
-      if (2 * j + 1 < nc) zs[(ne + 2 * j + 1) * ZS + lane] = u1;
-    }
+  }
+  norm_part[wave][lane] = part;
+  // cube part: slots ne..ne+nc-1 (basic.py:85, 633-640)
+  for (int j = wave; 2 * j < nc; j += DW) {
+    double u0, u1;
+    nb_uniform_pair(seed, g, (unsigned)j, NB_TAG_CUBE, u0, u1);
+    zs[(ne + 2 * j) * ZS + lane] = u0;
+    if (2 * j + 1 < nc) zs[(ne + 2 * j + 1) * ZS + lane] = u1;
   }
   __syncthreads();
 
-  // coalesced store of the wavefront's contiguous 64 x D block; every row
+  // |z| -> u^(1/D): every wavefront rescales the slots it wrote
+  double norm2 = norm_part[0][lane];
+#pragma unroll
+  for (int w = 1; w < DW; ++w) norm2 += norm_part[w][lane];
+  const double scale = radius_of[lane] / sqrt(norm2);
+  for (int j = wave; 2 * j < ne; j += DW) {
+    zs[(2 * j) * ZS + lane] *= scale;
+    if (2 * j + 1 < ne) zs[(2 * j + 1) * ZS + lane] *= scale;
+  }
+  __syncthreads();
+
+  // x = B z + c in place, four rows per step from the last row up; the rows
+  // of a step are read completely before any of them is overwritten
+  int ne_max = ne;
+  if (K > 1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int other = __shfl_xor(ne_max, o);
+      ne_max = other > ne_max ? other : ne_max;
+    }
+  }
+  ne_max = __builtin_amdgcn_readfirstlane(ne_max);
+  for (int r0 = ((ne_max + DW - 1) / DW - 1) * DW; r0 >= 0; r0 -= DW) {
+    const int r = r0 + wave;
+    double acc = 0.0;
+    if (r < ne) {
+      acc = (K == 1) ? draw_row(draw + 2 + 4 * dp, zs, r, lane)
+                     : draw_row(B, zs, r, lane);
+      acc += c[r];
+    }
+    __syncthreads();
+    if (r < ne) zs[r * ZS + lane] = acc;
+  }
+  __syncthreads();
+
+  // coalesced store of the workgroup's contiguous 64 x D block; every row
   // maps its columns to slots through its member's table
   long long rows = n - i0;
   if (rows > 64) rows = 64;
   const int total = (int)rows * n_dim;
-  int row = lane / n_dim, col = lane - row * n_dim;
-  const int drow = 64 / n_dim, dcol = 64 - drow * n_dim;
+  const int nt = 64 * DW;
+  int row = (int)threadIdx.x / n_dim, col = (int)threadIdx.x - row * n_dim;
+  const int drow = nt / n_dim, dcol = nt - drow * n_dim;
   double* dst = x_out + i0 * n_dim;
-  for (int e = lane; e < total; e += 64) {
+  for (int e = threadIdx.x; e < total; e += nt) {
     const long long* sl = (const long long*)(draw + member_of[row] *
                                              draw_stride) + 2 + 2 * dp;
     dst[e] = zs[(int)sl[col] * ZS + row];
@@ -327,7 +378,7 @@ int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
   if (n <= 0) return NB_OK;
   const long long blocks = (n + 63) / 64;
   const size_t lds = (size_t)n_dim * 65 * sizeof(double);
-  hipLaunchKernelGGL(nb_draw_kernel, dim3((unsigned)blocks), dim3(64), lds,
+  hipLaunchKernelGGL(nb_draw_kernel, dim3((unsigned)blocks), dim3(64 * DW), lds,
                      stream, blob_dev, seed, offset, n, x_out);
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;
