@@ -71,13 +71,14 @@ __device__ inline bool point_any(bool flag, int lane) {
   return ((b >> (lane & 15)) & 0x0001000100010001ull) != 0ull;
 }
 
-constexpr int TPW = 2;   // 16-point tiles per wavefront
+// TPW = 16-point tiles per wavefront (template parameter): 2 shares every A
+// operand between two tiles; 1 halves the register footprint (n_dim > 64).
 
 // y = B_inv (x - c) on the matrix cores plus the per-dimension box test, for
 // the TPW tiles of a wavefront (the A operand is shared).  r2 = |y|^2
 // (replicated over the 4 lanes of a point); box_bad is set if any coordinate
 // violates the member's [lo, hi) limits.
-template <int DT>
+template <int DT, int TPW>
 __device__ __forceinline__ void ell_eval(const double* blk,
                                          int n_dim,
                                          const double (&xin)[TPW][4 * DT],
@@ -170,7 +171,8 @@ template <int KSMAX, int HT, bool RELU>
 __device__ __forceinline__ void mlp_layer(const double* w, int ks_n,
                                           const double* in0, const double* in1,
                                           int lane, double* out0,
-                                          double* out1) {
+                                          double* out1, double& rem0,
+                                          double& rem1) {
 #pragma unroll
   for (int ht = 0; ht < HT - 1; ++ht) {
     nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
@@ -205,20 +207,15 @@ __device__ __forceinline__ void mlp_layer(const double* w, int ks_n,
       r1 = MFMA4(a, in1[ks], r1);
     }
   }
-  out0[4 * (HT - 1)] = RELU ? fmax(r0, 0.0) : r0;
-  out1[4 * (HT - 1)] = RELU ? fmax(r1, 0.0) : r1;
-#pragma unroll
-  for (int r = 1; r < 4; ++r) {
-    out0[4 * (HT - 1) + r] = 0.0;
-    out1[4 * (HT - 1) + r] = 0.0;
-  }
+  rem0 = RELU ? fmax(r0, 0.0) : r0;
+  rem1 = RELU ? fmax(r1, 0.0) : r1;
 }
 
 // same for a single tile (the gather left this wavefront only one)
 template <int KSMAX, int HT, bool RELU>
 __device__ __forceinline__ void mlp_layer1(const double* w, int ks_n,
                                            const double* in0, int lane,
-                                           double* out0) {
+                                           double* out0, double& rem0) {
 #pragma unroll
   for (int ht = 0; ht < HT - 1; ++ht) {
     nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
@@ -249,9 +246,46 @@ __device__ __forceinline__ void mlp_layer1(const double* w, int ks_n,
     }
   }
   const double v = r0 + r1;
-  out0[4 * (HT - 1)] = RELU ? fmax(v, 0.0) : v;
+  rem0 = RELU ? fmax(v, 0.0) : v;
+}
+
+// the TPW tiles of a wavefront through one layer (+ the constant-1 unit that
+// feeds the next layer's bias row: k-step ONE_KS, lane group ONE_LG)
+template <int TPW, int KSMAX, int HT, bool RELU, int ONE_KS, int ONE_LG,
+          int NIN, int NOUT>
+__device__ __forceinline__ void mlp_tiles(const double* w, int ks_n,
+                                          const double (&in)[TPW][NIN],
+                                          int lane, double (&out)[TPW][NOUT],
+                                          bool two_tiles) {
+  double rem[2] = {0.0, 0.0};     // units of the partial last tile
+  if constexpr (TPW == 2) {
+    if (two_tiles)
+      mlp_layer<KSMAX, HT, RELU>(w, ks_n, in[0], in[1], lane, out[0], out[1],
+                                 rem[0], rem[1]);
+    else
+      mlp_layer1<KSMAX, HT, RELU>(w, ks_n, in[0], lane, out[0], rem[0]);
+  } else {
+    mlp_layer1<KSMAX, HT, RELU>(w, ks_n, in[0], lane, out[0], rem[0]);
+  }
 #pragma unroll
-  for (int r = 1; r < 4; ++r) out0[4 * (HT - 1) + r] = 0.0;
+  for (int t = 0; t < TPW; ++t) out[t][4 * (HT - 1)] = rem[t];
+  // registers 1..3 of the last tile: zero padding, except the constant 1
+  // (written outside the branch above: branch-dependent element stores would
+  // turn the activation arrays into scratch memory)
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const int idx = 4 * (HT - 1) + r;
+      out[t][idx] = (idx == ONE_KS && (lane >> 4) == ONE_LG) ? 1.0 : 0.0;
+    }
+  if constexpr (ONE_KS >= 0 && ONE_KS == 4 * (HT - 1)) {
+    // the constant shares the k-step of the partial tile (50 = 48 + 2)
+    if ((lane >> 4) == ONE_LG) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) out[t][ONE_KS] = 1.0;
+    }
+  }
 }
 
 // asynchronous global -> LDS copy (global_load_lds_dwordx4): every wavefront
@@ -284,7 +318,7 @@ __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
 // slots (2j, 2j+1) with one 16-byte load and a point is covered by 64
 // contiguous bytes per instruction.  The per-dimension vectors (lo, hi, c) and
 // the K index of the ellipsoid tiles are stored in slot order by the host.
-template <int DT>
+template <int DT, int TPW>
 __device__ __forceinline__ void load_points(const double* __restrict__ x,
                                             const long long (&pt)[TPW],
                                             const bool (&valid)[TPW],
@@ -345,8 +379,8 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
 // into dense 16-point tiles through LDS before the MLP (shell exclusion and
 // association only need it for a minority of the points; without the
 // gather a wavefront evaluates all 32 of its points if one needs it).
-template <int DT, int VARIANT>   // 0 gather, 1 dense + DMA double buffer, 2 dense
-__global__ void __launch_bounds__(256)
+template <int DT, int VARIANT, int TPW>   // VARIANT 0 gather, 1 dense + DMA
+__global__ void __launch_bounds__(256)   // double buffer, 2 dense
 nb_eval_kernel(EvalArgs a, int w_doubles) {
   constexpr bool COMPACT = (VARIANT == 0);
   constexpr bool DBUF = (VARIANT == 1);
@@ -407,7 +441,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       int k_cnt[TPW];
       {
         double xin[TPW][4 * DT];
-        load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
+        load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
 
         // Bounding-sphere pre-test (shell exclusion / association): a point
         // of a bound with neural bounds lies inside one of their ellipsoids,
@@ -473,7 +507,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           __syncthreads();
           stage_weights(mblk + m * ell_stride, wlds, nb_ell_block_size(DT));
           __syncthreads();
-          ell_eval<DT>(wlds, n_dim, xin, lane, y, box_bad, r2);
+          ell_eval<DT, TPW>(wlds, n_dim, xin, lane, y, box_bad, r2);
 #pragma unroll
           for (int t = 0; t < TPW; ++t)
             k_cnt[t] += (!box_bad[t] && r2[t] < 1.0) ? 1 : 0;
@@ -520,11 +554,11 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           bool box_bad[TPW], inside_e[TPW], need[TPW];
           {
             double xin[TPW][4 * DT];
-            load_points<DT>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
+            load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
             __syncthreads();
             stage_weights(nb_m, wlds, nb_ell_block_size(DT));
             __syncthreads();
-            ell_eval<DT>(wlds, n_dim, xin, lane, y, box_bad, r2);
+            ell_eval<DT, TPW>(wlds, n_dim, xin, lane, y, box_bad, r2);
           }
           bool wave_need = false;
 #pragma unroll
@@ -634,11 +668,9 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                 const double* w1 = nets + e * net_stride;
                 double h1[TPW][4 * NB_HT1];
                 dma_weights(w1 + n_a, reg_b, n_b, wave, lane);
-                if (wave_mlp) {
-                  mlp_layer<KS1MAX, NB_HT1, true>(reg_a, ks1, tin[0], tin[1],
-                                                  lane, h1[0], h1[1]);
-                  if (lg == 0) { h1[0][25] = 1.0; h1[1][25] = 1.0; }
-                }
+                if (wave_mlp)
+                  mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
+                      reg_a, ks1, tin, lane, h1, true);          // unit 100
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (e + 1 < E)
@@ -648,63 +680,47 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                   const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
                   const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
                   double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
-                  mlp_layer<26, NB_HT2, true>(w2, 26, h1[0], h1[1], lane,
-                                              h2[0], h2[1]);
-                  if (lg == 2) { h2[0][12] = 1.0; h2[1][12] = 1.0; }
-                  mlp_layer<13, NB_HT3, true>(w3, 13, h2[0], h2[1], lane,
-                                              h3[0], h3[1]);
-                  if (lg == 0) { h3[0][5] = 1.0; h3[1][5] = 1.0; }
-                  mlp_layer<6, 1, false>(w4, 6, h3[0], h3[1], lane, o[0],
-                                         o[1]);
-                  total[0] += o[0][0];
-                  total[1] += o[1][0];
+                  mlp_tiles<TPW, 26, NB_HT2, true, 12, 2>(w2, 26, h1, lane, h2,
+                                                          true);   // unit 50
+                  mlp_tiles<TPW, 13, NB_HT3, true, 5, 0>(w3, 13, h2, lane, h3,
+                                                         true);    // unit 20
+                  mlp_tiles<TPW, 6, 1, false, -1, 0>(w4, 6, h3, lane, o, true);
+#pragma unroll
+                  for (int t = 0; t < TPW; ++t) total[t] += o[t][0];
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
               }
             } else {
-            for (int e = 0; e < E; ++e) {              const double* w1 = nets + e * net_stride;
-              double h1[TPW][4 * NB_HT1];
-              __syncthreads();                       // LDS free
-              stage_weights(w1, wlds, n_a);
-              __syncthreads();
-              if (wave_mlp) {
-                if (two_tiles)
-                  mlp_layer<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], tin[1],
-                                                  lane, h1[0], h1[1]);
-                else
-                  mlp_layer1<KS1MAX, NB_HT1, true>(wlds, ks1, tin[0], lane,
-                                                   h1[0]);
-                if (lg == 0) { h1[0][25] = 1.0; h1[1][25] = 1.0; }  // unit 100
-              }
-              __syncthreads();
-              stage_weights(w1 + n_a, wlds, n_b);
-              __syncthreads();
-              if (wave_mlp) {
-                const double* w2 = wlds;
-                const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
-                const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
-                double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
-                if (two_tiles) {
-                  mlp_layer<26, NB_HT2, true>(w2, 26, h1[0], h1[1], lane,
-                                              h2[0], h2[1]);
-                  if (lg == 2) { h2[0][12] = 1.0; h2[1][12] = 1.0; }  // 50
-                  mlp_layer<13, NB_HT3, true>(w3, 13, h2[0], h2[1], lane,
-                                              h3[0], h3[1]);
-                  if (lg == 0) { h3[0][5] = 1.0; h3[1][5] = 1.0; }    // 20
-                  mlp_layer<6, 1, false>(w4, 6, h3[0], h3[1], lane, o[0],
-                                         o[1]);
-                  total[1] += o[1][0];
-                } else {
-                  mlp_layer1<26, NB_HT2, true>(w2, 26, h1[0], lane, h2[0]);
-                  if (lg == 2) h2[0][12] = 1.0;
-                  mlp_layer1<13, NB_HT3, true>(w3, 13, h2[0], lane, h3[0]);
-                  if (lg == 0) h3[0][5] = 1.0;
-                  mlp_layer1<6, 1, false>(w4, 6, h3[0], lane, o[0]);
+              for (int e = 0; e < E; ++e) {
+                const double* w1 = nets + e * net_stride;
+                double h1[TPW][4 * NB_HT1];
+                __syncthreads();                       // LDS free
+                stage_weights(w1, wlds, n_a);
+                __syncthreads();
+                if (wave_mlp)
+                  mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
+                      wlds, ks1, tin, lane, h1, two_tiles);
+                __syncthreads();
+                stage_weights(w1 + n_a, wlds, n_b);
+                __syncthreads();
+                if (wave_mlp) {
+                  const double* w2 = wlds;
+                  const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
+                  const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
+                  double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
+                  mlp_tiles<TPW, 26, NB_HT2, true, 12, 2>(w2, 26, h1, lane, h2,
+                                                          two_tiles);
+                  mlp_tiles<TPW, 13, NB_HT3, true, 5, 0>(w3, 13, h2, lane, h3,
+                                                         two_tiles);
+                  mlp_tiles<TPW, 6, 1, false, -1, 0>(w4, 6, h3, lane, o,
+                                                     two_tiles);
+                  total[0] += o[0][0];             // unit 0 lives in lg == 0
+                  if constexpr (TPW == 2) {
+                    if (two_tiles) total[1] += o[1][0];
+                  }
                 }
-                total[0] += o[0][0];               // unit 0 lives in lg == 0
               }
-            }
             }
             if (COMPACT) {
               // scatter the scores back to the owners of the points
@@ -775,7 +791,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   }
 }
 
-template <int DT, int VARIANT>
+template <int DT, int VARIANT, int TPW>
 int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   constexpr bool COMPACT = (VARIANT == 0);
   constexpr int TS = 4 * (4 * DT + 1) + 1;
@@ -789,7 +805,7 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_kernel<DT, VARIANT>,
+        (const void*)nb_eval_kernel<DT, VARIANT, TPW>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -805,7 +821,7 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   long long blocks = n_super;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT>), dim3((unsigned)blocks),
+  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT, TPW>), dim3((unsigned)blocks),
                      dim3(256), lds, stream, a, w_doubles);
   return NB_OK;
 }
@@ -819,11 +835,15 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   const size_t need = ((size_t)lds_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
   const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC) &&
                            getenv("NB_EVAL_NO_GATHER") == nullptr;
+  // two tiles per wavefront up to n_dim = 64; beyond that the per-lane state
+  // (y, standardised input, hidden activations of two tiles) no longer fits
+  // the register file
+  constexpr int TPW = (DT <= 4) ? 2 : 1;
   if (sparse_mode && need <= 160 * 1024)
-    return launch_eval_impl<DT, 0>(a, lds_tiles, stream);
+    return launch_eval_impl<DT, 0, TPW>(a, lds_tiles, stream);
   if (((size_t)lds_tiles + 38) * NB_TILE * 8 <= 160 * 1024)
-    return launch_eval_impl<DT, 1>(a, lds_tiles, stream);
-  return launch_eval_impl<DT, 2>(a, lds_tiles, stream);
+    return launch_eval_impl<DT, 1, TPW>(a, lds_tiles, stream);
+  return launch_eval_impl<DT, 2, TPW>(a, lds_tiles, stream);
 }
 
 }  // namespace
