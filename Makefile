@@ -11,7 +11,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value
 
 all: $(LIB)
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h include/nautilus_hip.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h $(CSRC)/nb_tile.h include/nautilus_hip.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

@@ -216,6 +216,18 @@ int nb_set_eval_counters(uint64_t* counters_dev);
  * returns achieved TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64.          */
 int nb_mfma_f64_peak(int32_t iters, double* tflops_host);
 
+/* The iteration of minimum_volume_enclosing_ellipsoid (bounds/basic.py:
+ * 175-232; called by Ellipsoid.compute :295 and, through it, by
+ * UnitCubeEllipsoidMixture.compute and Union.compute/split): n_max sweeps of
+ * up to n_batch Khachiyan updates over the n points x_dev (n > n_dim).
+ * u_dev[n] receives the weights u of basic.py:231; centre, covariance and
+ * scaling (basic.py:233-241) follow from u on the host.  scratch_dev: n
+ * doubles.  n_dim <= 63 (NB_ERR_UNSUPPORTED above: the caller keeps its host
+ * construction); the reference's defaults are n_max = 100, n_batch = 20.     */
+int nb_mvee_weights(const double* x_dev, int64_t n, int32_t n_dim,
+                    int32_t n_max, int32_t n_batch, double* u_dev,
+                    double* scratch_dev, void* stream);
+
 /* PhaseShift.transform (bounds/periodic.py:50-72), in place on device rows:
  * x[:, periodic[i]] = (x[:, periodic[i]] -/+ (0.5 - centers[i])) mod 1
  * (inverse != 0 undoes the shift, nautilus.py:241-243).  `periodic` and

@@ -95,6 +95,9 @@ _SIGNATURES = {
                                     C.c_void_p]),
     'nb_set_eval_counters': (C.c_int, [C.c_void_p]),
     'nb_mfma_f64_peak': (C.c_int, [C.c_int32, c_double_p]),
+    'nb_mvee_weights': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     'nb_phase_shift': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                  c_int32_p, c_double_p, C.c_int32,
                                  C.c_void_p]),

@@ -33,6 +33,8 @@ int nb_launch_philox(unsigned long long seed, unsigned long long offset,
                      unsigned block, unsigned tag, long long n, double* u,
                      hipStream_t stream);
 int nb_run_mfma_peak(int iters, double* tflops);
+int nb_launch_mvee(const double* x, long long n, int n_dim, int n_max,
+                   int n_batch, double* u, double* g, hipStream_t stream);
 int nb_launch_phase_shift(double* x, long long n, int n_dim, const double* s,
                           const unsigned char* on, int inverse,
                           hipStream_t stream);
@@ -553,6 +555,16 @@ int nb_set_eval_counters(uint64_t* counters_dev) {
 
 int nb_mfma_f64_peak(int32_t iters, double* tflops) {
   return nb_run_mfma_peak(iters, tflops);
+}
+
+int nb_mvee_weights(const double* x, int64_t n, int32_t n_dim, int32_t n_max,
+                    int32_t n_batch, double* u, double* scratch, void* stream) {
+  if (x == nullptr || u == nullptr || scratch == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_mvee(x, n, n_dim, n_max, n_batch, u, scratch,
+                        as_stream(stream));
 }
 
 int nb_phase_shift(double* x, int64_t n, int32_t n_dim, int32_t n_periodic,

@@ -240,6 +240,22 @@ class DeviceBoundList:
         return idx
 
 
+MVEE_MAX_DIM = 63     # nb_mvee_weights keeps three (D+1)^2 matrices in LDS
+
+
+def mvee_weights(x, n_max=100, n_batch=20):
+    """Weights u of the batched Khachiyan iteration (reference
+    bounds/basic.py:175-232) for the rows of the cuda tensor / array ``x``."""
+    lib = _lib.load()
+    x = as_device_points(x)
+    n, d = x.shape
+    u = torch.empty(n, dtype=torch.float64, device='cuda')
+    scratch = torch.empty(n, dtype=torch.float64, device='cuda')
+    _lib.check(lib.nb_mvee_weights(_ptr(x), n, d, n_max, n_batch, _ptr(u),
+                                   _ptr(scratch), _stream()))
+    return u
+
+
 def phase_shift_(x, periodic, centers, inverse=False):
     """PhaseShift.transform (reference bounds/periodic.py:50-72) applied in
     place to the rows of the cuda tensor ``x``."""

@@ -1,11 +1,13 @@
 """Host-side construction of the bound geometry (small, sequential numerics).
 
-Bound *construction* -- minimum-volume enclosing ellipsoids, the greedy
-cube/ellipsoid split, the two-component mixture split and the ellipsoid
-overlap test -- runs a handful of times per bound on ~n_live points and stays
-on the host in this round (SURVEY.md section 8, rows f1/f2 "next").  What is
-built here is uploaded once through ``nb_bound_create``; every per-point
-operation afterwards (draw, contains, emulator, compaction) runs on the GPU.
+Bound *construction* runs a handful of times per bound on ~n_live points.  Its
+numerically heavy piece, the Khachiyan iteration of the minimum-volume
+enclosing ellipsoid, runs on the GPU (``nb_mvee_weights``); the O(D^3)
+finishing steps, the greedy cube/ellipsoid choice, the two-component mixture
+split and the ellipsoid overlap test stay on the host (SURVEY.md section 8,
+rows f1/f2).  What is built here is uploaded once through ``nb_bound_create``;
+every per-point operation afterwards (draw, contains, emulator, compaction)
+runs on the GPU.
 
 Semantics follow the reference (paths relative to /root/reference/nautilus):
 bounds/basic.py:154-241 (MVEE), 265-316 (Ellipsoid.compute), 471-563
@@ -28,14 +30,12 @@ def inv_spd(m):
     return tri + tri.T - np.diag(np.diag(tri))
 
 
-def mvee(points, n_max=100, n_batch=20):
-    """Batched Khachiyan iteration for the minimum-volume enclosing ellipsoid
-    (reference bounds/basic.py:175-241).  Unlike the reference the
+def khachiyan_weights_host(points, n_max=100, n_batch=20):
+    """Weights u of the batched Khachiyan iteration (reference
+    bounds/basic.py:175-232) on the host -- used for n_dim > 63, where the
+    device kernel's matrices no longer fit the LDS.  Unlike the reference the
     (n, D+1, D+1) tensor of outer products is never materialised: the
-    quadratic forms are computed as row sums of (Q V^-1) * Q.
-
-    Returns centre c, shape matrix A ((x-c)^T A (x-c) <= 1) and A^-1.
-    """
+    quadratic forms are computed as row sums of (Q V^-1) * Q."""
     n, d = points.shape
     q = np.empty((n, d + 1))
     q[:, :d] = points
@@ -63,6 +63,27 @@ def mvee(points, n_max=100, n_batch=20):
                 (1 - step)
             u *= (1 - step)
             u[j] += step
+    return u
+
+
+def khachiyan_weights(points, n_max=100, n_batch=20):
+    """The iteration runs on the GPU (``nb_mvee_weights``: one persistent
+    workgroup, quadratic forms on the matrix cores) whenever the dimension
+    allows it."""
+    from . import device
+    if points.shape[1] <= device.MVEE_MAX_DIM:
+        return device.mvee_weights(points, n_max, n_batch).cpu().numpy()
+    return khachiyan_weights_host(points, n_max, n_batch)
+
+
+def mvee(points, n_max=100, n_batch=20):
+    """Minimum-volume enclosing ellipsoid (reference bounds/basic.py:175-241):
+    Khachiyan weights, then centre / covariance / scaling (:233-241).
+
+    Returns centre c, shape matrix A ((x-c)^T A (x-c) <= 1) and A^-1.
+    """
+    points = np.ascontiguousarray(points, dtype=float)
+    u = khachiyan_weights(points, n_max, n_batch)
     c = np.atleast_1d(np.average(points, weights=u, axis=0))
     a_inv = np.atleast_2d(np.cov(points, aweights=u, rowvar=False, bias=True))
     a = np.linalg.inv(a_inv)

@@ -224,6 +224,55 @@ def test_nautilus_bound_contains_and_sample(dev, nautilus_d4):
     assert abs(log_v - float(g['log_v'])) < 0.1
 
 
+@pytest.mark.parametrize('d', [3, 20, 50])
+def test_mvee_kernel_matches_reference(dev, d):
+    """nb_mvee_weights (basic.py:175-232 on the device) against the oracle's
+    restatement and the reference's own ellipsoids (golden fixtures)."""
+    from nautilus_amd import geometry
+    from oracle import bounds_oracle as bo
+    g = load_golden('ellipsoid_D%d' % d)
+    pts = g['points']
+    c_o, a_o, _ = bo.mvee(pts)
+    u = dev.mvee_weights(pts).cpu().numpy()
+    assert u.shape == (len(pts),) and abs(u.sum() - 1.0) < 1e-12
+    assert np.all(u >= 0)
+    u_h = geometry.khachiyan_weights_host(pts)
+    assert np.allclose(u, u_h, rtol=0, atol=1e-9)
+    c, a, a_inv = geometry.mvee(pts)
+    assert np.allclose(c, c_o, rtol=0, atol=1e-9)
+    assert np.allclose(a, a_o, rtol=1e-7, atol=1e-8 * np.abs(a_o).max())
+    # every point inside, at least one on the surface (basic.py:236-239)
+    r2 = np.einsum('ij,jk,ik->i', pts - c, a, pts - c)
+    assert abs(r2.max() - 1.0) < 1e-12
+    p = geometry.ellipsoid_params(pts, float(g['enlarge']))
+    assert np.allclose(p['c'], g['c'], rtol=0, atol=1e-9)
+    assert np.allclose(p['B'], g['B'], rtol=1e-7, atol=1e-12)
+
+
+def test_mvee_kernel_shapes(dev):
+    """Known answers and ragged sizes: points on a sphere (reference
+    tests/test_bounds.py), n barely above n_dim, n not a multiple of 16, odd
+    and even dimensions up to the kernel's limit; above it the host form."""
+    from nautilus_amd import geometry
+    rng = np.random.default_rng(5)
+    for d, n in [(2, 3), (2, 100), (7, 9), (15, 333), (16, 200), (31, 64),
+                 (33, 1000), (62, 300), (63, 129)]:
+        pts = rng.normal(size=(n, d)) * rng.uniform(0.5, 2.0, size=d) + 0.3
+        u = dev.mvee_weights(pts).cpu().numpy()
+        u_h = geometry.khachiyan_weights_host(pts)
+        assert np.allclose(u, u_h, rtol=0, atol=1e-8), (d, n)
+    x = rng.normal(size=(500, 10))
+    x /= np.linalg.norm(x, axis=1)[:, None]
+    c, a, _ = geometry.mvee(x)
+    assert np.allclose(c, 0, atol=0.05)
+    assert np.allclose(a, np.eye(10), atol=0.1)
+    with pytest.raises(RuntimeError):
+        dev.mvee_weights(rng.normal(size=(200, 64)))
+    big = rng.normal(size=(300, 70))
+    assert np.allclose(geometry.khachiyan_weights(big),
+                       geometry.khachiyan_weights_host(big))
+
+
 def test_phase_shift_bit_exact(dev):
     """bounds/periodic.py on the device: centres, forward and inverse
     transform are bit-identical to the reference's (golden fixture)."""

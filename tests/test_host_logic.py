@@ -8,6 +8,17 @@ from scipy.stats import norm
 from conftest import load_golden
 
 
+@pytest.fixture(autouse=True)
+def host_khachiyan(monkeypatch):
+    """No GPU here: the host logic around the MVEE (finishing steps, greedy
+    cube/ellipsoid choice, overlap test) is exercised with the host form of
+    the Khachiyan iteration, which the product uses for n_dim > 63; the device
+    kernel itself is pinned under -m gpu (tests/test_hip_parity.py)."""
+    from nautilus_amd import geometry
+    monkeypatch.setattr(geometry, 'khachiyan_weights',
+                        geometry.khachiyan_weights_host)
+
+
 @pytest.mark.parametrize('d', [3, 20, 50])
 def test_ellipsoid_construction_matches_reference(d):
     from nautilus_amd import geometry
