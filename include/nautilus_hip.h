@@ -228,6 +228,26 @@ int nb_mvee_weights(const double* x_dev, int64_t n, int32_t n_dim,
                     int32_t n_max, int32_t n_batch, double* u_dev,
                     double* scratch_dev, void* stream);
 
+/* The mixture fit of Union.split (bounds/union.py:185-187): scikit-learn's
+ * GaussianMixture(n_components=2, n_init=n_init, covariance_type='full')
+ * restated on the device -- k-means++ / Lloyd initialisation, EM until the
+ * mean log-likelihood changes by less than tol (scikit-learn defaults: tol
+ * 1e-3, reg_covar 1e-6, max_iter 100).  One workgroup per restart.
+ * out_dev: n_init records of nb_gmm_out_doubles(n_dim) doubles
+ *   [lower_bound, n_iter, converged, failed, weight0, weight1,
+ *    mean0[D], mean1[D], cov0[D*D], cov1[D*D]]
+ * (the caller keeps the record with the largest lower bound, as
+ * mixture/_base.py:fit_predict does).  scratch_dev: n_init *
+ * nb_gmm_scratch_doubles(n, n_dim) doubles.  init_labels_dev (optional,
+ * [n_init][n] int32 in {0,1}) replaces the k-means initialisation.
+ * n_dim <= 63.                                                               */
+int64_t nb_gmm_out_doubles(int32_t n_dim);
+int64_t nb_gmm_scratch_doubles(int64_t n, int32_t n_dim);
+int nb_gmm_fit(const double* x_dev, int64_t n, int32_t n_dim, int32_t n_init,
+               uint64_t seed, double tol, double reg_covar, int32_t max_iter,
+               const int32_t* init_labels_dev, double* out_dev,
+               double* scratch_dev, void* stream);
+
 /* PhaseShift.transform (bounds/periodic.py:50-72), in place on device rows:
  * x[:, periodic[i]] = (x[:, periodic[i]] -/+ (0.5 - centers[i])) mod 1
  * (inverse != 0 undoes the shift, nautilus.py:241-243).  `periodic` and

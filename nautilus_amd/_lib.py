@@ -98,6 +98,11 @@ _SIGNATURES = {
     'nb_mvee_weights': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
+    'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
+    'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                             C.c_uint64, C.c_double, C.c_double, C.c_int32,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'nb_phase_shift': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                  c_int32_p, c_double_p, C.c_int32,
                                  C.c_void_p]),

@@ -35,6 +35,12 @@ int nb_launch_philox(unsigned long long seed, unsigned long long offset,
 int nb_run_mfma_peak(int iters, double* tflops);
 int nb_launch_mvee(const double* x, long long n, int n_dim, int n_max,
                    int n_batch, double* u, double* g, hipStream_t stream);
+long long nb_gmm_out_stride_impl(int d);
+long long nb_gmm_scratch_stride_impl(long long n, int d);
+int nb_launch_gmm(const double* x, long long n, int d, int n_init,
+                  unsigned long long seed, double tol, double reg, int max_iter,
+                  const int* init_labels, double* out, double* scratch,
+                  hipStream_t stream);
 int nb_launch_phase_shift(double* x, long long n, int n_dim, const double* s,
                           const unsigned char* on, int inverse,
                           hipStream_t stream);
@@ -565,6 +571,26 @@ int nb_mvee_weights(const double* x, int64_t n, int32_t n_dim, int32_t n_max,
   }
   return nb_launch_mvee(x, n, n_dim, n_max, n_batch, u, scratch,
                         as_stream(stream));
+}
+
+int64_t nb_gmm_out_doubles(int32_t n_dim) {
+  return nb_gmm_out_stride_impl(n_dim);
+}
+
+int64_t nb_gmm_scratch_doubles(int64_t n, int32_t n_dim) {
+  return nb_gmm_scratch_stride_impl(n, n_dim);
+}
+
+int nb_gmm_fit(const double* x, int64_t n, int32_t n_dim, int32_t n_init,
+               uint64_t seed, double tol, double reg_covar, int32_t max_iter,
+               const int32_t* init_labels, double* out, double* scratch,
+               void* stream) {
+  if (x == nullptr || out == nullptr || scratch == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_gmm(x, n, n_dim, n_init, seed, tol, reg_covar, max_iter,
+                       init_labels, out, scratch, as_stream(stream));
 }
 
 int nb_phase_shift(double* x, int64_t n, int32_t n_dim, int32_t n_periodic,

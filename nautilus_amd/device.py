@@ -256,6 +256,40 @@ def mvee_weights(x, n_max=100, n_batch=20):
     return u
 
 
+GMM_MAX_DIM = 63
+
+
+def gmm_fit(x, n_init=10, seed=0, tol=1e-3, reg_covar=1e-6, max_iter=100,
+            init_labels=None):
+    """Two-component full-covariance Gaussian mixture fits (one per restart)
+    on the device -- ``nb_gmm_fit``.  Returns a list of dicts with
+    ``lower_bound, n_iter, converged, failed, weights, means, covariances``."""
+    lib = _lib.load()
+    x = as_device_points(x)
+    n, d = x.shape
+    stride = lib.nb_gmm_out_doubles(d)
+    out = torch.zeros(n_init * stride, dtype=torch.float64, device='cuda')
+    scratch = torch.empty(n_init * lib.nb_gmm_scratch_doubles(n, d),
+                          dtype=torch.float64, device='cuda')
+    lab = None
+    if init_labels is not None:
+        lab = torch.from_numpy(np.ascontiguousarray(
+            init_labels, dtype=np.int32).reshape(n_init, n)).cuda()
+    _lib.check(lib.nb_gmm_fit(
+        _ptr(x), n, d, n_init, int(seed) & (2**64 - 1), float(tol),
+        float(reg_covar), int(max_iter), _ptr(lab) if lab is not None else None,
+        _ptr(out), _ptr(scratch), _stream()))
+    rec = out.cpu().numpy().reshape(n_init, stride)
+    fits = []
+    for r in rec:
+        fits.append(dict(
+            lower_bound=float(r[0]), n_iter=int(r[1]), converged=bool(r[2]),
+            failed=bool(r[3]), weights=r[4:6].copy(),
+            means=r[6:6 + 2 * d].reshape(2, d).copy(),
+            covariances=r[6 + 2 * d:].reshape(2, d, d).copy()))
+    return fits
+
+
 def phase_shift_(x, periodic, centers, inverse=False):
     """PhaseShift.transform (reference bounds/periodic.py:50-72) applied in
     place to the rows of the cuda tensor ``x``."""

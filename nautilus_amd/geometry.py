@@ -189,6 +189,17 @@ N_INIT = 10          # bounds/union.py:186
 _GMM_POOL = None
 
 
+class _Mixture:
+    """The three attributes of a fitted sklearn GaussianMixture that
+    Union.split reads (union.py:188-190)."""
+
+    def __init__(self, weights, means, covariances, lower_bound):
+        self.weights_ = weights
+        self.means_ = means
+        self.covariances_ = covariances
+        self.lower_bound_ = lower_bound
+
+
 def _fit_one(args):
     from sklearn.mixture import GaussianMixture
     points_t, seed = args
@@ -197,13 +208,12 @@ def _fit_one(args):
                                random_state=seed).fit(points_t)
 
 
-def _best_of_inits(points_t, random_state):
-    """Best of N_INIT EM runs of a two-component mixture.  The reference runs
-    them sequentially inside one ``GaussianMixture(n_init=10)`` call; here the
-    restarts get seeds derived from ``random_state`` and run concurrently on
-    host threads (numpy releases the GIL inside BLAS), which keeps the host
-    part of bound construction short.  Same estimator, same selection rule
-    (largest lower bound), deterministic for a given ``random_state``."""
+def _best_of_inits_host(points_t, random_state):
+    """scikit-learn on host threads -- used for n_dim > 63 only.  The
+    reference runs the restarts sequentially inside one
+    ``GaussianMixture(n_init=10)`` call; here they get seeds derived from
+    ``random_state`` and run concurrently (numpy releases the GIL inside
+    BLAS).  Same estimator, same selection rule (largest lower bound)."""
     global _GMM_POOL
     from concurrent.futures import ThreadPoolExecutor
     seeds = np.random.RandomState(random_state).randint(2**31 - 1,
@@ -212,6 +222,23 @@ def _best_of_inits(points_t, random_state):
         _GMM_POOL = ThreadPoolExecutor(max_workers=N_INIT)
     fits = list(_GMM_POOL.map(_fit_one, [(points_t, int(sd)) for sd in seeds]))
     return max(fits, key=lambda g: g.lower_bound_)
+
+
+def _best_of_inits(points_t, random_state):
+    """Best of N_INIT restarts of the two-component mixture
+    (mixture/_base.py:fit_predict keeps the largest lower bound).  All
+    restarts run concurrently on the GPU (``nb_gmm_fit``)."""
+    from . import device
+    if points_t.shape[1] > device.GMM_MAX_DIM:
+        return _best_of_inits_host(points_t, random_state)
+    fits = [f for f in device.gmm_fit(points_t, n_init=N_INIT,
+                                      seed=random_state) if not f['failed']]
+    if not fits:
+        raise ValueError('Fitting the mixture model failed because some '
+                         'components have ill-defined empirical covariance.')
+    best = max(fits, key=lambda f: f['lower_bound'])
+    return _Mixture(best['weights'], best['means'], best['covariances'],
+                    best['lower_bound'])
 
 
 def two_component_labels(points_t, n_points_min, random_state):

@@ -273,6 +273,86 @@ def test_mvee_kernel_shapes(dev):
                        geometry.khachiyan_weights_host(big))
 
 
+def _sklearn_em_from_labels(x, labels, **kw):
+    """scikit-learn's EM started from the M-step of a hard assignment (what
+    mixture/_base.py:_initialize_parameters does with the k-means labels)."""
+    from sklearn.mixture import GaussianMixture
+    resp = np.stack([labels == 0, labels == 1], axis=1).astype(float)
+    nk = resp.sum(axis=0) + 10 * np.finfo(float).eps
+    means = resp.T @ x / nk[:, None]
+    covs = []
+    for k in range(2):
+        diff = x - means[k]
+        cov = (resp[:, k] * diff.T) @ diff / nk[k]
+        cov.flat[::x.shape[1] + 1] += 1e-6
+        covs.append(cov)
+    gmm = GaussianMixture(
+        n_components=2, weights_init=nk / nk.sum(), means_init=means,
+        precisions_init=np.array([np.linalg.inv(c) for c in covs]), **kw)
+    with np.errstate(all='ignore'):
+        return gmm.fit(x)
+
+
+@pytest.mark.parametrize('d,n', [(2, 300), (7, 500), (20, 1500), (50, 2000),
+                                 (63, 700)])
+def test_gmm_em_matches_sklearn(dev, d, n):
+    """nb_gmm_fit against scikit-learn 1.7 (the reference's dependency for
+    Union.split, union.py:185-187): same initial assignment -> same EM
+    trajectory (number of iterations, lower bound, parameters)."""
+    rng = np.random.default_rng(d)
+    shift = np.zeros(d)
+    shift[0] = 3.0
+    x = np.vstack([rng.normal(size=(n // 2, d)),
+                   rng.normal(size=(n - n // 2, d)) * 0.7 + shift])
+    x = x[rng.permutation(n)]
+    inits = np.array([(x[:, 0] > 1.5).astype(np.int32),
+                      (x[:, 1] > 0.0).astype(np.int32),
+                      rng.integers(0, 2, n).astype(np.int32)])
+    fits = dev.gmm_fit(x, n_init=3, init_labels=inits)
+    for lab, fit in zip(inits, fits):
+        ref = _sklearn_em_from_labels(x, lab)
+        assert not fit['failed']
+        assert fit['n_iter'] == ref.n_iter_
+        assert fit['converged'] == ref.converged_
+        assert abs(fit['lower_bound'] - ref.lower_bound_) < 1e-9
+        assert np.allclose(fit['weights'], ref.weights_, rtol=0, atol=1e-10)
+        assert np.allclose(fit['means'], ref.means_, rtol=0, atol=1e-8)
+        assert np.allclose(fit['covariances'], ref.covariances_, rtol=0,
+                           atol=1e-8)
+
+
+def test_gmm_full_fit(dev):
+    """k-means++ / Lloyd seeding + EM: separated clusters are recovered like
+    scikit-learn recovers them; on a single Gaussian the best restart reaches
+    scikit-learn's likelihood; restarts are reproducible for a given seed."""
+    from sklearn.mixture import GaussianMixture
+    from nautilus_amd import geometry
+    rng = np.random.default_rng(3)
+    d, n = 10, 1200
+    shift = np.zeros(d)
+    shift[:2] = 6.0
+    x = np.vstack([rng.normal(size=(n // 3, d)),
+                   rng.normal(size=(n - n // 3, d)) + shift])
+    truth = np.r_[np.zeros(n // 3, int), np.ones(n - n // 3, int)]
+    fits = dev.gmm_fit(x, n_init=10, seed=42)
+    again = dev.gmm_fit(x, n_init=10, seed=42)
+    assert [f['lower_bound'] for f in fits] == \
+        [f['lower_bound'] for f in again]
+    best = max(fits, key=lambda f: f['lower_bound'])
+    ref = GaussianMixture(n_components=2, n_init=10, random_state=0).fit(x)
+    assert abs(best['lower_bound'] - ref.lower_bound_) < 2e-3
+    lab = geometry.two_component_labels(x, d + 1, 42)
+    agree = max(np.mean(lab == truth), np.mean(lab != truth))
+    assert agree == 1.0
+    # unimodal input (the usual case in Union.split): likelihood on par
+    x1 = rng.normal(size=(2000, 30))
+    best1 = max(dev.gmm_fit(x1, n_init=10, seed=7),
+                key=lambda f: f['lower_bound'])
+    ref1 = GaussianMixture(n_components=2, n_init=10, random_state=0).fit(x1)
+    assert best1['lower_bound'] > ref1.lower_bound_ - 0.02
+    assert np.bincount(geometry.two_component_labels(x1, 31, 7)).min() >= 31
+
+
 def test_phase_shift_bit_exact(dev):
     """bounds/periodic.py on the device: centres, forward and inverse
     transform are bit-identical to the reference's (golden fixture)."""
