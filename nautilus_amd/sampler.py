@@ -23,6 +23,7 @@ callable is evaluated on the host exactly like in the reference, including
 ``vectorized`` / ``pass_dict`` / ``pool`` handling.
 """
 
+import warnings
 from functools import partial
 from time import time
 
@@ -88,8 +89,6 @@ class Sampler:
             raise NotImplementedError(
                 'checkpointing is not part of the device path yet '
                 '(SURVEY.md section 8 row f3)')
-        if blobs_dtype is not None:
-            raise NotImplementedError('blobs are not supported yet')
 
         self._device_likelihood = bool(getattr(likelihood, 'device', False))
         self._prior_is_identity = getattr(prior, '__name__', '') == \
@@ -161,7 +160,9 @@ class Sampler:
         self._pts = []           # per shell: _Grow (n, n_dim) on the device
         self._ll_dev = []        # per shell: _Grow (n,) on the device
         self.log_l = []          # per shell: numpy mirror of log_l
-        self.blobs = None
+        self.blobs = None        # per shell: numpy (structured) arrays
+        self.blobs_dtype = blobs_dtype
+        self.blobs_t = None
         self._discard_exploration = False
         self.shell_n = np.zeros(0, dtype=int)
         self.shell_n_sample = np.zeros(0, dtype=int)
@@ -237,6 +238,27 @@ class Sampler:
         lz = (self.shell_log_l + self.shell_log_v)[use]
         eff = (self.shell_n_eff / self.shell_n)[use]
         return np.exp(2 * logsumexp(lz) - 2 * logsumexp(lz - 0.5 * np.log(eff)))
+
+    def effective_sample_size(self):
+        """Deprecated alias of ``n_eff`` (sampler.py:667-679)."""
+        warnings.warn("The function 'effective_sample_size' is deprecated. "
+                      "Please use the 'n_eff' property, instead.",
+                      DeprecationWarning, stacklevel=2)
+        return self.n_eff
+
+    def evidence(self):
+        """Deprecated alias of ``log_z`` (sampler.py:696-707)."""
+        warnings.warn("The function 'evidence' is deprecated. Please use the "
+                      "'log_z' property, instead.", DeprecationWarning,
+                      stacklevel=2)
+        return self.log_z
+
+    def asymptotic_sampling_efficiency(self):
+        """Deprecated alias of ``eta`` (sampler.py:732-744)."""
+        warnings.warn("The function 'asymptotic_sampling_efficiency' is "
+                      "deprecated. Please use the 'eta' property, instead.",
+                      DeprecationWarning, stacklevel=2)
+        return self.eta
 
     def _weights_and_log_l(self):
         per_point = np.repeat(
@@ -338,6 +360,8 @@ class Sampler:
             self._pts.pop(s)
             self._ll_dev.pop(s)
             self.log_l.pop(s)
+            if self.blobs is not None:
+                self.blobs.pop(s)
             for key in ('shell_n', 'shell_n_sample', 'shell_n_eff',
                         'shell_log_l_min', 'shell_log_l', 'shell_log_v'):
                 setattr(self, key, np.delete(getattr(self, key), s))
@@ -449,14 +473,17 @@ class Sampler:
 
     def evaluate_likelihood(self, points):
         """sampler.py:832-908.  ``points`` is a cuda tensor (n, n_dim);
-        returns (log_l numpy, log_l cuda tensor)."""
+        returns (log_l numpy, log_l cuda tensor, blobs or None)."""
         if self._device_likelihood:
             args = points
             if callable(self.prior) and not self._prior_is_identity:
                 args = self.prior(points)
             ll = self.likelihood(args)
+            if isinstance(ll, tuple):
+                raise NotImplementedError(
+                    'blobs are supported for host likelihoods only')
             self.n_like += ll.shape[0]
-            return ll.cpu().numpy(), ll
+            return ll.cpu().numpy(), ll, None
 
         if callable(self.prior):
             transform = self.prior
@@ -474,12 +501,32 @@ class Sampler:
             result = list(self.pool_l.map(self.likelihood, args))
         else:
             result = list(map(self.likelihood, args))
+        # blobs: everything the likelihood returns after the first element
+        # (sampler.py:875-905)
+        blobs = None
         if isinstance(result[0], tuple):
-            raise NotImplementedError('blobs are not supported yet')
+            blobs = [r[1:] for r in result]
+            result = [r[0] for r in result]
         log_l = (np.concatenate(result) if self.vectorized
                  else np.array(result)).astype(float)
+        if blobs is not None:
+            n_col = len(blobs[0])
+            if self.vectorized:
+                blobs = [np.concatenate([row[col] for row in blobs])
+                         for col in range(n_col)]
+            else:
+                blobs = [np.array([row[col] for row in blobs])
+                         for col in range(n_col)]
+            if self.blobs_dtype is None:
+                if n_col > 1:
+                    self.blobs_dtype = [('blob_{}'.format(i), b.dtype)
+                                        for i, b in enumerate(blobs)]
+                else:
+                    self.blobs_dtype = blobs[0].dtype
+            blobs = np.squeeze(np.array(list(zip(*blobs)),
+                                        dtype=self.blobs_dtype))
         self.n_like += len(log_l)
-        return log_l, torch.from_numpy(log_l).cuda()
+        return log_l, torch.from_numpy(log_l).cuda(), blobs
 
     def update_shell_info(self, index):
         """sampler.py:910-943 with the reductions on the device."""
@@ -512,6 +559,7 @@ class Sampler:
             self.print_status('Sampling', end='\r')
         t0 = time()
         log_l = None
+        blobs = None
         if shell == -1 and len(self.shell_t) > 0:
             pts, n_bound, idx_t = self.sample_shell(-1, self.shell_t)
             assert pts.shape[0] + len(idx_t) == n_bound
@@ -522,6 +570,9 @@ class Sampler:
                     torch.from_numpy(self.log_l_t[idx_t]).cuda())
                 self.log_l[-1] = np.concatenate(
                     (self.log_l[-1], self.log_l_t[idx_t]))
+                if self.blobs is not None:
+                    self.blobs[-1] = np.concatenate(
+                        (self.blobs[-1], self.blobs_t[idx_t]))
         elif self.comm is not None and self.explored:
             pts, log_l, log_l_dev, n_bound = self._sharded_batch(shell)
         else:
@@ -529,11 +580,17 @@ class Sampler:
         t1 = time()
         self.shell_n_sample[shell] += n_bound
         if log_l is None:
-            log_l, log_l_dev = self.evaluate_likelihood(pts)
+            log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
         t2 = time()
         self._pts[shell].append(pts)
         self._ll_dev[shell].append(log_l_dev)
         self.log_l[shell] = np.append(self.log_l[shell], log_l)
+        if blobs is not None:                      # sampler.py:1137-1141
+            if self.blobs is None:
+                self.blobs = [blobs]
+            else:
+                self.blobs[shell] = np.append(self.blobs[shell], blobs,
+                                              axis=0)
         self.update_shell_info(shell)
         t3 = time()
         self.timing['sample_shell'] += t1 - t0
@@ -563,7 +620,10 @@ class Sampler:
         n_local = parallel.split_batch(self.n_batch, comm.world)
         pts, n_bound = self.sample_shell(shell, n_target=n_local)
         n_like0 = self.n_like
-        _, ll_dev = self.evaluate_likelihood(pts)
+        _, ll_dev, blobs = self.evaluate_likelihood(pts)
+        if blobs is not None:
+            raise NotImplementedError(
+                'blobs are not exchanged between ranks of a sharded run')
         self.n_like = n_like0
         after = [getattr(o, c) for o in owners for c in counters]
         delta = [a - b for a, b in zip(after, before)]
@@ -635,11 +695,14 @@ class Sampler:
         self._pts.append(_Grow(self.n_dim))
         self._ll_dev.append(_Grow())
         self.log_l.append(np.zeros(0))
+        if self.blobs is not None:                 # sampler.py:1050-1052
+            self.blobs.append(np.zeros(self.blobs[-1][:0].shape,
+                                       dtype=self.blobs_dtype))
         self._later = {}
 
         if len(self.bounds) > 1:
             # candidates for transfer into the new shell, sampler.py:1057-1089
-            st, pt, lt = [], [], []
+            st, pt, lt, bt = [], [], [], []
             new = self.bounds[-1]
             for s in range(len(self.bounds) - 1):
                 if self._pts[s].n == 0:
@@ -652,6 +715,9 @@ class Sampler:
                 st.append(np.repeat(s, k))
                 pt.append(self._pts[s].view()[inside])
                 lt.append(self.log_l[s][inside_h])
+                if self.blobs is not None:
+                    bt.append(self.blobs[s][inside_h])
+                    self.blobs[s] = self.blobs[s][~inside_h]
                 self._pts[s].keep(~inside)
                 self._ll_dev[s].keep(~inside)
                 self.log_l[s] = self.log_l[s][~inside_h]
@@ -661,10 +727,14 @@ class Sampler:
                 self.shell_t = np.concatenate(st)
                 self._pts_t = torch.cat(pt)
                 self.log_l_t = np.concatenate(lt)
+                if self.blobs is not None:
+                    self.blobs_t = np.concatenate(bt)
             else:
                 self.shell_t = np.zeros(0, dtype=int)
                 self._pts_t = self._pts_t[:0]
                 self.log_l_t = np.zeros(0)
+                if self.blobs is not None:
+                    self.blobs_t = self.blobs[0][:0]
         self.timing['add_bound'] += time() - t0
         return True
 
@@ -674,7 +744,7 @@ class Sampler:
     def posterior(self, return_as_dict=None, equal_weight=False,
                   equal_weight_boost=1.0, return_blobs=False):
         """sampler.py:541-647."""
-        if return_blobs:
+        if return_blobs and self.blobs is None:
             raise ValueError('No blobs have been calculated.')
         if return_as_dict is None:
             return_as_dict = bool(callable(self.prior) and self.pass_dict)
@@ -688,6 +758,9 @@ class Sampler:
         log_w = np.repeat(self.shell_log_v -
                           np.log(np.maximum(self.shell_n, 1)),
                           self.shell_n) + log_l
+        blobs = None
+        if return_blobs:
+            blobs = np.concatenate([b[s:] for b, s in zip(self.blobs, start)])
         if equal_weight:
             rep = np.exp(log_w - np.amax(log_w)) * equal_weight_boost
             rep = np.floor(rep).astype(int) + (
@@ -695,6 +768,8 @@ class Sampler:
             pts = np.repeat(pts, rep, axis=0)
             log_w = np.zeros(np.sum(rep))
             log_l = np.repeat(log_l, rep, axis=0)
+            if return_blobs:
+                blobs = np.repeat(blobs, rep, axis=0)
         if callable(self.prior):
             transform = self.prior
         elif return_as_dict:
@@ -708,6 +783,8 @@ class Sampler:
         if not return_as_dict and callable(self.prior) and self.pass_dict:
             raise ValueError('Cannot return points as numpy array. The prior '
                              'function only returns dictionaries.')
+        if return_blobs:
+            return pts, log_w - logsumexp(log_w), log_l, blobs
         return pts, log_w - logsumexp(log_w), log_l
 
     def shell_bound_occupation(self, fractional=True):

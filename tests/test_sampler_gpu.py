@@ -349,3 +349,90 @@ def test_sampler_periodic(periodic):
     for qx in (pts[:, 0] < 0.5, pts[:, 0] >= 0.5):
         for qy in (pts[:, 1] < 0.5, pts[:, 1] >= 0.5):
             assert abs(np.sum(w[qx & qy]) - 0.25) < 0.04
+
+
+def likelihood_basic(x, pass_dict, n_blobs):
+    # module scope: picklable for the multiprocessing pool
+    if pass_dict:
+        x = np.squeeze(np.column_stack([x['a'], x['b']]))
+    log_l = -np.linalg.norm(x - 0.5, axis=-1) * 0.001
+    if n_blobs == 0:
+        return log_l
+    if n_blobs == 1:
+        return log_l, x[..., 0]
+    return log_l, x[..., 0], x[..., 1]
+
+
+@pytest.mark.parametrize('n_networks,vectorized,pass_dict,pool,n_blobs', [
+    (0, True, True, None, 0), (0, True, False, None, 1),
+    (0, False, True, None, 2), (0, False, False, None, 1),
+    (1, True, False, None, 2), (1, False, True, None, 1),
+    (1, True, True, 2, 1), (0, False, False, 2, 2)])
+def test_sampler_basic_with_blobs(n_networks, vectorized, pass_dict, pool,
+                                  n_blobs):
+    """reference tests/test_sampler.py:24-66: every argument-passing mode of
+    the likelihood, with and without blobs."""
+    from functools import partial
+    from nautilus_amd import Prior, Sampler
+    if pass_dict:
+        prior = Prior()
+        prior.add_parameter('a')
+        prior.add_parameter('b')
+    else:
+        def prior(x):
+            return x
+    likelihood = partial(likelihood_basic, pass_dict=pass_dict,
+                         n_blobs=n_blobs)
+    sampler = Sampler(prior, likelihood, n_dim=2, n_networks=n_networks,
+                      vectorized=vectorized, pass_dict=pass_dict, n_live=200,
+                      pool=pool, seed=1)
+    sampler.run(n_like_max=600)
+    sampler.posterior()
+    sampler.posterior(equal_weight=True)
+    points, log_w, log_l = sampler.posterior(return_as_dict=pass_dict)
+    if pass_dict:
+        assert isinstance(points, dict)
+        points = np.column_stack([points[key] for key in points])
+    assert len(np.unique(points, axis=0)) == len(points)
+    assert sampler.n_eff > 0
+    assert 0 < sampler.eta < 1
+    if n_blobs == 0:
+        with pytest.raises(ValueError):
+            sampler.posterior(return_blobs=True)
+    elif n_blobs == 1:
+        blobs = sampler.posterior(return_blobs=True)[-1]
+        assert np.allclose(points[:, 0], blobs)
+    else:
+        blobs = sampler.posterior(return_blobs=True)[-1]
+        assert np.allclose(points[:, 0], blobs['blob_0'])
+        assert np.allclose(points[:, 1], blobs['blob_1'])
+    # blobs follow their points through exploration discard and resampling
+    if n_blobs == 1:
+        sampler.discard_exploration = True
+        pts, _, _, blobs = sampler.posterior(return_blobs=True,
+                                             return_as_dict=False) \
+            if not pass_dict else (None, None, None, None)
+        if pts is not None:
+            assert np.allclose(pts[:, 0], blobs)
+        p_eq = sampler.posterior(equal_weight=True, return_blobs=True,
+                                 return_as_dict=pass_dict)
+        pe = p_eq[0]
+        if pass_dict:
+            pe = np.column_stack([pe[key] for key in pe])
+        assert np.allclose(pe[:, 0], p_eq[-1])
+
+
+def test_deprecated_accessors():
+    """reference tests/test_sampler.py:85-94."""
+    from nautilus_amd import Sampler
+    s = Sampler(lambda u: u, gauss3_numpy, n_dim=3, n_live=300, n_networks=0,
+                vectorized=True, seed=2)
+    s.run(n_like_max=1000)
+    with pytest.warns(DeprecationWarning):
+        assert s.evidence() == s.log_z
+    with pytest.warns(DeprecationWarning):
+        assert s.effective_sample_size() == s.n_eff
+    with pytest.warns(DeprecationWarning):
+        assert s.asymptotic_sampling_efficiency() == s.eta
+    with pytest.raises(ValueError):
+        s.posterior(return_blobs=True)
