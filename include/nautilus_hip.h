@@ -228,6 +228,19 @@ int nb_mvee_weights(const double* x_dev, int64_t n, int32_t n_dim,
                     int32_t n_max, int32_t n_batch, double* u_dev,
                     double* scratch_dev, void* stream);
 
+/* Ellipsoid.transform (bounds/basic.py:318-342, forward direction):
+ * y_dev[i] = B_inv (x_i - c) for an Ellipsoid bound (or the ellipsoid of a
+ * NeuralBound) -- the emulator's training inputs (bounds/neural.py:90).      */
+int nb_ellipsoid_transform(const nb_bound* bound, const double* x_dev,
+                           int64_t n, double* y_dev, void* stream);
+
+/* Input standardisation of NeuralNetworkEmulator.train (neural.py:74-77):
+ * mean_dev[j] = mean(x[:, j]), scale_dev[j] = std(x[:, j]) and, when out_dev
+ * is not NULL, out_dev = (x - mean) / scale.                                 */
+int nb_standardize(const double* x_dev, int64_t n, int32_t n_dim,
+                   double* mean_dev, double* scale_dev, double* out_dev,
+                   void* stream);
+
 /* The mixture fit of Union.split (bounds/union.py:185-187): scikit-learn's
  * GaussianMixture(n_components=2, n_init=n_init, covariance_type='full')
  * restated on the device -- k-means++ / Lloyd initialisation, EM until the

@@ -98,6 +98,10 @@ _SIGNATURES = {
     'nb_mvee_weights': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    'nb_ellipsoid_transform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p]),
+    'nb_standardize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
     'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
     'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

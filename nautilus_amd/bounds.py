@@ -629,11 +629,9 @@ class PhaseShift:
 
 
 def transform_device(ellipsoid, x):
-    """B_inv (x - c) for a cuda tensor of points (reference basic.py:340).
-    A one-off per bound construction; expressed as a dense product."""
-    c = torch.from_numpy(ellipsoid.c).cuda()
-    b_inv_t = torch.from_numpy(np.ascontiguousarray(ellipsoid.B_inv.T)).cuda()
-    return ((x - c) @ b_inv_t).contiguous()
+    """B_inv (x - c) for a cuda tensor of points (reference basic.py:340), on
+    the matrix cores like every later evaluation of the same transform."""
+    return ellipsoid.device_bound().transform(x)
 
 
 class NautilusBound(_RejectionSampler):

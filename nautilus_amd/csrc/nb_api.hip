@@ -35,6 +35,11 @@ int nb_launch_philox(unsigned long long seed, unsigned long long offset,
 int nb_run_mfma_peak(int iters, double* tflops);
 int nb_launch_mvee(const double* x, long long n, int n_dim, int n_max,
                    int n_batch, double* u, double* g, hipStream_t stream);
+int nb_launch_transform(const double* ell_block, int dt, int n_dim,
+                        const double* x, long long n, double* y,
+                        hipStream_t stream);
+int nb_launch_standardize(const double* x, long long n, int d, double* mean,
+                          double* scale, double* out, hipStream_t stream);
 long long nb_gmm_out_stride_impl(int d);
 long long nb_gmm_scratch_stride_impl(long long n, int d);
 int nb_launch_gmm(const double* x, long long n, int d, int n_init,
@@ -66,7 +71,12 @@ struct nb_bound {
   int n_dim = 0, dt = 0, K = 0, M = 0, E = 0;
   bool single_full_ellipsoid = false;
   int64_t off_stream = 0;
+  int64_t off_members = 0, off_neural = 0;
 };
+
+static inline int64_t nb_hdr_host_off_members(const nb_bound* b) {
+  return b->off_members;
+}
 
 struct nb_boundlist {
   const double** ptrs_dev = nullptr;
@@ -397,6 +407,8 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   b->n_dim = n_dim; b->dt = dt; b->K = K; b->M = M; b->E = E;
   b->single_full_ellipsoid = single_full;
   b->off_stream = off_stream;
+  b->off_members = off_members;
+  b->off_neural = off_neural;
   hipError_t e = hipMalloc((void**)&b->blob_dev, (size_t)total * sizeof(double));
   if (e == hipSuccess)
     e = hipMemcpy(b->blob_dev, buf.data(), (size_t)total * sizeof(double),
@@ -571,6 +583,30 @@ int nb_mvee_weights(const double* x, int64_t n, int32_t n_dim, int32_t n_max,
   }
   return nb_launch_mvee(x, n, n_dim, n_max, n_batch, u, scratch,
                         as_stream(stream));
+}
+
+int nb_ellipsoid_transform(const nb_bound* b, const double* x, int64_t n,
+                           double* y, void* stream) {
+  const double* blk = nullptr;
+  if (b->single_full_ellipsoid)
+    blk = b->blob_dev + nb_hdr_host_off_members(b);
+  else if (b->K == 0 && b->M >= 1)
+    blk = b->blob_dev + b->off_neural;
+  if (blk == nullptr) {
+    nb_set_error("nb_ellipsoid_transform needs an Ellipsoid or a NeuralBound");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_transform(blk, b->dt, b->n_dim, x, n, y, as_stream(stream));
+}
+
+int nb_standardize(const double* x, int64_t n, int32_t n_dim, double* mean,
+                   double* scale, double* out, void* stream) {
+  if (x == nullptr || mean == nullptr || scale == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_standardize(x, n, n_dim, mean, scale, out,
+                               as_stream(stream));
 }
 
 int64_t nb_gmm_out_doubles(int32_t n_dim) {

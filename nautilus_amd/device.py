@@ -167,6 +167,15 @@ class DeviceBound:
             self._h, _ptr(x), x.shape[0], _ptr(mask), _stream()))
         return mask.bool()
 
+    def transform(self, x):
+        """B_inv (x - c) of an Ellipsoid / NeuralBound ellipsoid (reference
+        basic.py:340) -- ``nb_ellipsoid_transform``."""
+        x = as_device_points(x, self.n_dim)
+        y = torch.empty_like(x)
+        _lib.check(self._lib.nb_ellipsoid_transform(
+            self._h, _ptr(x), x.shape[0], _ptr(y), _stream()))
+        return y
+
     def member_count(self, x):
         x = as_device_points(x, self.n_dim)
         cnt = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
@@ -254,6 +263,20 @@ def mvee_weights(x, n_max=100, n_batch=20):
     _lib.check(lib.nb_mvee_weights(_ptr(x), n, d, n_max, n_batch, _ptr(u),
                                    _ptr(scratch), _stream()))
     return u
+
+
+def standardize(x):
+    """(mean, scale, (x - mean) / scale) of the rows of a cuda tensor
+    (reference neural.py:74-77) -- ``nb_standardize``."""
+    lib = _lib.load()
+    x = as_device_points(x)
+    n, d = x.shape
+    mean = torch.empty(d, dtype=torch.float64, device='cuda')
+    scale = torch.empty(d, dtype=torch.float64, device='cuda')
+    out = torch.empty_like(x)
+    _lib.check(lib.nb_standardize(_ptr(x), n, d, _ptr(mean), _ptr(scale),
+                                  _ptr(out), _stream()))
+    return mean, scale, out
 
 
 GMM_MAX_DIM = 63

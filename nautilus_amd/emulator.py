@@ -171,11 +171,9 @@ class NeuralNetworkEmulator:
         yt = (y if isinstance(y, torch.Tensor) else
               torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64))
               ).to('cuda', torch.float64).contiguous()
-        mean = xt.mean(dim=0)
-        scale = xt.std(dim=0, unbiased=False)
+        mean, scale, xs = device.standardize(xt)         # neural.py:74-77
         emu.mean = mean.cpu().numpy()
         emu.scale = scale.cpu().numpy()
-        xs = ((xt - mean) / scale).contiguous()
         hp = _hparams_from_kwargs(dict(neural_network_kwargs))
         emu.neural_networks, emu.trainer_stats = train_networks(
             xs, yt, list(range(n_networks)), hp)

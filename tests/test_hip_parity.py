@@ -353,6 +353,28 @@ def test_gmm_full_fit(dev):
     assert np.bincount(geometry.two_component_labels(x1, 31, 7)).min() >= 31
 
 
+@pytest.mark.parametrize('d', [3, 20, 50])
+def test_transform_and_standardize(dev, d):
+    """nb_ellipsoid_transform (basic.py:340) and nb_standardize
+    (neural.py:74-77) against numpy on the golden ellipsoids."""
+    import torch
+    from oracle import bounds_oracle as bo
+    g = load_golden('ellipsoid_D%d' % d)
+    e = bo.OEllipsoid.from_params(g['c'], g['B'], g['B_inv'])
+    b = upload(e)
+    x = np.random.default_rng(d).random((1003, d))
+    y = b.transform(x).cpu().numpy()
+    want = e.transform(x)
+    assert np.allclose(y, want, rtol=0, atol=1e-11 * np.abs(want).max())
+    mean, scale, xs = dev.standardize(torch.from_numpy(want).cuda())
+    assert np.allclose(mean.cpu().numpy(), want.mean(axis=0), rtol=0,
+                       atol=1e-13 * np.abs(want).max())
+    assert np.allclose(scale.cpu().numpy(), want.std(axis=0), rtol=1e-13)
+    assert np.allclose(xs.cpu().numpy(),
+                       (want - want.mean(axis=0)) / want.std(axis=0),
+                       rtol=0, atol=1e-11)
+
+
 def test_phase_shift_bit_exact(dev):
     """bounds/periodic.py on the device: centres, forward and inverse
     transform are bit-identical to the reference's (golden fixture)."""
