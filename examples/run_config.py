@@ -1,0 +1,101 @@
+"""End-to-end runs of the BASELINE.json configurations (SURVEY.md section 8d,
+C1-C5) on one GPU:  python examples/run_config.py C4 [--n-eff 10000]
+
+Prints one JSON line per run: wall time, log Z (and the analytic value where
+one exists), effective sample size, likelihood calls, bounds.  The likelihoods
+are user-side code (torch on the device batch), not part of the product.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from nautilus_amd import (GaussianLikelihood, GaussianMixtureLikelihood,  # noqa
+                          Sampler, unit_prior)
+
+
+def rosenbrock(u):
+    x = 10.0 * u - 5.0
+    return -torch.sum(100.0 * (x[:, 1:] - x[:, :-1]**2)**2 +
+                      (1.0 - x[:, :-1])**2, dim=1)
+
+
+rosenbrock.device = True
+
+
+def funnel(u):
+    # x0 ~ N(0.5, 0.1^2), x_i ~ N(0.5, (exp(20 (x0 - 0.5)) / 100)^2)
+    d = u.shape[1]
+    s = torch.exp(20.0 * (u[:, 0] - 0.5)) / 100.0
+    z0 = (u[:, 0] - 0.5) / 0.1
+    zi = (u[:, 1:] - 0.5) / s[:, None]
+    return (-0.5 * z0**2 - np.log(0.1) - 0.5 * np.log(2 * np.pi) -
+            0.5 * torch.sum(zi**2, dim=1) - (d - 1) * torch.log(s) -
+            0.5 * (d - 1) * np.log(2 * np.pi))
+
+
+funnel.device = True
+
+
+def config(name):
+    if name == 'C1':
+        like = GaussianLikelihood([0.4, 0.5, 0.6], 0.01 * np.eye(3))
+        return dict(like=like, n_dim=3, n_live=1000, n_networks=4,
+                    analytic=-6.4e-5)
+    if name == 'C2':
+        d, s = 20, 0.05
+        cov = s**2 * (0.5 * np.ones((d, d)) + 0.5 * np.eye(d))
+        return dict(like=GaussianLikelihood(np.full(d, 0.5), cov), n_dim=d,
+                    n_live=2000, n_networks=4, analytic=0.0)
+    if name == 'C3':
+        return dict(like=rosenbrock, n_dim=30, n_live=3000, n_networks=4,
+                    analytic=None)
+    if name == 'C4':
+        means = 0.25 + 0.5 * np.random.default_rng(3).random((4, 50))
+        return dict(like=GaussianMixtureLikelihood(means, 0.02), n_dim=50,
+                    n_live=5000, n_networks=4, analytic=0.0)
+    if name == 'C5':
+        return dict(like=funnel, n_dim=100, n_live=10000, n_networks=8,
+                    analytic=None)
+    raise SystemExit('unknown config ' + name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('name')
+    ap.add_argument('--n-eff', type=float, default=10000)
+    ap.add_argument('--n-batch', type=int, default=8192)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--timeout', type=float, default=np.inf)
+    args = ap.parse_args()
+    c = config(args.name)
+    t0 = time.time()
+    s = Sampler(unit_prior, c['like'], n_dim=c['n_dim'], n_live=c['n_live'],
+                n_networks=c['n_networks'], n_batch=args.n_batch,
+                vectorized=True, seed=args.seed)
+    ok = s.run(n_eff=args.n_eff, discard_exploration=True,
+               timeout=args.timeout)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    pts, log_w, _ = s.posterior()
+    w = np.exp(log_w)
+    mean = np.average(pts, weights=w, axis=0)
+    print(json.dumps(dict(
+        config=args.name, finished=bool(ok), wall_s=round(wall, 2),
+        log_z=float(s.log_z), analytic_log_z=c['analytic'],
+        n_eff=float(s.n_eff), n_like=int(s.n_like), n_bounds=len(s.bounds),
+        n_neural_last=len(s.bounds[-1].neural_bounds)
+        if len(s.bounds) > 1 else 0,
+        n_proposals=int(s.n_proposals), mean_first3=mean[:3].round(4).tolist(),
+        timing={k: round(v, 2) for k, v in s.timing.items()})))
+
+
+if __name__ == '__main__':
+    main()

@@ -156,6 +156,58 @@ __device__ __forceinline__ void mlp_layer1(const double* w, int ks_n,
   rem0 = RELU ? fmax(v, 0.0) : v;
 }
 
+// Layer 1 of one tile in two K chunks (n_dim > 64: its weights do not fit one
+// LDS region).  h holds the pre-activations between the chunks; the last
+// chunk applies the ReLU and writes the constant-1 unit (k-step 25, lane
+// group 0) and the zero padding of the partial tile.  w is the chunk in LDS:
+// k-tile index relative to KS_LO / 4.
+template <int KS_LO, int KS_HI, bool FIRST, bool LAST>
+__device__ __forceinline__ void l1_part(const double* w, int ks_n,
+                                        const double* in, int lane,
+                                        double* h) {
+  static_assert(KS_LO % 4 == 0, "chunks start at a k-tile boundary");
+#pragma unroll
+  for (int ht = 0; ht < NB_HT1 - 1; ++ht) {
+    nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    if (!FIRST) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc0[r] = h[4 * ht + r];
+    }
+#pragma unroll
+    for (int ks = KS_LO; ks < KS_HI; ++ks) {
+      if (ks < ks_n) {
+        const int kt = (ks - KS_LO) >> 2, s = ks & 3;
+        const double a = w[(kt * NB_HT1 + ht) * NB_TILE + s * 64 + lane];
+        if (ks & 1) acc1 = MFMA(a, in[ks], acc1);
+        else acc0 = MFMA(a, in[ks], acc0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = acc0[r] + acc1[r];
+      h[4 * ht + r] = LAST ? fmax(v, 0.0) : v;
+    }
+  }
+  double r0 = FIRST ? 0.0 : h[4 * (NB_HT1 - 1)], r1 = 0.0;
+  const int roff = (NB_HT1 - 1) * NB_TILE + (lane >> 4) * 16 + (lane & 3);
+#pragma unroll
+  for (int ks = KS_LO; ks < KS_HI; ++ks) {
+    if (ks < ks_n) {
+      const int kt = (ks - KS_LO) >> 2, s = ks & 3;
+      const double a = w[kt * NB_HT1 * NB_TILE + s * 64 + roff];
+      if (ks & 1) r1 = MFMA4(a, in[ks], r1);
+      else r0 = MFMA4(a, in[ks], r0);
+    }
+  }
+  const double v = r0 + r1;
+  h[4 * (NB_HT1 - 1)] = LAST ? fmax(v, 0.0) : v;
+  if (LAST) {
+    h[4 * (NB_HT1 - 1) + 1] = ((lane >> 4) == 0) ? 1.0 : 0.0;   // unit 100
+    h[4 * (NB_HT1 - 1) + 2] = 0.0;
+    h[4 * (NB_HT1 - 1) + 3] = 0.0;
+  }
+}
+
 // the TPW tiles of a wavefront through one layer (+ the constant-1 unit that
 // feeds the next layer's bias row: k-step ONE_KS, lane group ONE_LG)
 template <int TPW, int KSMAX, int HT, bool RELU, int ONE_KS, int ONE_LG,
@@ -497,41 +549,66 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) total[t] = 0.0;
             if constexpr (DBUF) {
-              // dense path: layer-1 weights live in region A, layers 2-4 in
-              // region B; each region is refilled by DMA while the other one
-              // feeds the matrix cores (two barriers per network)
-              double* reg_a = wlds;
-              double* reg_b = tlds;
+              // dense path: the weights stream through two LDS regions of 38
+              // tiles; while one feeds the matrix cores the other is refilled
+              // by DMA (one barrier per stage).  Stages of a network: layer 1
+              // (two K chunks for n_dim > 64, where it exceeds a region), then
+              // layers 2-4.
+              constexpr bool TWO = (DT >= 5);
+              constexpr int KA = (DT + 2) / 2;          // k-tiles of chunk A
+              constexpr int NST = TWO ? 3 : 2;
+              const int n_a0 = TWO ? KA * NB_HT1 * NB_TILE : n_a;
+              double* reg[2] = {wlds, tlds};
+              double h1[TPW][4 * NB_HT1];
+              auto issue = [&](int e, int st, int q) {
+                const double* w1 = nets + e * net_stride;
+                if (st == 0) dma_weights(w1, reg[q & 1], n_a0, wave, lane);
+                else if (TWO && st == 1)
+                  dma_weights(w1 + n_a0, reg[q & 1], n_a - n_a0, wave, lane);
+                else dma_weights(w1 + n_a, reg[q & 1], n_b, wave, lane);
+              };
               __syncthreads();
-              dma_weights(nets, reg_a, n_a, wave, lane);
+              issue(0, 0, 0);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               __syncthreads();
+              int q = 0;
               for (int e = 0; e < E; ++e) {
-                const double* w1 = nets + e * net_stride;
-                double h1[TPW][4 * NB_HT1];
-                dma_weights(w1 + n_a, reg_b, n_b, wave, lane);
-                if (wave_mlp)
-                  mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
-                      reg_a, ks1, tin, lane, h1, true);          // unit 100
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (e + 1 < E)
-                  dma_weights(w1 + net_stride, reg_a, n_a, wave, lane);
-                if (wave_mlp) {
-                  const double* w2 = reg_b;
-                  const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
-                  const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
-                  double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
-                  mlp_tiles<TPW, 26, NB_HT2, true, 12, 2>(w2, 26, h1, lane, h2,
-                                                          true);   // unit 50
-                  mlp_tiles<TPW, 13, NB_HT3, true, 5, 0>(w3, 13, h2, lane, h3,
-                                                         true);    // unit 20
-                  mlp_tiles<TPW, 6, 1, false, -1, 0>(w4, 6, h3, lane, o, true);
 #pragma unroll
-                  for (int t = 0; t < TPW; ++t) total[t] += o[t][0];
+                for (int st = 0; st < NST; ++st, ++q) {
+                  if (st + 1 < NST) issue(e, st + 1, q + 1);
+                  else if (e + 1 < E) issue(e + 1, 0, q + 1);
+                  const double* cur = reg[q & 1];
+                  if (wave_mlp) {
+                    if (st == 0) {
+                      if constexpr (TWO)
+                        l1_part<0, 4 * KA, true, false>(cur, ks1, tin[0], lane,
+                                                        h1[0]);
+                      else
+                        mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
+                            cur, ks1, tin, lane, h1, true);      // unit 100
+                    } else if (TWO && st == 1) {
+                      if constexpr (TWO)
+                        l1_part<4 * KA, KS1MAX, false, true>(cur, ks1, tin[0],
+                                                             lane, h1[0]);
+                    } else {
+                      const double* w2 = cur;
+                      const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
+                      const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
+                      double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3],
+                          o[TPW][4];
+                      mlp_tiles<TPW, 26, NB_HT2, true, 12, 2>(
+                          w2, 26, h1, lane, h2, true);           // unit 50
+                      mlp_tiles<TPW, 13, NB_HT3, true, 5, 0>(
+                          w3, 13, h2, lane, h3, true);           // unit 20
+                      mlp_tiles<TPW, 6, 1, false, -1, 0>(w4, 6, h3, lane, o,
+                                                         true);
+#pragma unroll
+                      for (int t = 0; t < TPW; ++t) total[t] += o[t][0];
+                    }
+                  }
+                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  __syncthreads();
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
               }
             } else {
               for (int e = 0; e < E; ++e) {
@@ -670,22 +747,26 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
 
 template <int DT>
 int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
-  int lds_tiles = (kt1_max * NB_HT1 > 38) ? kt1_max * NB_HT1 : 38;
-  if (lds_tiles < DT * DT + 1) lds_tiles = DT * DT + 1;   // one ell block
+  // region A: a whole layer 1 (n_dim <= 64) or one of its two K chunks; the
+  // ellipsoid block of large n_dim may extend into region B (it is only
+  // needed while no weights are staged)
+  int lds_tiles = 38;
+  if (DT <= 4 && kt1_max * NB_HT1 > lds_tiles) lds_tiles = kt1_max * NB_HT1;
+  constexpr int ELL_TILES = (2 + 48 * DT + 256 * DT * DT + NB_TILE - 1) / NB_TILE;
+  static_assert(ELL_TILES <= 76, "ellipsoid block must fit the two regions");
+  const int gather_tiles = (lds_tiles > ELL_TILES) ? lds_tiles : ELL_TILES;
   constexpr int TS = 4 * (4 * DT + 1) + 1;
   // gather emulator inputs through LDS when weights + 128 gathered points fit
-  const size_t need = ((size_t)lds_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
+  const size_t need = ((size_t)gather_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
   const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC) &&
                            getenv("NB_EVAL_NO_GATHER") == nullptr;
   // two tiles per wavefront up to n_dim = 64; beyond that the per-lane state
   // (y, standardised input, hidden activations of two tiles) no longer fits
   // the register file
   constexpr int TPW = (DT <= 4) ? 2 : 1;
-  if (sparse_mode && need <= 160 * 1024)
-    return launch_eval_impl<DT, 0, TPW>(a, lds_tiles, stream);
-  if (((size_t)lds_tiles + 38) * NB_TILE * 8 <= 160 * 1024)
-    return launch_eval_impl<DT, 1, TPW>(a, lds_tiles, stream);
-  return launch_eval_impl<DT, 2, TPW>(a, lds_tiles, stream);
+  if (sparse_mode && DT <= 4 && need <= 160 * 1024)
+    return launch_eval_impl<DT, 0, TPW>(a, gather_tiles, stream);
+  return launch_eval_impl<DT, 1, TPW>(a, lds_tiles, stream);
 }
 
 }  // namespace

@@ -126,9 +126,145 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
   }
 }
 
+// Odd n_dim: rows are only 8-byte aligned, so the 16-byte row loads above are
+// not available.  A group of 32 points is still one contiguous, 16-byte
+// aligned block of 32 * D doubles: every wavefront DMAs its block into LDS
+// (global_load_lds, fully coalesced, double buffered -- the next block is in
+// flight while the current one is multiplied) and gathers the B operands
+// from there; an odd row stride spreads the points over the LDS banks.
+typedef const void __attribute__((address_space(1))) * nbs_gptr;
+typedef void __attribute__((address_space(3))) * nbs_lptr;
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
+                         const double* __restrict__ tiles, int n_dim,
+                         const double* __restrict__ x, long long n,
+                         unsigned char* __restrict__ mask, int bufsz) {
+  constexpr int TPW = 2;
+  constexpr int NT = DT * (DT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* wl = lds;
+  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 512)
+    *(double2*)(wl + i) = *(const double2*)(tiles + i);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  double* mybuf = lds + NT * NB_TILE + wave * 2 * bufsz;
+  const int blk = 16 * TPW * n_dim;          // doubles of one group of points
+  const long long total = n * n_dim;
+
+  double cper[4 * DT];
+#pragma unroll
+  for (int j = 0; j < 2 * DT; ++j) {
+    const int f = 8 * j + 2 * lg;
+    cper[2 * j] = cvec[f];
+    cper[2 * j + 1] = cvec[f + 1];
+  }
+
+  const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
+  const long long g0 = (long long)blockIdx.x * 4 + wave;
+  const long long gstep = (long long)gridDim.x * 4;
+  auto issue = [&](long long grp, int b) {
+    const long long base = grp * blk;
+    for (int c = 0; c < blk; c += 128) {
+      long long off = base + c + 2 * lane;
+      if (off + 1 >= total) off = (total - 2) & ~1LL;   // stay inside x
+      __builtin_amdgcn_global_load_lds((nbs_gptr)(x + off),
+                                       (nbs_lptr)(mybuf + b * bufsz + c), 16,
+                                       0, 0);
+    }
+  };
+  if (g0 < n_groups) issue(g0, 0);
+  int b = 0;
+  for (long long grp = g0; grp < n_groups; grp += gstep, b ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (grp + gstep < n_groups) issue(grp + gstep, b ^ 1);
+    const double* buf = mybuf + b * bufsz;
+    double d[TPW][4 * DT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const double* row = buf + (t * 16 + li) * n_dim;
+#pragma unroll
+      for (int j = 0; j < 2 * DT; ++j) {
+        const int f = 8 * j + 2 * lg;
+        const double v0 = row[f < n_dim ? f : 0];
+        const double v1 = row[f + 1 < n_dim ? f + 1 : 0];
+        d[t][2 * j] = (f < n_dim ? v0 : 0.0) - cper[2 * j];
+        d[t][2 * j + 1] = (f + 1 < n_dim ? v1 : 0.0) - cper[2 * j + 1];
+      }
+    }
+    double part[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) part[t] = 0.0;
+#pragma unroll
+    for (int ht = 0; ht < DT; ++ht) {
+      if (16 * ht < n_dim) {
+        nb_d4 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4 * (ht + 1); ++ks) {
+          const int kt = ks >> 2, s4 = ks & 3;
+          const double a =
+              wl[((ht * (ht + 1)) / 2 + kt) * NB_TILE + s4 * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = MFMA(a, d[t][ks], acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[t] = fma(acc[t][r], acc[t][r], part[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      double r2 = part[t];
+      r2 += __shfl_xor(r2, 16);
+      r2 += __shfl_xor(r2, 32);
+      const long long pt = (grp * TPW + t) * 16 + li;
+      if (lg == 0 && pt < n) mask[pt] = (r2 < 1.0) ? 1 : 0;
+    }
+  }
+}
+
+template <int DT>
+int launch_odd(const double* cvec, const double* tiles, int n_dim,
+               const double* x, long long n, unsigned char* mask,
+               hipStream_t stream) {
+  constexpr int NT = DT * (DT + 1) / 2;
+  const int bufsz = (32 * n_dim + 127) & ~127;
+  const size_t lds = ((size_t)NT * NB_TILE + 8 * (size_t)bufsz) * sizeof(double);
+  static size_t allowed = 0;
+  if (lds > allowed) {
+    if (hipFuncSetAttribute((const void*)nb_ell_stream_odd_kernel<DT>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed", lds);
+      return NB_ERR_HIP;
+    }
+    allowed = lds;
+  }
+  (void)hipGetLastError();
+  const long long n_groups = (n + 31) / 32;
+  long long blocks = (n_groups + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((nb_ell_stream_odd_kernel<DT>), dim3((unsigned)blocks),
+                     dim3(256), lds, stream, cvec, tiles, n_dim, x, n, mask,
+                     bufsz);
+  return NB_OK;
+}
+
 template <int DT>
 int launch(const double* cvec, const double* tiles, int n_dim, const double* x,
            long long n, unsigned char* mask, hipStream_t stream) {
+  if constexpr (DT <= 4) {
+    if ((n_dim & 1) && n >= 64)
+      return launch_odd<DT>(cvec, tiles, n_dim, x, n, mask, stream);
+  }
   // 4 tiles per wavefront while the operands fit the register file
   constexpr int TPW = (DT <= 4) ? 4 : 2;
   const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
@@ -150,19 +286,21 @@ int nb_launch_ell_stream(const double* cvec, const double* tiles, int n_dim,
                          hipStream_t stream) {
   if (n <= 0) return NB_OK;
   const int dt = (n_dim + 15) / 16;
+  int rc = NB_OK;
   switch (dt) {
-    case 1: launch<1>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 2: launch<2>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 3: launch<3>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 4: launch<4>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 5: launch<5>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 6: launch<6>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 7: launch<7>(cvec, tiles, n_dim, x, n, mask, stream); break;
-    case 8: launch<8>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 1: rc = launch<1>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 2: rc = launch<2>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 3: rc = launch<3>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 4: rc = launch<4>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 5: rc = launch<5>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 6: rc = launch<6>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 7: rc = launch<7>(cvec, tiles, n_dim, x, n, mask, stream); break;
+    case 8: rc = launch<8>(cvec, tiles, n_dim, x, n, mask, stream); break;
     default:
       nb_set_error("n_dim > 128 unsupported");
       return NB_ERR_UNSUPPORTED;
   }
+  if (rc != NB_OK) return rc;
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;
 }

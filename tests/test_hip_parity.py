@@ -195,6 +195,39 @@ def test_emulator_predict_golden(dev, d, e):
     assert np.allclose(score.cpu().numpy(), g['predict'], rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize('d,e', [(49, 3), (64, 2), (65, 2), (79, 1), (80, 2),
+                                 (96, 1), (100, 8), (127, 2), (128, 1)])
+def test_neural_bound_large_dims(dev, d, e):
+    """Every kernel variant of the emulator evaluation (one / two tiles per
+    wavefront, layer 1 streamed in one or two K chunks): NeuralBound.contains,
+    the score and shell exclusion against the oracle with random networks."""
+    from oracle import bounds_oracle as bo
+    from oracle import mlp_oracle as mo
+    rng = np.random.default_rng(1000 * d + e)
+    nets = [mo.glorot_init(d, i)[:2] for i in range(e)]
+    mean, scale = rng.normal(size=d) * 0.1, rng.uniform(0.5, 1.5, d)
+    emu = mo.Emulator.from_weights(mean, scale, nets)
+    b_mat = np.tril(rng.normal(size=(d, d)) * 0.02) + np.eye(d) * 0.4
+    ell = bo.OEllipsoid.from_params(np.full(d, 0.5), b_mat)
+    nb = bo.ONeural()
+    nb.outer_bound, nb.n_dim, nb.emulator = ell, d, emu
+    x = 0.5 + (rng.normal(size=(3000, d)) @ b_mat.T) * (0.6 / np.sqrt(d))
+    score_o = emu.predict(ell.transform(x))
+    nb.score_predict_min = float(np.median(score_o))
+    b = upload(nb)
+    r2, score = b.neural_score(x)
+    assert np.allclose(score.cpu().numpy(), score_o, rtol=0, atol=1e-10)
+    want = nb.contains(x)
+    got = b.contains(x).cpu().numpy()
+    edge = near_boundary(score_o, nb.score_predict_min - 1e-9, 1e-9)
+    assert np.array_equal(got[~edge], want[~edge])
+    assert 0.2 < want.mean() < 0.8
+    lst = dev.DeviceBoundList([b, upload(ell)])
+    any_o = want | ell.contains(x)
+    assert np.array_equal(lst.contains_any(x).cpu().numpy()[~edge],
+                          any_o[~edge])
+
+
 @pytest.fixture(scope='module')
 def nautilus_d4():
     from helpers import nautilus_from_golden
