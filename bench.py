@@ -54,6 +54,11 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=20.0)
     p.add_argument('--explore-timeout', type=float, default=1500.0)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--host-likelihood', action='store_true',
+                   help='evaluate the likelihood with numpy on the host '
+                        '(points cross PCIe both ways every step): the '
+                        'PCIe-inclusive rate quoted in DESIGN.md, never the '
+                        'headline value')
     p.add_argument('--backend', default='nccl',
                    help="torch.distributed backend ('nccl' = RCCL; 'gloo' "
                         "only for functional tests)")
@@ -201,7 +206,11 @@ def main():
 
     d = args.dim
     like = GaussianLikelihood(np.full(d, 0.5), np.eye(d) * 0.05**2)
-    sampler = Sampler(unit_prior, like, n_dim=d, n_live=args.n_live,
+    like_used = like
+    if args.host_likelihood:
+        def like_used(x_host):             # plain callable -> host path
+            return like.numpy(x_host)
+    sampler = Sampler(unit_prior, like_used, n_dim=d, n_live=args.n_live,
                       n_networks=args.n_networks,
                       n_batch=args.n_batch_setup, vectorized=True,
                       seed=args.seed, comm=comm)
@@ -320,7 +329,9 @@ def main():
                     n_batch_per_gpu=args.n_batch,
                     n_batch_setup=args.n_batch_setup,
                     n_batch_global=args.n_batch * world,
-                    discard_exploration=True, seed=args.seed),
+                    discard_exploration=True, seed=args.seed,
+                    likelihood='host numpy (PCIe inclusive)'
+                    if args.host_likelihood else 'device'),
         log_z=float(sampler.log_z), abs_dlogz=abs(float(sampler.log_z)),
         n_eff=float(n_eff1), n_like=int(n_like1),
         n_bounds=len(sampler.bounds), setup_s=setup_s, shell_fill_s=fill_s,

@@ -527,35 +527,56 @@ class NeuralBound(_DeviceBoundBase):
                 n_networks=4, neural_network_kwargs={}, pool=None, rng=None):
         """``points`` may be a numpy array or a cuda tensor (the sampler keeps
         all points on the device); ``log_l`` is a numpy array."""
-        self = cls()
-        log_l = np.asarray(log_l)
-        x = device.as_device_points(points)
-        self.n_dim = x.shape[1]
-        rng = _default_rng(rng)
-        live = x[torch.from_numpy(log_l >= log_l_min).cuda()].cpu().numpy()
-        self.outer_bound = Ellipsoid.compute(
-            live, enlarge_per_dim=enlarge_per_dim, rng=rng)
-        if n_networks == 0:
-            self.emulator = None
-            self.score_predict_min = 0
-            return self
+        return cls.compute_many([(points, log_l)], log_l_min,
+                                enlarge_per_dim=enlarge_per_dim,
+                                n_networks=n_networks,
+                                neural_network_kwargs=neural_network_kwargs,
+                                rng=rng)[0]
 
-        inside = self.outer_bound.contains_device(x)
-        x_in = x[inside]
-        log_l = log_l[inside.cpu().numpy()]
-        # ellipsoid-frame coordinates on the device (basic.py:340)
-        x_t = transform_device(self.outer_bound, x_in)
-        score = np.zeros(len(log_l))
-        hi = log_l >= log_l_min
-        score[hi] = 0.5 * (1 + (rankdata(log_l[hi]) - 0.5) / np.sum(hi))
-        score[~hi] = 0.5 * ((rankdata(log_l[~hi]) - 0.5) / np.sum(~hi))
-        self.emulator = NeuralNetworkEmulator.train(
-            x_t, score, n_networks=n_networks,
-            neural_network_kwargs=neural_network_kwargs, pool=pool)
-        pred = self.emulator.predict_device(x_t).cpu().numpy()
-        self.score_predict_min = np.polyval(
-            np.polyfit(score, pred, 3), np.amin(score[hi]))
-        return self
+    @classmethod
+    def compute_many(cls, data, log_l_min, enlarge_per_dim=1.1, n_networks=4,
+                     neural_network_kwargs={}, rng=None):
+        """bounds/neural.py:58-97 for several (points, log_l) sets -- the
+        neural bounds of one NautilusBound (nautilus.py:107-114).  The
+        reference trains their emulators one after the other; here all
+        ensembles train side by side on the GPU.  No random numbers are
+        consumed (the networks are seeded 0..n_networks-1, neural.py:88), so
+        the order of the work does not matter."""
+        rng = _default_rng(rng)
+        bounds, train = [], []
+        for points, log_l in data:
+            self = cls()
+            log_l = np.asarray(log_l)
+            x = device.as_device_points(points)
+            self.n_dim = x.shape[1]
+            live = x[torch.from_numpy(log_l >= log_l_min).cuda()].cpu().numpy()
+            self.outer_bound = Ellipsoid.compute(
+                live, enlarge_per_dim=enlarge_per_dim, rng=rng)
+            bounds.append(self)
+            if n_networks == 0:
+                self.emulator = None
+                self.score_predict_min = 0
+                continue
+            inside = self.outer_bound.contains_device(x)
+            log_l = log_l[inside.cpu().numpy()]
+            # ellipsoid-frame coordinates on the device (basic.py:340)
+            x_t = transform_device(self.outer_bound, x[inside])
+            score = np.zeros(len(log_l))
+            hi = log_l >= log_l_min
+            score[hi] = 0.5 * (1 + (rankdata(log_l[hi]) - 0.5) / np.sum(hi))
+            score[~hi] = 0.5 * ((rankdata(log_l[~hi]) - 0.5) / np.sum(~hi))
+            train.append((self, x_t, score, hi))
+        if train:
+            emus = NeuralNetworkEmulator.train_many(
+                [(x_t, score) for _, x_t, score, _ in train],
+                n_networks=n_networks,
+                neural_network_kwargs=neural_network_kwargs)
+            for (self, x_t, score, hi), emu in zip(train, emus):
+                self.emulator = emu
+                pred = emu.predict_device(x_t).cpu().numpy()
+                self.score_predict_min = np.polyval(
+                    np.polyfit(score, pred, 3), np.amin(score[hi]))
+        return bounds
 
     @classmethod
     def from_parts(cls, ellipsoid, emulator, score_predict_min):
@@ -665,14 +686,14 @@ class NautilusBound(_RejectionSampler):
         while multi.split(allow_overlap=False):
             pass
         t1 = time()
-        self.neural_bounds = []
+        data = []
         for ell in multi.bounds:
             sel = ell.contains_device(x)
-            self.neural_bounds.append(NeuralBound.compute(
-                x[sel], log_l[sel.cpu().numpy()], log_l_min,
-                enlarge_per_dim=enlarge_per_dim, n_networks=n_networks,
-                neural_network_kwargs=neural_network_kwargs, pool=pool,
-                rng=self.rng))
+            data.append((x[sel], log_l[sel.cpu().numpy()]))
+        self.neural_bounds = NeuralBound.compute_many(
+            data, log_l_min, enlarge_per_dim=enlarge_per_dim,
+            n_networks=n_networks,
+            neural_network_kwargs=neural_network_kwargs, rng=self.rng)
 
         t2 = time()
         # sampling envelope (:116-133)

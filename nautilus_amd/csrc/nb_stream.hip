@@ -170,11 +170,14 @@ nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
   auto issue = [&](long long grp, int b) {
     const long long base = grp * blk;
     for (int c = 0; c < blk; c += 128) {
-      long long off = base + c + 2 * lane;
-      if (off + 1 >= total) off = (total - 2) & ~1LL;   // stay inside x
-      __builtin_amdgcn_global_load_lds((nbs_gptr)(x + off),
-                                       (nbs_lptr)(mybuf + b * bufsz + c), 16,
-                                       0, 0);
+      const long long off = base + c + 2 * lane;
+      double* dst = mybuf + b * bufsz + c;
+      if (off + 1 < total) {
+        __builtin_amdgcn_global_load_lds((nbs_gptr)(x + off), (nbs_lptr)dst,
+                                         16, 0, 0);
+      } else if (off < total) {
+        dst[2 * lane] = x[off];          // last element of an odd-sized array
+      }
     }
   };
   if (g0 < n_groups) issue(g0, 0);

@@ -166,19 +166,30 @@ class NeuralNetworkEmulator:
         """neural.py:50-98.  ``x`` / ``y`` may be numpy arrays or cuda
         tensors; ``pool`` is accepted for API compatibility (the networks
         train concurrently on the GPU, one workgroup each)."""
-        emu = cls()
-        xt = device.as_device_points(x)
-        yt = (y if isinstance(y, torch.Tensor) else
-              torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64))
-              ).to('cuda', torch.float64).contiguous()
-        mean, scale, xs = device.standardize(xt)         # neural.py:74-77
-        emu.mean = mean.cpu().numpy()
-        emu.scale = scale.cpu().numpy()
+        return cls.train_many([(x, y)], n_networks, neural_network_kwargs)[0]
+
+    @classmethod
+    def train_many(cls, data, n_networks=4, neural_network_kwargs={}):
+        """``train`` for several (x, y) sets at once; the ensembles train
+        concurrently on separate streams."""
         hp = _hparams_from_kwargs(dict(neural_network_kwargs))
-        emu.neural_networks, emu.trainer_stats = train_networks(
-            xs, yt, list(range(n_networks)), hp)
-        emu._dev = None
-        return emu
+        emus, jobs = [], []
+        for x, y in data:
+            emu = cls()
+            xt = device.as_device_points(x)
+            yt = (y if isinstance(y, torch.Tensor) else
+                  torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64))
+                  ).to('cuda', torch.float64).contiguous()
+            mean, scale, xs = device.standardize(xt)     # neural.py:74-77
+            emu.mean = mean.cpu().numpy()
+            emu.scale = scale.cpu().numpy()
+            emu._dev = None
+            emus.append(emu)
+            jobs.append(dict(xs=xs, y=yt, seeds=list(range(n_networks)),
+                             hparams=hp))
+        for emu, (nets, stats) in zip(emus, train_ensembles(jobs)):
+            emu.neural_networks, emu.trainer_stats = nets, stats
+        return emus
 
     @classmethod
     def from_weights(cls, mean, scale, networks):
@@ -213,59 +224,112 @@ class NeuralNetworkEmulator:
         return state
 
 
+class _TrainJob:
+    """One ensemble in flight: its trainer, the per-network shuffle streams
+    and the bookkeeping of the chunked epoch loop."""
+
+    def __init__(self, xs, y, seeds, hparams, permutations, init, max_epochs,
+                 stream):
+        self.n, d = xs.shape
+        self.e = len(seeds)
+        self.stream = stream
+        self.states = [np.random.RandomState(s) for s in seeds]
+        nets0 = [_glorot(d, rs) for rs in self.states]
+        if init is not None:
+            nets0 = init
+        with torch.cuda.stream(stream):
+            self.trainer = Trainer(xs, y, nets0, hparams)
+        self.permutations = permutations
+        self.max_iter = (hparams or {}).get('max_iter', 10000)
+        if max_epochs is not None:
+            self.max_iter = min(self.max_iter, max_epochs)
+        self.orders = [np.arange(self.n) for _ in range(self.e)]
+        self.status = np.zeros(self.e, dtype=int)
+        self.done_epochs = 0
+        self.in_flight = False
+        self.finished = False
+
+    def next_chunk(self):
+        """Shuffles of the next chunk of epochs (host work that overlaps with
+        the GPU training the previous chunk), or None."""
+        chunk = min(EPOCH_CHUNK, self.max_iter - self.done_epochs)
+        if chunk <= 0:
+            return None
+        n, e = self.n, self.e
+        perms = np.zeros((e, chunk, n), dtype=np.int32)
+        for i in range(e):
+            for ep in range(chunk):
+                if self.permutations is not None:
+                    self.orders[i] = np.asarray(
+                        self.permutations[i][self.done_epochs + ep])
+                elif self.status[i] >= 0:
+                    # sklearn.utils.shuffle: permutations compose
+                    # (_multilayer_perceptron.py:700-704)
+                    idx = np.arange(n)
+                    self.states[i].shuffle(idx)
+                    self.orders[i] = self.orders[i][idx]
+                perms[i, ep] = self.orders[i]
+        return perms
+
+    def step(self):
+        """Prepare the next chunk, collect the status of the chunk in flight,
+        enqueue the next one.  Returns False once the ensemble is done."""
+        if self.finished:
+            return False
+        perms = self.next_chunk()
+        with torch.cuda.stream(self.stream):
+            if self.in_flight:
+                self.status = self.trainer.status()
+                self.in_flight = False
+            if perms is None or not np.any(self.status >= 0):
+                self.finished = True
+                return False
+            self.trainer.run(perms, sync=False)
+        self.in_flight = True
+        self.done_epochs += perms.shape[1]
+        return True
+
+    def result(self):
+        networks = []
+        with torch.cuda.stream(self.stream):
+            for i in range(self.e):
+                n_iter = abs(int(self.status[i]))
+                coefs, intercepts = self.trainer.weights(i)
+                networks.append(Network(coefs, intercepts, n_iter,
+                                        self.trainer.loss_curve(i, n_iter)))
+        stats = dict(n_iter=[abs(int(s)) for s in self.status], n_rows=self.n)
+        return networks, stats
+
+
+def train_ensembles(jobs):
+    """Train several ensembles concurrently, one HIP stream each (the neural
+    bounds of a multi-modal NautilusBound: every Adam step is a pair of small
+    launches, so independent ensembles fill the GPU side by side).  ``jobs``:
+    list of dicts with keys xs, y, seeds and optionally hparams,
+    permutations, init, max_epochs."""
+    main = torch.cuda.current_stream()
+    running = []
+    for k, job in enumerate(jobs):
+        stream = main if len(jobs) == 1 else torch.cuda.Stream()
+        stream.wait_stream(main)
+        running.append(_TrainJob(
+            job['xs'], job['y'], job['seeds'], job.get('hparams'),
+            job.get('permutations'), job.get('init'), job.get('max_epochs'),
+            stream))
+    active = list(running)
+    while active:
+        active = [j for j in active if j.step()]
+    out = [j.result() for j in running]
+    for j in running:
+        main.wait_stream(j.stream)
+    return out
+
+
 def train_networks(xs, y, seeds, hparams=None, permutations=None,
                    init=None, max_epochs=None):
     """Train ``len(seeds)`` networks on standardised inputs ``xs`` (cuda
     tensor) concurrently.  ``permutations`` (list over networks of lists of
     per-epoch orders) and ``init`` override the RandomState draws (tests)."""
-    n, d = xs.shape
-    e = len(seeds)
-    states = [np.random.RandomState(s) for s in seeds]
-    nets0 = [_glorot(d, rs) for rs in states]
-    if init is not None:
-        nets0 = init
-    trainer = Trainer(xs, y, nets0, hparams)
-    max_iter = (hparams or {}).get('max_iter', 10000)
-    if max_epochs is not None:
-        max_iter = min(max_iter, max_epochs)
-    orders = [np.arange(n) for _ in range(e)]
-    status = np.zeros(e, dtype=int)
-    done_epochs = 0
-    in_flight = False
-    while True:
-        # the shuffles of the next chunk are drawn on the host while the GPU
-        # is still training on the previous chunk
-        chunk = min(EPOCH_CHUNK, max_iter - done_epochs)
-        perms = None
-        if chunk > 0:
-            perms = np.zeros((e, chunk, n), dtype=np.int32)
-            for i in range(e):
-                for ep in range(chunk):
-                    if permutations is not None:
-                        orders[i] = np.asarray(
-                            permutations[i][done_epochs + ep])
-                    elif status[i] >= 0:
-                        # sklearn.utils.shuffle: permutations compose
-                        # (_multilayer_perceptron.py:700-704)
-                        idx = np.arange(n)
-                        states[i].shuffle(idx)
-                        orders[i] = orders[i][idx]
-                    perms[i, ep] = orders[i]
-        if in_flight:
-            status = trainer.status()
-            in_flight = False
-        if perms is None or not np.any(status >= 0):
-            break
-        trainer.run(perms, sync=False)
-        in_flight = True
-        done_epochs += chunk
-    if in_flight:
-        status = trainer.status()
-    networks = []
-    for i in range(e):
-        n_iter = abs(int(status[i]))
-        coefs, intercepts = trainer.weights(i)
-        networks.append(Network(coefs, intercepts, n_iter,
-                                trainer.loss_curve(i, n_iter)))
-    stats = dict(n_iter=[abs(int(s)) for s in status], n_rows=n)
-    return networks, stats
+    return train_ensembles([dict(xs=xs, y=y, seeds=seeds, hparams=hparams,
+                                 permutations=permutations, init=init,
+                                 max_epochs=max_epochs)])[0]

@@ -84,6 +84,31 @@ def test_ellipsoid_stream_large(dev):
         assert torch.equal(b.contains_stream(x[:k]), m1[:k])
 
 
+@pytest.mark.parametrize('d', [1, 7, 33, 49, 63, 65, 127])
+def test_ellipsoid_stream_odd_dims(dev, d):
+    """Odd n_dim (rows only 8-byte aligned): the DMA-staged streaming kernel
+    (n_dim <= 63) and the scalar-load path above it against the oracle, for
+    sizes around the 32-point groups and the end of the array."""
+    import torch
+    from oracle import bounds_oracle as bo
+    rng = np.random.default_rng(d)
+    b_mat = np.tril(rng.normal(size=(d, d)) * 0.05) + np.eye(d) * 0.5
+    ell = bo.OEllipsoid.from_params(np.full(d, 0.5), b_mat)
+    b = upload(ell)
+    n = 70001
+    x = 0.5 + (rng.normal(size=(n, d)) @ b_mat.T) / np.sqrt(d + 2.0)
+    r2 = np.sum(ell.transform(x)**2, axis=-1)
+    want = r2 < 1
+    xt = torch.from_numpy(x).cuda()
+    full = b.contains_stream(xt).cpu().numpy()
+    edge = near_boundary(r2, 1.0, TOL)
+    assert np.array_equal(full[~edge], want[~edge])
+    assert 0.05 < want.mean() < 0.98
+    for k in (1, 31, 32, 33, 63, 64, 65, 127, 4096, 4097, 69999):
+        part = b.contains_stream(xt[:k]).cpu().numpy()
+        assert np.array_equal(part, full[:k]), k
+
+
 def test_mixture_contains_golden(dev):
     from oracle import bounds_oracle as bo
     g = load_golden('mixture_D6')
