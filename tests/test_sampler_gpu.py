@@ -436,3 +436,76 @@ def test_deprecated_accessors():
         assert s.asymptotic_sampling_efficiency() == s.eta
     with pytest.raises(ValueError):
         s.posterior(return_blobs=True)
+
+
+def _sphere_cloud(seed=0, n=1000, d=3):
+    rng = np.random.RandomState(seed)
+    pts = rng.normal(size=(n, d))
+    pts /= np.sqrt(np.sum(pts**2, axis=1))[:, None]
+    return pts * rng.uniform(size=n)[:, None]**(1.0 / d)
+
+
+def test_union_split_trim_and_rng_like_reference():
+    """tests/test_bounds.py:209-295 of the reference: splitting stops with
+    enough points per member, trimming drops the low-density ellipsoid, equal
+    generators give equal draws."""
+    from nautilus_amd import Union
+    x = np.linspace(-1, 1, 30)
+    arc = Union.compute(np.vstack([x, x**2]).T)
+    n = 0
+    while arc.split():
+        n += 1
+    assert n > 0
+    assert min(len(p) for p in arc.points_bounds) >= arc.n_points_min
+
+    sph = _sphere_cloud()
+    far = np.vstack([sph, sph + 10, sph[:30] + 1e7])
+    u = Union.compute(far, unit=False, n_points_min=50,
+                      rng=np.random.default_rng(0))
+    assert u.log_v > 15
+    assert u.split() and u.split()
+    assert u.log_v > 15
+    assert u.trim()
+    assert u.log_v < 5
+    assert not u.trim()
+
+    def fresh(seed):
+        v = Union.compute(sph, unit=False, rng=np.random.default_rng(seed))
+        v.split()
+        return v
+    a, same, other = fresh(0), fresh(0), fresh(1)
+    pts = a.sample(100)
+    assert np.array_equal(pts, same.sample(100))
+    assert not np.array_equal(pts, other.sample(100))
+    assert not np.array_equal(pts, a.sample(100))
+
+    tight = Union.compute(sph + 50, enlarge_per_dim=1.0, unit=False,
+                          rng=np.random.default_rng(0))
+    for _ in range(4):
+        tight.split()
+    inner = tight.sample(100)
+    assert inner.shape == (100, 3) and np.all(tight.contains(inner))
+    wide = Union.compute(inner, enlarge_per_dim=1.1, unit=False,
+                         rng=np.random.default_rng(0))
+    assert not np.all(tight.contains(wide.sample(100)))
+
+
+def test_nautilus_bound_gaussian_shell():
+    """tests/test_bounds.py:352-378: a thin ring in two dimensions."""
+    from nautilus_amd import NautilusBound
+    radius, width = 0.45, 0.01
+    rng = np.random.RandomState(0)
+    pts = rng.random_sample((10000, 2))
+
+    def ring(p):
+        return -((np.linalg.norm(p - 0.5, axis=1) - radius) / width)**2
+    log_l = ring(pts)
+    keep = log_l > -100
+    target = np.log(2 * np.pi * radius * width * 2)
+    b = NautilusBound.compute(pts[keep], log_l[keep], -1, target,
+                              split_threshold=1, n_networks=1,
+                              rng=np.random.default_rng(0))
+    drawn = b.sample(10000)
+    assert np.isclose(b.log_v, target, rtol=0, atol=np.log(2))
+    assert np.mean(ring(drawn) > -1) > 0.5
+    assert b.n_net == 1
