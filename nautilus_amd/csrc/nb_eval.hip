@@ -252,18 +252,20 @@ __device__ __forceinline__ void mlp_tiles(const double* w, int ks_n,
 // data is complete after s_waitcnt vmcnt(0) + workgroup barrier
 typedef const void __attribute__((address_space(1))) * nb_gptr;
 typedef void __attribute__((address_space(3))) * nb_lptr;
+template <int NW>
 __device__ __forceinline__ void dma_weights(const double* __restrict__ src,
                                             double* dst, int n_doubles,
                                             int wave, int lane) {
-  for (int c = wave * 128; c < n_doubles; c += 4 * 128)
+  for (int c = wave * 128; c < n_doubles; c += NW * 128)
     __builtin_amdgcn_global_load_lds((nb_gptr)(src + c + 2 * lane),
                                      (nb_lptr)(dst + c), 16, 0, 0);
 }
 
 // cooperative global -> LDS copy by the whole workgroup (16 bytes per lane)
+template <int NW>
 __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
                                               double* dst, int n_doubles) {
-  for (int i = 2 * threadIdx.x; i < n_doubles; i += 2 * 256) {
+  for (int i = 2 * threadIdx.x; i < n_doubles; i += 2 * 64 * NW) {
     const double2 v = *(const double2*)(src + i);
     *(double2*)(dst + i) = v;
   }
@@ -273,8 +275,11 @@ __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
 // into dense 16-point tiles through LDS before the MLP (shell exclusion and
 // association only need it for a minority of the points; without the
 // gather a wavefront evaluates all 32 of its points if one needs it).
-template <int DT, int VARIANT, int TPW>   // VARIANT 0 gather, 1 dense + DMA
-__global__ void __launch_bounds__(256)   // double buffer, 2 dense
+// VARIANT 0 gather, 1 dense + DMA double buffer.  NW wavefronts x TPW tiles =
+// 128 points per workgroup pass: 4 x 2 (every A operand feeds two tiles) or
+// 8 x 1 (two wavefronts per SIMD hide each other's LDS and barrier waits).
+template <int DT, int VARIANT, int TPW, int NW>
+__global__ void __launch_bounds__(64 * NW)
 nb_eval_kernel(EvalArgs a, int w_doubles) {
   constexpr bool COMPACT = (VARIANT == 0);
   constexpr bool DBUF = (VARIANT == 1);
@@ -282,13 +287,13 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   constexpr int KS1MAX = 4 * DT + 1;
   constexpr int TS = 4 * KS1MAX + 1;        // LDS row stride of a gathered point
   extern __shared__ __attribute__((aligned(16))) double wlds[];
-  __shared__ int wcnt[4];
+  __shared__ int wcnt[NW];
   double* tlds = wlds + w_doubles;          // [128][TS] gathered inputs
   double* slds = tlds + 128 * TS;           // [128] scores
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = lane >> 4;
-  const long long n_super = (a.n + 16 * 4 * TPW - 1) / (16 * 4 * TPW);
+  const long long n_super = (a.n + 16 * NW * TPW - 1) / (16 * NW * TPW);
   unsigned long long cnt_outer = 0, cnt_ell = 0, cnt_mlp = 0;
 
   const double* blob0 = a.blobs[0];
@@ -300,7 +305,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
     bool valid[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      pt[t] = ((sup * 4 + wave) * TPW + t) * 16 + (lane & 15);
+      pt[t] = ((sup * NW + wave) * TPW + t) * 16 + (lane & 15);
       valid[t] = pt[t] < a.n;
     }
 
@@ -399,7 +404,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           // the member's limits, centre and B_inv tiles are staged in LDS and
           // shared by the 8 tiles of the workgroup
           __syncthreads();
-          stage_weights(mblk + m * ell_stride, wlds, nb_ell_block_size(DT));
+          stage_weights<NW>(mblk + m * ell_stride, wlds, nb_ell_block_size(DT));
           __syncthreads();
           ell_eval<DT, TPW>(wlds, n_dim, xin, lane, y, box_bad, r2);
 #pragma unroll
@@ -450,7 +455,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             double xin[TPW][4 * DT];
             load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
             __syncthreads();
-            stage_weights(nb_m, wlds, nb_ell_block_size(DT));
+            stage_weights<NW>(nb_m, wlds, nb_ell_block_size(DT));
             __syncthreads();
             ell_eval<DT, TPW>(wlds, n_dim, xin, lane, y, box_bad, r2);
           }
@@ -487,7 +492,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           __syncthreads();
           int base = 0, n_need = 0;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) {
+          for (int w = 0; w < NW; ++w) {
             if (w < wave) base += wcnt[w];
             n_need += wcnt[w];
           }
@@ -534,7 +539,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               const int n_ct = (n_need + 15) >> 4;     // dense tiles
 #pragma unroll
               for (int t = 0; t < TPW; ++t) {
-                const int q = wave + 4 * t;
+                const int q = wave + NW * t;
                 const int slot = 16 * q + (lane & 15);
                 const bool on = q < n_ct && slot < n_need;
 #pragma unroll
@@ -542,7 +547,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                   tin[t][ks] = on ? tlds[slot * TS + 4 * ks + lg] : 0.0;
               }
               wave_mlp = wave < n_ct;
-              two_tiles = wave + 4 < n_ct;
+              two_tiles = wave + NW < n_ct;
             }
 
             double total[TPW];
@@ -562,10 +567,10 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               double h1[TPW][4 * NB_HT1];
               auto issue = [&](int e, int st, int q) {
                 const double* w1 = nets + e * net_stride;
-                if (st == 0) dma_weights(w1, reg[q & 1], n_a0, wave, lane);
+                if (st == 0) dma_weights<NW>(w1, reg[q & 1], n_a0, wave, lane);
                 else if (TWO && st == 1)
-                  dma_weights(w1 + n_a0, reg[q & 1], n_a - n_a0, wave, lane);
-                else dma_weights(w1 + n_a, reg[q & 1], n_b, wave, lane);
+                  dma_weights<NW>(w1 + n_a0, reg[q & 1], n_a - n_a0, wave, lane);
+                else dma_weights<NW>(w1 + n_a, reg[q & 1], n_b, wave, lane);
               };
               __syncthreads();
               issue(0, 0, 0);
@@ -615,13 +620,13 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                 const double* w1 = nets + e * net_stride;
                 double h1[TPW][4 * NB_HT1];
                 __syncthreads();                       // LDS free
-                stage_weights(w1, wlds, n_a);
+                stage_weights<NW>(w1, wlds, n_a);
                 __syncthreads();
                 if (wave_mlp)
                   mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
                       wlds, ks1, tin, lane, h1, two_tiles);
                 __syncthreads();
-                stage_weights(w1 + n_a, wlds, n_b);
+                stage_weights<NW>(w1 + n_a, wlds, n_b);
                 __syncthreads();
                 if (wave_mlp) {
                   const double* w2 = wlds;
@@ -645,7 +650,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               // scatter the scores back to the owners of the points
 #pragma unroll
               for (int t = 0; t < TPW; ++t)
-                if (lg == 0) slds[16 * (wave + 4 * t) + (lane & 15)] = total[t];
+                if (lg == 0) slds[16 * (wave + NW * t) + (lane & 15)] = total[t];
               __syncthreads();
 #pragma unroll
               for (int t = 0; t < TPW; ++t) {
@@ -710,7 +715,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   }
 }
 
-template <int DT, int VARIANT, int TPW>
+template <int DT, int VARIANT, int TPW, int NW>
 int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   constexpr bool COMPACT = (VARIANT == 0);
   constexpr int TS = 4 * (4 * DT + 1) + 1;
@@ -724,7 +729,7 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_kernel<DT, VARIANT, TPW>,
+        (const void*)nb_eval_kernel<DT, VARIANT, TPW, NW>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -734,14 +739,15 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
     lds_allowed = lds;
   }
   (void)hipGetLastError();
-  const long long n_super = (a.n + 16 * 4 * TPW - 1) / (16 * 4 * TPW);
+  const long long n_super = (a.n + 16 * NW * TPW - 1) / (16 * NW * TPW);
   // the kernel uses the whole register file (one wave per SIMD): one
   // workgroup per CU, grid-stride over the 128-point super tiles
   long long blocks = n_super;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT, TPW>), dim3((unsigned)blocks),
-                     dim3(256), lds, stream, a, w_doubles);
+  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT, TPW, NW>),
+                     dim3((unsigned)blocks), dim3(64 * NW), lds, stream, a,
+                     w_doubles);
   return NB_OK;
 }
 
@@ -765,8 +771,10 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   // the register file
   constexpr int TPW = (DT <= 4) ? 2 : 1;
   if (sparse_mode && DT <= 4 && need <= 160 * 1024)
-    return launch_eval_impl<DT, 0, TPW>(a, gather_tiles, stream);
-  return launch_eval_impl<DT, 1, TPW>(a, lds_tiles, stream);
+    return launch_eval_impl<DT, 0, TPW, 4>(a, gather_tiles, stream);
+  // (8 wavefronts x 1 tile was measured as well: +7 % at D = 20, -2 % at
+  // D = 50, where the 256-register budget per wavefront forces ~100 spills)
+  return launch_eval_impl<DT, 1, TPW, 4>(a, lds_tiles, stream);
 }
 
 }  // namespace
