@@ -355,8 +355,12 @@ __global__ void nb_philox_kernel(unsigned long long seed,
   u[2 * i + 1] = u1;
 }
 
-// back-to-back fp64 MFMA issue-rate probe (4 independent accumulators)
-__global__ void __launch_bounds__(256)
+// back-to-back fp64 MFMA issue-rate probe (4 independent accumulators).  The
+// register budget of a 1024-thread block keeps the accumulators in ordinary
+// VGPRs; with a larger budget the compiler moves them to AGPRs and copies all
+// of them in and out on every loop trip, which measures the copies (47
+// instead of 77 TFLOP/s).
+__global__ void __launch_bounds__(1024)
 nb_mfma_peak_kernel(int iters, double* sink) {
   nb_d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
   double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
@@ -442,8 +446,10 @@ int nb_run_mfma_peak(int iters, double* tflops) {
   NB_HIP_CHECK(hipEventCreate(&e0));
   NB_HIP_CHECK(hipEventCreate(&e1));
   const int blocks = 256 * 4;   // 4 workgroups of 4 waves per CU
-  hipLaunchKernelGGL(nb_mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, 16,
-                     sink);
+  // warm-up long enough for the clocks to leave their idle state (a short
+  // probe right after an idle period reads ~48 instead of ~77 TFLOP/s)
+  hipLaunchKernelGGL(nb_mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0,
+                     iters > 20000 ? iters : 20000, sink);
   NB_HIP_CHECK(hipEventRecord(e0, 0));
   hipLaunchKernelGGL(nb_mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters,
                      sink);
