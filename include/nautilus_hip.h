@@ -241,6 +241,14 @@ int nb_standardize(const double* x_dev, int64_t n, int32_t n_dim,
                    double* mean_dev, double* scale_dev, double* out_dev,
                    void* stream);
 
+/* Prior.unit_to_physical (prior.py:85-120), x = dist.isf(1 - u), for
+ * parameters with uniform (kind 0) or normal (kind 1) distributions;
+ * kind / loc / scale are host arrays of length n_dim (scipy's loc / scale).
+ * Keeps the physical points of a device likelihood on the GPU.               */
+int nb_prior_transform(const double* u_dev, int64_t n, int32_t n_dim,
+                       const uint8_t* kind, const double* loc,
+                       const double* scale, double* out_dev, void* stream);
+
 /* The mixture fit of Union.split (bounds/union.py:185-187): scikit-learn's
  * GaussianMixture(n_components=2, n_init=n_init, covariance_type='full')
  * restated on the device -- k-means++ / Lloyd initialisation, EM until the

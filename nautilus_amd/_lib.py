@@ -102,6 +102,9 @@ _SIGNATURES = {
                                          C.c_void_p, C.c_void_p]),
     'nb_standardize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nb_prior_transform': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
+                                     C.c_void_p, c_double_p, c_double_p,
+                                     C.c_void_p, C.c_void_p]),
     'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
     'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
     'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

@@ -40,6 +40,9 @@ int nb_launch_transform(const double* ell_block, int dt, int n_dim,
                         hipStream_t stream);
 int nb_launch_standardize(const double* x, long long n, int d, double* mean,
                           double* scale, double* out, hipStream_t stream);
+int nb_launch_prior(const double* u, long long n, int d,
+                    const unsigned char* kind, const double* loc,
+                    const double* scale, double* out, hipStream_t stream);
 long long nb_gmm_out_stride_impl(int d);
 long long nb_gmm_scratch_stride_impl(long long n, int d);
 int nb_launch_gmm(const double* x, long long n, int d, int n_init,
@@ -607,6 +610,22 @@ int nb_standardize(const double* x, int64_t n, int32_t n_dim, double* mean,
   }
   return nb_launch_standardize(x, n, n_dim, mean, scale, out,
                                as_stream(stream));
+}
+
+int nb_prior_transform(const double* u, int64_t n, int32_t n_dim,
+                       const uint8_t* kind, const double* loc,
+                       const double* scale, double* out, void* stream) {
+  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT || kind == nullptr ||
+      loc == nullptr || scale == nullptr || (n > 0 && (!u || !out))) {
+    nb_set_error("bad prior transform arguments");
+    return NB_ERR_ARG;
+  }
+  for (int j = 0; j < n_dim; ++j)
+    if (kind[j] > 1) {
+      nb_set_error("prior kind %d of parameter %d is not supported", kind[j], j);
+      return NB_ERR_UNSUPPORTED;
+    }
+  return nb_launch_prior(u, n, n_dim, kind, loc, scale, out, as_stream(stream));
 }
 
 int64_t nb_gmm_out_doubles(int32_t n_dim) {

@@ -78,7 +78,49 @@ nb_standardize_kernel(const double* __restrict__ x, long long total, int d,
   }
 }
 
+// Prior.unit_to_physical (reference nautilus/prior.py:85-120: x_j =
+// dist_j.isf(1 - u_j)) for the two distribution families that cover flat and
+// Gaussian priors, evaluated with scipy's formulas:
+//   uniform(loc, scale).isf(q) = (1 - q) * scale + loc
+//   norm(loc, scale).isf(q)    = -ndtri(q) * scale + loc
+struct PriorArgs {
+  double p0[16 * NB_MAX_DT], p1[16 * NB_MAX_DT];
+  unsigned char kind[16 * NB_MAX_DT];     // 0 uniform, 1 normal
+};
+
+__global__ void __launch_bounds__(256)
+nb_prior_kernel(const double* __restrict__ u, long long total, int d,
+                PriorArgs a, double* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+       e < total; e += stride) {
+    const int col = (int)(e % d);
+    const double q = 1.0 - u[e];
+    const double z = a.kind[col] ? -normcdfinv(q) : 1.0 - q;
+    out[e] = z * a.p1[col] + a.p0[col];
+  }
+}
+
 }  // namespace
+
+int nb_launch_prior(const double* u, long long n, int d,
+                    const unsigned char* kind, const double* loc,
+                    const double* scale, double* out, hipStream_t stream) {
+  if (n <= 0) return NB_OK;
+  PriorArgs a;
+  for (int j = 0; j < 16 * NB_MAX_DT; ++j) {
+    a.kind[j] = j < d ? kind[j] : 0;
+    a.p0[j] = j < d ? loc[j] : 0.0;
+    a.p1[j] = j < d ? scale[j] : 1.0;
+  }
+  const long long total = n * d;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nb_prior_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     stream, u, total, d, a, out);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
 
 int nb_launch_transform(const double* ell_block, int dt, int n_dim,
                         const double* x, long long n, double* y,

@@ -279,6 +279,21 @@ def standardize(x):
     return mean, scale, out
 
 
+def prior_transform(u, kind, loc, scale):
+    """x = dist.isf(1 - u) column by column (reference prior.py:85-120) for
+    uniform (kind 0) / normal (kind 1) parameters -- ``nb_prior_transform``."""
+    lib = _lib.load()
+    u = as_device_points(u)
+    n, d = u.shape
+    out = torch.empty_like(u)
+    kind = np.ascontiguousarray(kind, dtype=np.uint8)
+    loc, scale = _f64(loc), _f64(scale)
+    _lib.check(lib.nb_prior_transform(
+        _ptr(u), n, d, kind.ctypes.data_as(C.c_void_p), _dp(loc), _dp(scale),
+        _ptr(out), _stream()))
+    return out
+
+
 GMM_MAX_DIM = 63
 
 

@@ -1,6 +1,8 @@
 """Prior helper with the interface of ``nautilus.Prior`` (reference
-nautilus/prior.py:9-181).  Host-side and elementwise; out of the GPU hot path
-(SURVEY.md section 2.1)."""
+nautilus/prior.py:9-181).  Numpy points are transformed on the host exactly as
+in the reference; cuda tensors (the batches of a device likelihood) are
+transformed on the GPU when every free parameter is uniform or normal
+(``nb_prior_transform``)."""
 
 import numbers
 
@@ -55,8 +57,44 @@ class Prior:
         if self.dimensionality() != arr.shape[-1]:
             raise ValueError('Dimensionality of points does not match prior.')
 
+    def device_spec(self):
+        """(kind, loc, scale) arrays if every free parameter is a frozen scipy
+        ``uniform`` (kind 0) or ``norm`` (kind 1), else None."""
+        kind, loc, scale = [], [], []
+        for dist in self.dists:
+            if not _is_free(dist):
+                continue
+            name = getattr(getattr(dist, 'dist', None), 'name', None)
+            if name not in ('uniform', 'norm'):
+                return None
+            try:
+                _, lo, sc = dist.dist._parse_args(*dist.args, **dist.kwds)
+            except Exception:
+                return None
+            kind.append(0 if name == 'uniform' else 1)
+            loc.append(float(lo))
+            scale.append(float(sc))
+        return np.array(kind, np.uint8), np.array(loc), np.array(scale)
+
+    @property
+    def device(self):
+        """True if batches can be transformed on the GPU."""
+        return self.device_spec() is not None
+
     def unit_to_physical(self, points):
         """Inverse-survival transform per free parameter (prior.py:85-120)."""
+        import torch
+        if isinstance(points, torch.Tensor):
+            from . import device
+            spec = self.device_spec()
+            if spec is None:
+                raise ValueError(
+                    'only uniform and normal parameters can be transformed '
+                    'on the device')
+            if self.dimensionality() != points.shape[-1]:
+                raise ValueError('Dimensionality of points does not match '
+                                 'prior.')
+            return device.prior_transform(points, *spec)
         points = np.asarray(points)
         self._check(points)
         out = np.zeros_like(points)
@@ -68,7 +106,21 @@ class Prior:
         return out
 
     def physical_to_dictionary(self, phys_points):
-        """prior.py:122-162."""
+        """prior.py:122-162 (numpy arrays or cuda tensors)."""
+        import torch
+        if isinstance(phys_points, torch.Tensor):
+            out = {}
+            col = 0
+            for key, dist in zip(self.keys, self.dists):
+                if _is_free(dist):
+                    out[key] = phys_points[..., col]
+                    col += 1
+                elif isinstance(dist, numbers.Number):
+                    out[key] = torch.full_like(phys_points[..., 0], dist)
+            for key, dist in zip(self.keys, self.dists):
+                if isinstance(dist, str):
+                    out[key] = out[dist]
+            return out
         phys_points = np.asarray(phys_points)
         self._check(phys_points)
         out = {}

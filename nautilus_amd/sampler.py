@@ -476,8 +476,13 @@ class Sampler:
         returns (log_l numpy, log_l cuda tensor, blobs or None)."""
         if self._device_likelihood:
             args = points
-            if callable(self.prior) and not self._prior_is_identity:
-                args = self.prior(points)
+            if callable(self.prior):
+                if not self._prior_is_identity:
+                    args = self.prior(points)
+            elif self.pass_dict:
+                args = self.prior.unit_to_dictionary(points)
+            else:
+                args = self.prior.unit_to_physical(points)
             ll = self.likelihood(args)
             if isinstance(ll, tuple):
                 raise NotImplementedError(

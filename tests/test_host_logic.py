@@ -195,3 +195,21 @@ def test_shell_batch_prefix_rule_is_negative_binomial():
         csum = np.cumsum(keep)
         used = int(np.searchsorted(csum, need)) + 1
         assert used == n_bound
+
+
+def test_prior_device_spec():
+    """Which priors can be transformed on the GPU (row f4): uniform / normal
+    parameters, fixed and tied parameters are passed through."""
+    from scipy.stats import expon
+    from nautilus_amd import Prior
+    p = Prior()
+    p.add_parameter('a', dist=(-3, 5))
+    p.add_parameter('b', dist=norm(loc=2.0, scale=0.5))
+    p.add_parameter('c', dist=1.5)
+    p.add_parameter('d', dist='a')
+    kind, loc, scale = p.device_spec()
+    assert kind.tolist() == [0, 1]
+    assert np.allclose(loc, [-3, 2.0]) and np.allclose(scale, [8, 0.5])
+    assert p.device
+    p.add_parameter('e', dist=expon())
+    assert p.device_spec() is None and not p.device
