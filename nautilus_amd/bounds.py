@@ -98,7 +98,26 @@ class _Fifo:
         self.head = 0
 
 
-class _DeviceBoundBase:
+class _Persistent:
+    """``write`` / ``read`` / ``update`` of the reference's bounds (HDF5 groups
+    in the reference's layout; implemented in io.py)."""
+
+    def write(self, group):
+        from . import io
+        io.write_bound(self, group)
+
+    def update(self, group):
+        from . import io
+        io.update_bound(self, group)
+
+    @classmethod
+    def read(cls, group, rng=None):
+        from . import io
+        return io.read_bound(cls, group, rng) if cls is not PhaseShift \
+            else io.read_bound(cls, group)
+
+
+class _DeviceBoundBase(_Persistent):
     """Shared contains / upload plumbing."""
 
     _dev = None
@@ -603,7 +622,7 @@ class NeuralBound(_DeviceBoundBase):
         return _to_numpy_mask(self.contains_device(pts), points)
 
 
-class PhaseShift:
+class PhaseShift(_Persistent):
     """Recentring of periodic dimensions (reference bounds/periodic.py:6-72):
     the largest gap between the points of a periodic dimension is moved onto
     the boundary of the unit interval."""

@@ -23,6 +23,7 @@ callable is evaluated on the host exactly like in the reference, including
 ``vectorized`` / ``pass_dict`` / ``pool`` handling.
 """
 
+import os
 import warnings
 from functools import partial
 from time import time
@@ -86,9 +87,8 @@ class Sampler:
                  pool=None, seed=None, blobs_dtype=None, filepath=None,
                  resume=True, comm=None):
         if filepath is not None:
-            raise NotImplementedError(
-                'checkpointing is not part of the device path yet '
-                '(SURVEY.md section 8 row f3)')
+            from . import io
+            io.h5py()          # ImportError now rather than at the first write
 
         self._device_likelihood = bool(getattr(likelihood, 'device', False))
         self._prior_is_identity = getattr(prior, '__name__', '') == \
@@ -182,6 +182,10 @@ class Sampler:
         self.timing = dict(add_bound=0.0, sample_shell=0.0, likelihood=0.0,
                            bookkeeping=0.0)
         self.n_proposals = 0     # raw proposal evaluations (outer draws)
+        self.filepath = filepath
+        if resume and filepath is not None and os.path.exists(filepath):
+            from . import io
+            io.read_sampler(self, filepath)     # sampler.py:330-371
 
     # ------------------------------------------------------------------
     # pickling (the reference's sampler is picklable; device handles and
@@ -333,15 +337,29 @@ class Sampler:
                     self.add_bound(verbose=verbose)
                     self.n_update_iter = 0
                     self.n_like_iter = 0
+                    if self.filepath is not None:
+                        self.write(self.filepath, overwrite=True)
                 self.n_update_iter += self.add_samples(-1, verbose=verbose)
                 self.n_like_iter += self.n_batch
+                if self.filepath is not None:
+                    # the complete file after the first batch (:449-453)
+                    if self.n_like == self.n_batch:
+                        self.write(self.filepath, overwrite=True)
+                    self.write_shell_update(self.filepath, -1)
                 if self.f_live <= f_live:
                     self._finish_exploration(discard_exploration)
+                    if self.filepath is not None:
+                        self.write(self.filepath, overwrite=True)
             elif np.any(self.shell_n < n_shell):
-                self.add_samples(int(np.flatnonzero(self.shell_n < n_shell)[0]),
-                                 verbose=verbose)
+                shell = int(np.flatnonzero(self.shell_n < n_shell)[0])
+                self.add_samples(shell, verbose=verbose)
+                if self.filepath is not None:
+                    self.write_shell_update(self.filepath, shell)
             elif self.n_eff < n_eff:
-                self.add_samples(self._next_shell(), verbose=verbose)
+                shell = self._next_shell()
+                self.add_samples(shell, verbose=verbose)
+                if self.filepath is not None:
+                    self.write_shell_update(self.filepath, shell)
             done = finished()
         if verbose:
             self.print_status('Finished' if done else 'Stopped')
@@ -791,6 +809,17 @@ class Sampler:
         if return_blobs:
             return pts, log_w - logsumexp(log_w), log_l, blobs
         return pts, log_w - logsumexp(log_w), log_l
+
+    def write(self, filepath, overwrite=False):
+        """Write the sampler to an HDF5 file in the reference's layout
+        (sampler.py:1253-1332)."""
+        from . import io
+        io.write_sampler(self, filepath, overwrite=overwrite)
+
+    def write_shell_update(self, filepath, shell):
+        """sampler.py:1334-1377."""
+        from . import io
+        io.write_shell_update(self, filepath, shell)
 
     def shell_bound_occupation(self, fractional=True):
         """sampler.py:1223-1251."""

@@ -166,7 +166,7 @@ def test_sampler_argument_errors():
         Sampler(lambda x: x, like)                       # n_dim missing
     with pytest.raises(ValueError):
         Sampler(lambda x: x, like, n_dim=1)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ImportError):                     # no h5py here
         Sampler(lambda x: x, like, n_dim=2, filepath='x.hdf5')
     dev_like = GaussianLikelihood(np.zeros(2) + 0.5, np.eye(2) * 0.01)
     with pytest.raises(ValueError):
