@@ -762,10 +762,14 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   static_assert(ELL_TILES <= 76, "ellipsoid block must fit the two regions");
   const int gather_tiles = (lds_tiles > ELL_TILES) ? lds_tiles : ELL_TILES;
   constexpr int TS = 4 * (4 * DT + 1) + 1;
-  // gather emulator inputs through LDS when weights + 128 gathered points fit
+  // Gathered variant (emulator inputs compacted through LDS): pays off when
+  // only a small minority of a workgroup's points reaches an emulator.  In
+  // the benchmark's shell exclusion the dense variant with its overlapped
+  // weight streaming is 3 % faster end to end, so it is the default;
+  // NB_EVAL_GATHER=1 selects the gathered kernel for the sparse modes.
   const size_t need = ((size_t)gather_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
   const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC) &&
-                           getenv("NB_EVAL_NO_GATHER") == nullptr;
+                           getenv("NB_EVAL_GATHER") != nullptr;
   // two tiles per wavefront up to n_dim = 64; beyond that the per-lane state
   // (y, standardised input, hidden activations of two tiles) no longer fits
   // the register file
