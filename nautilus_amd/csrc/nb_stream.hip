@@ -27,7 +27,76 @@
 
 namespace {
 
-template <int DT, int TPW>
+// |B_inv (x - c)|^2 contributions of one group of TPW tiles: d holds the
+// centred inputs in the permuted K order.  Work is trimmed to the real
+// dimension: k-steps beyond ceil(n_dim / 4) hold only zero padding and are
+// skipped, and a last row tile with at most 4 real rows (n_dim mod 16 in
+// 1..4, e.g. D = 50 or 20) runs on v_mfma_f64_4x4x4_4b_f64 -- 16 instead of 64
+// cycles per k-step (A lane i + 4b + 16k, B lane p + 16k, D lane p + 16i; the
+// A operand is gathered from the same tile storage).  At D = 50 that removes
+// a third of the matrix cycles of a kernel that sits at the ridge between
+// the HBM and the fp64 MFMA roof.
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+
+// KL = number of k-steps that hold real features (the K permutation pairs
+// k-steps: 2j, 2j+1 cover features 8j .. 8j+7, so KL = 2 ceil(n_dim / 8));
+// SMALL = the last row tile has at most 4 real rows.  Both are compile-time
+// so that the MFMA sequences stay branch free.
+template <int DT, int TPW, int KL, bool SMALL>
+__device__ __forceinline__ void stream_quadform(const double* wl, int n_dim,
+                                                int lane,
+                                                const double (&d)[TPW][4 * DT],
+                                                double (&part)[TPW]) {
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) part[t] = 0.0;
+#pragma unroll
+  for (int ht = 0; ht < DT; ++ht) {
+    const int ks_n = (4 * (ht + 1) < KL) ? 4 * (ht + 1) : KL;   // lower-tri
+    // (always true; the run-time test keeps the row tiles in separate basic
+    // blocks -- merged, the scheduler hoists every operand read and the kernel
+    // spills 220 registers)
+    if (16 * ht >= n_dim) continue;
+    if (SMALL && ht == DT - 1) {
+      double r[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) r[t] = 0.0;
+      const int roff = (lane >> 4) * 16 + (lane & 3);
+#pragma unroll
+      for (int ks = 0; ks < 4 * DT; ++ks) {
+        if (ks < ks_n) {
+          const int kt = ks >> 2, s = ks & 3;
+          const double a =
+              wl[((ht * (ht + 1)) / 2 + kt) * NB_TILE + s * 64 + roff];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) r[t] = MFMA4(a, d[t][ks], r[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) part[t] = fma(r[t], r[t], part[t]);
+    } else {
+      nb_d4 acc[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4 * DT; ++ks) {
+        if (ks < ks_n) {
+          const int kt = ks >> 2, s = ks & 3;
+          const double a =
+              wl[((ht * (ht + 1)) / 2 + kt) * NB_TILE + s * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = MFMA(a, d[t][ks], acc[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          part[t] = fma(acc[t][r], acc[t][r], part[t]);
+    }
+  }
+}
+
+template <int DT, int TPW, int KL, bool SMALL>
 __global__ void __launch_bounds__(256, 2)
 nb_ell_stream_kernel(const double* __restrict__ cvec,
                      const double* __restrict__ tiles,   // permuted, lower-tri
@@ -93,28 +162,7 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
     }
 
     double part[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) part[t] = 0.0;
-#pragma unroll
-    for (int ht = 0; ht < DT; ++ht) {
-      if (16 * ht < n_dim) {
-        nb_d4 acc[TPW];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 4 * (ht + 1); ++ks) {     // lower-triangular
-          const int kt = ks >> 2, s = ks & 3;
-          const double a =
-              wl[((ht * (ht + 1)) / 2 + kt) * NB_TILE + s * 64 + lane];
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t] = MFMA(a, d[t][ks], acc[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[t] = fma(acc[t][r], acc[t][r], part[t]);
-      }
-    }
+    stream_quadform<DT, TPW, KL, SMALL>(wl, n_dim, lane, d, part);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       double r2 = part[t];
@@ -135,7 +183,7 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
 typedef const void __attribute__((address_space(1))) * nbs_gptr;
 typedef void __attribute__((address_space(3))) * nbs_lptr;
 
-template <int DT>
+template <int DT, int KL, bool SMALL>
 __global__ void __launch_bounds__(256)
 nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
                          const double* __restrict__ tiles, int n_dim,
@@ -200,28 +248,7 @@ nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
       }
     }
     double part[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) part[t] = 0.0;
-#pragma unroll
-    for (int ht = 0; ht < DT; ++ht) {
-      if (16 * ht < n_dim) {
-        nb_d4 acc[TPW];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 4 * (ht + 1); ++ks) {
-          const int kt = ks >> 2, s4 = ks & 3;
-          const double a =
-              wl[((ht * (ht + 1)) / 2 + kt) * NB_TILE + s4 * 64 + lane];
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t] = MFMA(a, d[t][ks], acc[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[t] = fma(acc[t][r], acc[t][r], part[t]);
-      }
-    }
+    stream_quadform<DT, TPW, KL, SMALL>(wl, n_dim, lane, d, part);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       double r2 = part[t];
@@ -233,7 +260,7 @@ nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
   }
 }
 
-template <int DT>
+template <int DT, int KL, bool SMALL>
 int launch_odd(const double* cvec, const double* tiles, int n_dim,
                const double* x, long long n, unsigned char* mask,
                hipStream_t stream) {
@@ -242,7 +269,7 @@ int launch_odd(const double* cvec, const double* tiles, int n_dim,
   const size_t lds = ((size_t)NT * NB_TILE + 8 * (size_t)bufsz) * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
-    if (hipFuncSetAttribute((const void*)nb_ell_stream_odd_kernel<DT>,
+    if (hipFuncSetAttribute((const void*)nb_ell_stream_odd_kernel<DT, KL, SMALL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed", lds);
@@ -255,18 +282,19 @@ int launch_odd(const double* cvec, const double* tiles, int n_dim,
   long long blocks = (n_groups + 3) / 4;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_ell_stream_odd_kernel<DT>), dim3((unsigned)blocks),
-                     dim3(256), lds, stream, cvec, tiles, n_dim, x, n, mask,
-                     bufsz);
+  hipLaunchKernelGGL((nb_ell_stream_odd_kernel<DT, KL, SMALL>),
+                     dim3((unsigned)blocks), dim3(256), lds, stream, cvec,
+                     tiles, n_dim, x, n, mask, bufsz);
   return NB_OK;
 }
 
-template <int DT>
-int launch(const double* cvec, const double* tiles, int n_dim, const double* x,
-           long long n, unsigned char* mask, hipStream_t stream) {
+template <int DT, int KL, bool SMALL>
+int launch_variant(const double* cvec, const double* tiles, int n_dim,
+                   const double* x, long long n, unsigned char* mask,
+                   hipStream_t stream) {
   if constexpr (DT <= 4) {
     if ((n_dim & 1) && n >= 64)
-      return launch_odd<DT>(cvec, tiles, n_dim, x, n, mask, stream);
+      return launch_odd<DT, KL, SMALL>(cvec, tiles, n_dim, x, n, mask, stream);
   }
   // 4 tiles per wavefront while the operands fit the register file
   constexpr int TPW = (DT <= 4) ? 4 : 2;
@@ -274,9 +302,27 @@ int launch(const double* cvec, const double* tiles, int n_dim, const double* x,
   long long blocks = (n_groups + 3) / 4;
   if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_ell_stream_kernel<DT, TPW>), dim3((unsigned)blocks),
-                     dim3(256), 0, stream, cvec, tiles, n_dim, x, n, mask);
+  hipLaunchKernelGGL((nb_ell_stream_kernel<DT, TPW, KL, SMALL>),
+                     dim3((unsigned)blocks), dim3(256), 0, stream, cvec, tiles,
+                     n_dim, x, n, mask);
   return NB_OK;
+}
+
+template <int DT>
+int launch(const double* cvec, const double* tiles, int n_dim, const double* x,
+           long long n, unsigned char* mask, hipStream_t stream) {
+  const int kl = 2 * ((n_dim + 7) >> 3);
+  const int rem = n_dim & 15;
+  if (kl == 4 * DT)
+    return launch_variant<DT, 4 * DT, false>(cvec, tiles, n_dim, x, n, mask,
+                                             stream);
+  // (with two tiles per wavefront an operand read feeds only 32 cycles of
+  // 4x4x4 work and the LDS latency shows: slower than the padded tile)
+  if (DT <= 4 && rem >= 1 && rem <= 4)
+    return launch_variant<DT, 4 * DT - 2, true>(cvec, tiles, n_dim, x, n, mask,
+                                                stream);
+  return launch_variant<DT, 4 * DT - 2, false>(cvec, tiles, n_dim, x, n, mask,
+                                               stream);
 }
 
 }  // namespace
