@@ -62,6 +62,27 @@ def test_mixture_construction_matches_reference():
     assert np.allclose(ell['c'], g['c'], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize('seed,d,n_flat', [(0, 8, 2), (1, 12, 5), (2, 20, 0),
+                                           (3, 5, 5)])
+def test_mixture_greedy_choice_matches_oracle(seed, d, n_flat):
+    """The Schur-complement form of the drop-one-dimension volumes
+    (geometry.mixture_params) picks the same cube dimensions and the same
+    ellipsoid as the reference's loop restated in the oracle."""
+    from nautilus_amd import geometry
+    from oracle import bounds_oracle as bo
+    rng = np.random.default_rng(seed)
+    pts = np.clip(0.5 + 0.07 * rng.normal(size=(400, d)), 0, 1)
+    pts[:, :n_flat] = rng.random((400, n_flat))
+    dim_cube, ell = geometry.mixture_params(pts, 1.1)
+    ref = bo.OMixture.build(pts, enlarge_per_dim=1.1)
+    assert np.array_equal(dim_cube, ref.dim_cube)
+    if ref.ellipsoid is None:
+        assert ell is None
+    else:
+        assert np.allclose(ell['B'], ref.ellipsoid.B, rtol=1e-8, atol=1e-10)
+        assert np.allclose(ell['c'], ref.ellipsoid.c, rtol=0, atol=1e-9)
+
+
 def test_overlap_test_matches_oracle():
     from nautilus_amd import geometry
     from oracle import bounds_oracle as bo
