@@ -181,7 +181,6 @@ class Sampler:
         self._later = {}         # cache: shell index -> DeviceBoundList
         self.timing = dict(add_bound=0.0, sample_shell=0.0, likelihood=0.0,
                            bookkeeping=0.0)
-        self.n_proposals = 0     # raw proposal evaluations (outer draws)
         self.filepath = filepath
         if resume and filepath is not None and os.path.exists(filepath):
             from . import io
@@ -212,6 +211,14 @@ class Sampler:
     def points(self):
         """Per-shell points as numpy arrays (reference attribute)."""
         return [p.view().cpu().numpy() for p in self._pts]
+
+    @property
+    def n_proposals(self):
+        """Raw proposal evaluations so far: points drawn from the outer
+        multi-ellipsoids of all bounds (``outer_bound.n_sample``,
+        union.py:322)."""
+        return int(sum(b.outer_bound.n_sample for b in self.bounds
+                       if hasattr(b, 'outer_bound')))
 
     @property
     def points_t(self):
