@@ -240,8 +240,10 @@ def _best_of_inits(points_t, random_state):
     fits = [f for f in device.gmm_fit(points_t, n_init=N_INIT,
                                       seed=random_state) if not f['failed']]
     if not fits:
-        raise ValueError('Fitting the mixture model failed because some '
-                         'components have ill-defined empirical covariance.')
+        # every restart hit an empty cluster or a covariance that is not
+        # positive definite (degenerate point sets): scikit-learn relocates
+        # empty clusters and may still succeed -- let it decide
+        return _best_of_inits_host(points_t, random_state)
     best = max(fits, key=lambda f: f['lower_bound'])
     return _Mixture(best['weights'], best['means'], best['covariances'],
                     best['lower_bound'])

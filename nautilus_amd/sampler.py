@@ -195,9 +195,6 @@ class Sampler:
         state['_later'] = {}
         state['comm'] = None
         state['_pts_t'] = self._pts_t.cpu().numpy()
-        for b in state['bounds']:
-            if hasattr(b, '_fifo') and b._fifo is not None:
-                pass
         return state
 
     def __setstate__(self, state):
