@@ -433,6 +433,21 @@ def test_transform_and_standardize(dev, d):
                        rtol=0, atol=1e-11)
 
 
+def test_gmm_degenerate_input_falls_back(dev):
+    """Every device restart fails on a degenerate cloud (all points equal up
+    to a few duplicates); the labels then come from scikit-learn."""
+    import warnings
+    from nautilus_amd import geometry
+    x = np.zeros((300, 4)) + 0.5
+    x[:5] += 0.1
+    fits = dev.gmm_fit(x, n_init=4, seed=1)
+    assert len(fits) == 4
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        lab = geometry.two_component_labels(x, 5, 3)
+    assert lab.shape == (300,) and set(np.unique(lab)) <= {0, 1}
+
+
 def test_phase_shift_bit_exact(dev):
     """bounds/periodic.py on the device: centres, forward and inverse
     transform are bit-identical to the reference's (golden fixture)."""
