@@ -23,15 +23,19 @@
 // as A operands from 16x16 tile-major storage: one contiguous 512-byte row of
 // the tile per MFMA.
 //
-// Workgroup structure: 4 wavefronts x 2 tiles = 128 points per workgroup
-// pass.  Emulator weights are the bulk of the operand traffic (227 MFMAs per
-// tile and network, 132 KB of weights per network at D = 50), so a workgroup
-// stages them in LDS once per (bound, network) -- layer 1 first, then layers
-// 2-4 -- and all 8 tiles of the workgroup read their A operands from LDS
-// (conflict-free ds_read_b64); each wavefront shares every A operand between
-// its two tiles.  Measured: operand fetch from L2 was the bottleneck (12.9
-// TFLOP/s; 46.9 with the loads stubbed out).  The small ellipsoid factors are
-// read straight from L2.
+// Workgroup structure: 4 wavefronts x 2 tiles = 128 points per workgroup pass
+// (1 tile per wavefront for n_dim > 64), one workgroup per CU (the kernel
+// uses the whole register file), grid-stride over the 128-point super tiles.
+// Emulator weights are the bulk of the operand traffic (132 KB per network
+// at D = 50), so they stream through two LDS regions of 38 tiles: while one
+// region feeds the matrix cores the other is refilled by global_load_lds DMA
+// (layer 1, for n_dim > 64 in two K chunks, then layers 2-4; one barrier per
+// stage).  All tiles of the workgroup read their A operands from LDS
+// (conflict-free ds_read_b64) and each wavefront shares every A operand
+// between its two tiles.  The partial last tile of every layer (4, 2, 4, 1
+// units) runs on v_mfma_f64_4x4x4_4b_f64.  Ellipsoid blocks are staged in LDS
+// per bound.  Measured on MI355X (profiles/r01/eval_pmc.md): 39 TFLOP/s
+// algorithmic at D = 50, HBM traffic 1.01x algorithmic, matrix pipe 56 % busy.
 #include "nb_common.h"
 
 #include <cstdlib>
