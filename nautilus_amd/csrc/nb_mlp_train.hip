@@ -7,12 +7,13 @@
 // All networks of an emulator train concurrently.  Every Adam step is two
 // kernel launches on one stream (the kernel boundary is the grid-wide sync):
 //
-//  FB  one wavefront per 16-row tile of the minibatch: forward through
-//      the four layers with activations held in registers (the MFMA C/D
-//      layout is the next layer's B-operand layout), output delta, backward
-//      deltas through W^T read from the same 16x16 tile-major weights; the
-//      activations and deltas are written row-major to a stash in global
-//      memory (L2 resident, ~0.8 MB per network).
+//  FB  one workgroup of four wavefronts per 16-row tile of the minibatch:
+//      forward through the four layers (the output tiles of a layer are split
+//      over the wavefronts, activations / deltas are exchanged through LDS in
+//      [unit][row] layout), output delta, backward deltas through W^T read
+//      from the same 16x16 tile-major weights; every weight operand is
+//      loaded before the first barrier; activations and deltas go row-major
+//      to a stash in global memory (L2 resident, ~0.8 MB per network).
 //  G   one wavefront per 16x16 weight tile: dW = act^T delta contracted over all
 //      rows of the minibatch in a fixed order (deterministic, no atomics),
 //      then the Adam update of that tile in place.  The bias is row K of the
