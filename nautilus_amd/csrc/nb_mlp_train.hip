@@ -24,6 +24,7 @@
 #include "nb_common.h"
 #include "../../include/nautilus_hip.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -207,8 +208,9 @@ __device__ __forceinline__ nb_d4 bwd_tile(const double* __restrict__ w,
 }
 
 template <int DT>
-__global__ void __launch_bounds__(256)
-nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
+__device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
+                                        int net, int tile, int ep,
+                                        long long start, int nb) {
   constexpr int KS1MAX = 4 * DT + 1;
   constexpr int LD0MAX = 16 * (DT + 1);
   // activations / deltas of the tile in [unit][row] layout
@@ -220,7 +222,6 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   __shared__ __attribute__((aligned(16))) double sD3[LD3 * LS];
   __shared__ __attribute__((aligned(16))) double sD2[LD2 * LS];
 
-  const NetState st = a.nets[blockIdx.y];
   if (st.scal[4] != 0.0) return;                 // network already stopped
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -228,9 +229,8 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   const int D = a.n_dim, kt1 = a.kt1;
   const int ld0 = 16 * kt1;
   const int ks1 = (D + 1 + 3) >> 2;
-  const int tile = blockIdx.x;
   const long long n = a.n;
-  const int* perm = a.perm + ((long long)blockIdx.y * a.n_epochs + ep) * n;
+  const int* perm = a.perm + ((long long)net * a.n_epochs + ep) * n;
 
   double* W1 = st.W;
   double* W2 = W1 + kt1 * NB_HT1 * NB_TILE;
@@ -411,18 +411,24 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   flush_stash(sD2, D2, LD2, LD2, tile);
 }
 
-__global__ void __launch_bounds__(64)
-nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
+template <int DT>
+__global__ void __launch_bounds__(256)
+nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   const NetState st = a.nets[blockIdx.y];
+  fb_body<DT>(a, st, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb);
+}
+
+// ---- G: dW of one 16x16 weight tile over the minibatch + Adam, one wavefront
+__device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
+                                       int gt, int lane, int nb,
+                                       long long t_adam) {
   if (st.scal[4] != 0.0) return;
-  const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
   const int kt1 = a.kt1;
   const int ld0 = 16 * kt1;
   const int n_tiles = (nb + 15) >> 4;
   const int n_gt1 = kt1 * NB_HT1, n_gt2 = NB_HT1 * NB_HT2,
             n_gt3 = NB_HT2 * NB_HT3;
-  const int gt = blockIdx.x;
 
   const double* A0 = st.stash;
   const double* A1 = A0 + MAXB * ld0;
@@ -497,11 +503,18 @@ nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
   }
 }
 
+__global__ void __launch_bounds__(64)
+nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
+  const NetState st = a.nets[blockIdx.y];
+  g_body(a, st, (int)blockIdx.x, (int)threadIdx.x, nb, t_adam);
+}
+
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
-// (sklearn/_multilayer_perceptron.py:730-760, 819-822)
-__global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
-  const NetState st = a.nets[blockIdx.x];
-  if (threadIdx.x != 0 || st.scal[4] != 0.0) return;
+// (sklearn/_multilayer_perceptron.py:730-760, 819-822); one thread
+__device__ __forceinline__ void epoch_body(const TrainArgs& a,
+                                           const NetState& st,
+                                           long long t_adam) {
+  if (st.scal[4] != 0.0) return;
   const double loss = st.scal[5] / (double)a.n;
   int n_iter = (int)st.scal[3];
   double best = st.scal[1];
@@ -518,6 +531,127 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
   if (stale > a.n_iter_no_change || n_iter >= a.max_iter) st.scal[4] = 1.0;
 }
 
+__global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
+  const NetState st = a.nets[blockIdx.x];
+  if (threadIdx.x == 0) epoch_body(a, st, t_adam);
+}
+
+// ---------------------------------------------------------------------------
+// One launch per chunk of epochs, one XCD per network.
+//
+// Two launches per Adam step cost about a third of the step in dispatch and
+// drain (the end-of-kernel release writes the L2 of every XCD back so that the
+// next kernel's workgroups, anywhere on the chip, see the data).  A resident
+// kernel with an agent-scope barrier pays the same write-back inside the
+// kernel (measured: slower).  What does work: consecutive workgroup ids go
+// round-robin over the 8 XCDs (workgroup i -> XCD i mod 8; checked at run
+// time through HW_REG_XCC_ID), so the 17 workgroups {net, net + 8, ...} of a
+// network share one L2.  Within one L2 a producer only has to wait for its
+// stores (s_waitcnt) and a consumer to drop its CU's L1 (buffer_inv): no L2
+// write-back, and the barrier is one atomic in that L2.
+// ---------------------------------------------------------------------------
+constexpr int XCD_COUNT = 8;
+constexpr int XCD_SLOTS = 17;            // workgroups per network
+constexpr int SYNC_WORDS = 4;            // counter, error, xcc mask, pad
+constexpr int SYNC_LIMIT = 1 << 22;
+
+__device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
+                                            int n_wg) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // stores of this workgroup are in L2 once the counters drain
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    const int target = (++phase) * n_wg;
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SYNC_LIMIT) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    // invalidate this CU's vector L1: later loads come from the shared L2
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+struct XcdMap {
+  int n_nets;
+  int net[XCD_COUNT];
+};
+
+__global__ void nb_xcc_probe_kernel(int* out) {
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[blockIdx.x] = (int)(xcc & 15);
+  }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
+  // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
+  // own disjoint XCDs; map.net[x] = network of XCD x or -1
+  const int n_nets = map.n_nets;
+  const int net = map.net[(int)blockIdx.x % XCD_COUNT];
+  if (net < 0) return;
+  const int slot = (int)blockIdx.x / XCD_COUNT;
+  if (net >= n_nets) return;
+  const NetState st = a.nets[net];
+  int* counter = sync + SYNC_WORDS * net;
+  int* err = counter + 1;
+  int* mask = counter + 2;
+  int phase = 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long n = a.n;
+  const int steps = (int)((n + a.batch - 1) / a.batch);
+  const int n_gt = nb_net_tiles(a.kt1);
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicOr(mask, 1 << (xcc & 15));
+  }
+  xcd_barrier(counter, err, phase, XCD_SLOTS);
+  {
+    const int m = __hip_atomic_load(mask, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+    if (__popc(m) != 1) {                 // not one XCD: no shared L2
+      if (threadIdx.x == 0)
+        __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  long long t_adam = t_adam0;
+  for (int ep = 0; ep < a.n_epochs; ++ep) {
+    // uniform over the network's workgroups: the flag only changes in
+    // epoch_body, which is followed by a barrier
+    const bool done = ((volatile double*)st.scal)[4] != 0.0;
+    for (int sidx = 0; sidx < steps; ++sidx) {
+      const long long start = (long long)sidx * a.batch;
+      const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
+      t_adam += 1;
+      if (done) continue;
+      if (slot * 16 < nb) fb_body<DT>(a, st, net, slot, ep, start, nb);
+      xcd_barrier(counter, err, phase, XCD_SLOTS);
+      for (int gt = slot * 4 + wave; gt < n_gt; gt += XCD_SLOTS * 4)
+        g_body(a, st, gt, lane, nb, t_adam);
+      xcd_barrier(counter, err, phase, XCD_SLOTS);
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT) != 0)
+        return;
+    }
+    if (done) continue;
+    if (slot == 0 && threadIdx.x == 0) epoch_body(a, st, t_adam);
+    xcd_barrier(counter, err, phase, XCD_SLOTS);
+  }
+}
+
 void put_w(double* tiles, int ht_n, int k, int h, double v) {
   tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
         (h & 15)] = v;
@@ -528,6 +662,28 @@ double get_w(const double* tiles, int ht_n, int k, int h) {
 }
 
 }  // namespace
+
+// One-time check of the placement the resident kernel relies on: workgroups
+// i, i + 8, i + 16, ... of a 1-D grid run on the same XCD.
+static bool xcd_pinning_available() {
+  static int cached = -1;
+  if (cached >= 0) return cached == 1;
+  cached = 0;
+  const int n = XCD_COUNT * XCD_SLOTS;
+  int* dev = nullptr;
+  if (hipMalloc((void**)&dev, n * sizeof(int)) != hipSuccess) return false;
+  hipLaunchKernelGGL(nb_xcc_probe_kernel, dim3(n), dim3(64), 0, 0, dev);
+  int host[XCD_COUNT * XCD_SLOTS];
+  const hipError_t e = hipMemcpy(host, dev, sizeof host, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  bool ok = true;
+  for (int i = 0; i < n; ++i) ok = ok && host[i] == host[i % XCD_COUNT];
+  cached = ok ? 1 : 0;
+  return ok;
+}
+
+static unsigned g_xcd_in_use = 0;   // XCDs owned by live resident trainers
 
 struct nb_trainer {
   int n_dim = 0, E = 0, kt1 = 0, dt = 0;
@@ -541,6 +697,10 @@ struct nb_trainer {
   int max_iter = 10000, n_iter_no_change = 10, batch = 200;
   double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
   long long t_adam = 0;
+  int* sync_dev = nullptr;         // per network: counter, error, xcc mask
+  bool two_launch = false;         // fall back to two launches per step
+  XcdMap xcd_map;                  // XCDs owned by this trainer's networks
+  unsigned xcd_owned = 0;
 };
 
 extern "C" {
@@ -568,9 +728,35 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
   if (e == hipSuccess) e = hipMemset(t->pool, 0, bytes);
   if (e == hipSuccess)
     e = hipMalloc((void**)&t->nets_dev, n_networks * sizeof(NetState));
+  if (e == hipSuccess)
+    e = hipMalloc((void**)&t->sync_dev,
+                  SYNC_WORDS * XCD_COUNT * sizeof(int));
+  t->two_launch = n_networks > XCD_COUNT ||
+                  getenv("NB_TRAIN_TWO_LAUNCH") != nullptr ||
+                  !xcd_pinning_available();
+  // A resident workgroup takes a whole CU; two resident kernels competing for
+  // the CUs of one XCD could each end up partially dispatched and wait for
+  // each other.  So every trainer owns its XCDs exclusively; a trainer that
+  // finds too few free ones trains with two launches per step instead.
+  t->xcd_map.n_nets = n_networks;
+  for (int x = 0; x < XCD_COUNT; ++x) t->xcd_map.net[x] = -1;
+  if (!t->two_launch) {
+    int assigned = 0;
+    for (int x = 0; x < XCD_COUNT && assigned < n_networks; ++x)
+      if (!(g_xcd_in_use & (1u << x))) {
+        t->xcd_map.net[x] = assigned++;
+        t->xcd_owned |= 1u << x;
+      }
+    if (assigned < n_networks) {
+      t->xcd_owned = 0;
+      t->two_launch = true;
+    } else {
+      g_xcd_in_use |= t->xcd_owned;
+    }
+  }
   if (e != hipSuccess) {
     nb_set_error("trainer allocation failed: %s", hipGetErrorString(e));
-    delete t;
+    nb_trainer_destroy(t);
     return NB_ERR_HIP;
   }
   std::vector<double> w((size_t)t->n_w);
@@ -646,6 +832,27 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
   const long long n = t->n;
   const int steps_per_epoch = (int)((n + a.batch - 1) / a.batch);
   const int n_gt = nb_net_tiles(t->kt1);
+  if (!t->two_launch) {
+    NB_HIP_CHECK(hipMemsetAsync(t->sync_dev, 0,
+                                SYNC_WORDS * XCD_COUNT * sizeof(int), s));
+    const dim3 grid(XCD_COUNT * XCD_SLOTS), blk(256);
+    switch (t->dt) {
+#define NB_CASE(DT_)                                                       \
+      case DT_:                                                            \
+        hipLaunchKernelGGL(nb_train_xcd_kernel<DT_>, grid, blk, 0, s, a,   \
+                           t->xcd_map, t->t_adam, t->sync_dev);            \
+        break;
+      NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4)
+      NB_CASE(5) NB_CASE(6) NB_CASE(7) NB_CASE(8)
+#undef NB_CASE
+      default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
+    }
+    t->t_adam += (long long)n_epochs * steps_per_epoch;
+    NB_HIP_CHECK(hipGetLastError());
+    if (status_host != nullptr)
+      return nb_trainer_status(t, status_host, stream);
+    return NB_OK;
+  }
   for (int ep = 0; ep < n_epochs; ++ep) {
     for (int sidx = 0; sidx < steps_per_epoch; ++sidx) {
       const long long start = (long long)sidx * a.batch;
@@ -675,6 +882,21 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
 
 int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream) {
   NB_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (!t->two_launch) {
+    int sync[SYNC_WORDS * XCD_COUNT];
+    NB_HIP_CHECK(hipMemcpy(sync, t->sync_dev, sizeof sync,
+                           hipMemcpyDeviceToHost));
+    for (int i = 0; i < t->E; ++i)
+      if (sync[SYNC_WORDS * i + 1] != 0) {
+        nb_set_error("resident training kernel failed for network %d (%s); "
+                     "set NB_TRAIN_TWO_LAUNCH=1 to train with two launches "
+                     "per step", i,
+                     sync[SYNC_WORDS * i + 1] == 2
+                         ? "its workgroups do not share an XCD"
+                         : "barrier timeout");
+        return NB_ERR_HIP;
+      }
+  }
   for (int i = 0; i < t->E; ++i) {
     double scal[8];
     NB_HIP_CHECK(hipMemcpy(scal, t->nets_host[i].scal, sizeof scal,
@@ -722,7 +944,9 @@ int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs,
 int nb_trainer_destroy(nb_trainer* t) {
   if (t == nullptr) return NB_OK;
   if (t->pool) (void)hipFree(t->pool);
+  g_xcd_in_use &= ~t->xcd_owned;
   if (t->nets_dev) (void)hipFree(t->nets_dev);
+  if (t->sync_dev) (void)hipFree(t->sync_dev);
   delete t;
   return NB_OK;
 }
