@@ -186,6 +186,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if args.same_device:
+        # several processes on one GPU: the resident training kernel owns
+        # whole XCDs per process and must not be shared between processes
+        os.environ['NB_TRAIN_TWO_LAUNCH'] = '1'
         local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
