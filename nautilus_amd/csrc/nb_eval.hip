@@ -63,9 +63,17 @@ struct EvalArgs {
 enum { MODE_ANY = 0, MODE_ASSOC = 1, MODE_SAMPLE = 2, MODE_COUNT = 3,
        MODE_SCORE = 4 };
 
-// one dense layer on the matrix cores for both tiles of the wavefront:
+// One dense layer on the matrix cores for the T tiles of a wavefront:
 // out[h] = act(sum_k in[k] W[k][h]), bias folded in as row k = K (the input
 // carries a constant 1 there).  w points to LDS.
+//
+// Loop order: k-step outer, output tile inner.  Every B operand (the
+// activations, in registers) meets the HT A operands of its k-step; the
+// 2 (HT - 1) accumulators are independent, so neither the MFMA latency nor the
+// LDS latency of a single operand sits on the critical path, and only the
+// last four k-steps depend on the runtime count ks_n (n_dim + 1 >
+// 16 (DT - 1) + 1): the others form one basic block.  The accumulators are
+// the output registers themselves.
 //
 // The hidden sizes (100, 50, 20, 1) leave 4, 2, 4 and 1 units in the last
 // 16-wide tile.  Those are computed with v_mfma_f64_4x4x4_4b_f64 instead of a
@@ -76,177 +84,179 @@ enum { MODE_ANY = 0, MODE_ASSOC = 1, MODE_SAMPLE = 2, MODE_COUNT = 3,
 // the result is directly k-step 4*(HT-1) of the next layer.  The A operand is
 // gathered from the unchanged tile-major weights (element (kk, hh) of the
 // last tile, hh = lane & 3).
+//
+// A layer whose weights exceed an LDS region (layer 1 for n_dim > 64) runs in
+// K chunks [KS_LO, KS_HI): `out` carries the pre-activations between them, w
+// is the chunk in LDS (k-tile index relative to KS_LO / 4).
+#ifndef NB_SPLIT_LO
+#define NB_SPLIT_LO 8
+#endif
+#ifndef NB_SPLIT_4
+#define NB_SPLIT_4 2
+#endif
+#ifndef NB_SPLIT_HI
+#define NB_SPLIT_HI 8
+#endif
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
-template <int KSMAX, int HT, bool RELU>
-__device__ __forceinline__ void mlp_layer(const double* w, int ks_n,
-                                          const double* in0, const double* in1,
-                                          int lane, double* out0,
-                                          double* out1, double& rem0,
-                                          double& rem1) {
-#pragma unroll
-  for (int ht = 0; ht < HT - 1; ++ht) {
-    nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-#pragma unroll
-    for (int ks = 0; ks < KSMAX; ++ks) {
-      if (ks < ks_n) {
-        const int kt = ks >> 2, s = ks & 3;
-#ifdef NB_EXPERIMENT_NOLOAD
-        const double a = 1e-3 * (double)(lane + ks);   // dev experiment only
-#else
-        const double a = w[(kt * HT + ht) * NB_TILE + s * 64 + lane];
-#endif
-        acc0 = MFMA(a, in0[ks], acc0);
-        acc1 = MFMA(a, in1[ks], acc1);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      out0[4 * ht + r] = RELU ? fmax(acc0[r], 0.0) : acc0[r];
-      out1[4 * ht + r] = RELU ? fmax(acc1[r], 0.0) : acc1[r];
-    }
-  }
-  // last tile: units 16(HT-1) .. 16(HT-1)+3
-  double r0 = 0.0, r1 = 0.0;
-  const int roff = (HT - 1) * NB_TILE + (lane >> 4) * 16 + (lane & 3);
-#pragma unroll
-  for (int ks = 0; ks < KSMAX; ++ks) {
-    if (ks < ks_n) {
-      const int kt = ks >> 2, s = ks & 3;
-      const double a = w[kt * HT * NB_TILE + s * 64 + roff];
-      r0 = MFMA4(a, in0[ks], r0);
-      r1 = MFMA4(a, in1[ks], r1);
-    }
-  }
-  rem0 = RELU ? fmax(r0, 0.0) : r0;
-  rem1 = RELU ? fmax(r1, 0.0) : r1;
-}
-
-// same for a single tile (the gather left this wavefront only one)
-template <int KSMAX, int HT, bool RELU>
-__device__ __forceinline__ void mlp_layer1(const double* w, int ks_n,
-                                           const double* in0, int lane,
-                                           double* out0, double& rem0) {
-#pragma unroll
-  for (int ht = 0; ht < HT - 1; ++ht) {
-    nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-#pragma unroll
-    for (int ks = 0; ks < KSMAX; ++ks) {
-      if (ks < ks_n) {
-        const int kt = ks >> 2, s = ks & 3;
-        const double a = w[(kt * HT + ht) * NB_TILE + s * 64 + lane];
-        if (ks & 1) acc1 = MFMA(a, in0[ks], acc1);
-        else acc0 = MFMA(a, in0[ks], acc0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double v = acc0[r] + acc1[r];
-      out0[4 * ht + r] = RELU ? fmax(v, 0.0) : v;
-    }
-  }
-  double r0 = 0.0, r1 = 0.0;
-  const int roff = (HT - 1) * NB_TILE + (lane >> 4) * 16 + (lane & 3);
-#pragma unroll
-  for (int ks = 0; ks < KSMAX; ++ks) {
-    if (ks < ks_n) {
-      const int kt = ks >> 2, s = ks & 3;
-      const double a = w[kt * HT * NB_TILE + s * 64 + roff];
-      if (ks & 1) r1 = MFMA4(a, in0[ks], r1);
-      else r0 = MFMA4(a, in0[ks], r0);
-    }
-  }
-  const double v = r0 + r1;
-  rem0 = RELU ? fmax(v, 0.0) : v;
-}
-
-// Layer 1 of one tile in two K chunks (n_dim > 64: its weights do not fit one
-// LDS region).  h holds the pre-activations between the chunks; the last
-// chunk applies the ReLU and writes the constant-1 unit (k-step 25, lane
-// group 0) and the zero padding of the partial tile.  w is the chunk in LDS:
-// k-tile index relative to KS_LO / 4.
-template <int KS_LO, int KS_HI, bool FIRST, bool LAST>
-__device__ __forceinline__ void l1_part(const double* w, int ks_n,
-                                        const double* in, int lane,
-                                        double* h) {
+// output tiles [H0, H1) of a layer (+ the partial last tile if H1 == HT)
+template <int T, int KSMAX, int HT, bool RELU, int KS_LO, int KS_HI, int H0,
+          int H1, int NIN, int NOUT>
+__device__ __forceinline__ void mlp_block(const double* w, int ks_n,
+                                          const double (&in)[T][NIN], int lane,
+                                          double (&out)[T][NOUT]) {
   static_assert(KS_LO % 4 == 0, "chunks start at a k-tile boundary");
+  constexpr bool FIRST = (KS_LO == 0), LAST = (KS_HI == KSMAX);
+  constexpr int NFL = HT - 1;                 // full 16-unit tiles of the layer
+  constexpr bool REM = (H1 == HT);
+  constexpr int NF = (REM ? NFL : H1) - H0;   // full tiles of this block
+  constexpr int NA = NF + (REM ? 1 : 0);      // A operands per k-step
+  nb_d4 acc[T][NF > 0 ? NF : 1];
+  double rem[T];
 #pragma unroll
-  for (int ht = 0; ht < NB_HT1 - 1; ++ht) {
-    nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-    if (!FIRST) {
+  for (int t = 0; t < T; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc0[r] = h[4 * ht + r];
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[t][h][r] = FIRST ? 0.0 : out[t][4 * (H0 + h) + r];
+    rem[t] = (FIRST || !REM) ? 0.0 : out[t][4 * NFL];
+  }
+  const int roff = NFL * NB_TILE + (lane >> 4) * 16 + (lane & 3);
+  auto read_a = [&](int ks, double (&a)[NA]) {
+    const double* wk = w + ((ks - KS_LO) >> 2) * HT * NB_TILE + (ks & 3) * 64;
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+#ifdef NB_EXPERIMENT_NOLOAD
+      a[h] = 1e-3 * (double)(lane + ks + 7 * h);       // dev experiment only
+#else
+      a[h] = wk[(H0 + h) * NB_TILE + lane];
+#endif
     }
+    if constexpr (REM) a[NF] = wk[roff];
+  };
+  auto step = [&](int ks, const double (&a)[NA]) {
 #pragma unroll
-    for (int ks = KS_LO; ks < KS_HI; ++ks) {
-      if (ks < ks_n) {
-        const int kt = (ks - KS_LO) >> 2, s = ks & 3;
-        const double a = w[(kt * NB_HT1 + ht) * NB_TILE + s * 64 + lane];
-        if (ks & 1) acc1 = MFMA(a, in[ks], acc1);
-        else acc0 = MFMA(a, in[ks], acc0);
-      }
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t][h] = MFMA(a[h], in[t][ks], acc[t][h]);
+    if constexpr (REM) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) rem[t] = MFMA4(a[NF], in[t][ks], rem[t]);
     }
+  };
+  // Software pipeline over the unguarded k-steps: wait for the operands of
+  // step ks (read one step ago), issue the reads of step ks + 1, then the
+  // MFMAs of step ks.  The empty asm is a use of the operands, so that the
+  // compiler's s_waitcnt lands BEFORE the next reads are issued (otherwise it
+  // waits for those as well); sched_barrier pins the order.  (Prefetch
+  // distances > 1 were measured: no gain, the extra operand registers spill.)
+  auto arrived = [&](const double (&a)[NA]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double v = acc0[r] + acc1[r];
-      h[4 * ht + r] = LAST ? fmax(v, 0.0) : v;
+    for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(a[i]));
+  };
+  constexpr int KS_U = (KS_HI < KSMAX - 4) ? KS_HI : KSMAX - 4;
+  constexpr int PD = 1, R = PD + 1;
+  if constexpr (KS_LO < KS_U) {
+    double a[R][NA];
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+      if (KS_LO + i < KS_U) read_a(KS_LO + i, a[i % R]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = KS_LO; ks < KS_U; ++ks) {
+      arrived(a[(ks - KS_LO) % R]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + PD < KS_U) read_a(ks + PD, a[(ks - KS_LO + PD) % R]);
+      __builtin_amdgcn_sched_barrier(0);
+      step(ks, a[(ks - KS_LO) % R]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  double r0 = FIRST ? 0.0 : h[4 * (NB_HT1 - 1)], r1 = 0.0;
-  const int roff = (NB_HT1 - 1) * NB_TILE + (lane >> 4) * 16 + (lane & 3);
 #pragma unroll
-  for (int ks = KS_LO; ks < KS_HI; ++ks) {
+  for (int ks = (KS_LO > KS_U ? KS_LO : KS_U); ks < KS_HI; ++ks) {
     if (ks < ks_n) {
-      const int kt = (ks - KS_LO) >> 2, s = ks & 3;
-      const double a = w[kt * NB_HT1 * NB_TILE + s * 64 + roff];
-      if (ks & 1) r1 = MFMA4(a, in[ks], r1);
-      else r0 = MFMA4(a, in[ks], r0);
+      double a[NA];
+      read_a(ks, a);
+      step(ks, a);
     }
   }
-  const double v = r0 + r1;
-  h[4 * (NB_HT1 - 1)] = LAST ? fmax(v, 0.0) : v;
-  if (LAST) {
-    h[4 * (NB_HT1 - 1) + 1] = ((lane >> 4) == 0) ? 1.0 : 0.0;   // unit 100
-    h[4 * (NB_HT1 - 1) + 2] = 0.0;
-    h[4 * (NB_HT1 - 1) + 3] = 0.0;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[t][4 * (H0 + h) + r] =
+            (LAST && RELU) ? fmax(acc[t][h][r], 0.0) : acc[t][h][r];
+    if constexpr (REM)
+      out[t][4 * NFL] = (LAST && RELU) ? fmax(rem[t], 0.0) : rem[t];
+  }
+}
+
+// a layer = blocks of SPLIT output tiles (fewer live accumulators per block,
+// more operand reuse and independent accumulators within it)
+template <int T, int SPLIT, int KSMAX, int HT, bool RELU, int KS_LO, int KS_HI,
+          int H0 = 0, int NIN, int NOUT>
+__device__ __forceinline__ void mlp_layer(const double* w, int ks_n,
+                                          const double (&in)[T][NIN], int lane,
+                                          double (&out)[T][NOUT]) {
+  if constexpr (HT - 1 - H0 > SPLIT) {
+    mlp_block<T, KSMAX, HT, RELU, KS_LO, KS_HI, H0, H0 + SPLIT>(
+        w, ks_n, in, lane, out);
+    mlp_layer<T, SPLIT, KSMAX, HT, RELU, KS_LO, KS_HI, H0 + SPLIT>(
+        w, ks_n, in, lane, out);
+  } else {
+    mlp_block<T, KSMAX, HT, RELU, KS_LO, KS_HI, H0, HT>(w, ks_n, in, lane,
+                                                        out);
   }
 }
 
 // the TPW tiles of a wavefront through one layer (+ the constant-1 unit that
-// feeds the next layer's bias row: k-step ONE_KS, lane group ONE_LG)
-template <int TPW, int KSMAX, int HT, bool RELU, int ONE_KS, int ONE_LG,
-          int NIN, int NOUT>
+// feeds the next layer's bias row: k-step ONE_KS, lane group ONE_LG); the
+// gather may have left the wavefront a single tile
+template <int TPW, int SPLIT, int KSMAX, int HT, bool RELU, int ONE_KS,
+          int ONE_LG, int KS_LO = 0, int KS_HI = KSMAX, int NIN, int NOUT>
 __device__ __forceinline__ void mlp_tiles(const double* w, int ks_n,
                                           const double (&in)[TPW][NIN],
                                           int lane, double (&out)[TPW][NOUT],
                                           bool two_tiles) {
-  double rem[2] = {0.0, 0.0};     // units of the partial last tile
   if constexpr (TPW == 2) {
-    if (two_tiles)
-      mlp_layer<KSMAX, HT, RELU>(w, ks_n, in[0], in[1], lane, out[0], out[1],
-                                 rem[0], rem[1]);
-    else
-      mlp_layer1<KSMAX, HT, RELU>(w, ks_n, in[0], lane, out[0], rem[0]);
-  } else {
-    mlp_layer1<KSMAX, HT, RELU>(w, ks_n, in[0], lane, out[0], rem[0]);
-  }
+    if (two_tiles) {
+      mlp_layer<2, SPLIT, KSMAX, HT, RELU, KS_LO, KS_HI>(w, ks_n, in, lane,
+                                                         out);
+    } else {
+      // branch-dependent element stores would turn the activation arrays into
+      // scratch memory: compute into a copy, merge with selects
+      double in1[1][NIN], out1[1][NOUT];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) out[t][4 * (HT - 1)] = rem[t];
-  // registers 1..3 of the last tile: zero padding, except the constant 1
-  // (written outside the branch above: branch-dependent element stores would
-  // turn the activation arrays into scratch memory)
+      for (int i = 0; i < NIN; ++i) in1[0][i] = in[0][i];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
+      for (int i = 0; i < NOUT; ++i) out1[0][i] = out[0][i];
+      mlp_layer<1, SPLIT, KSMAX, HT, RELU, KS_LO, KS_HI>(w, ks_n, in1, lane,
+                                                         out1);
 #pragma unroll
-    for (int r = 1; r < 4; ++r) {
-      const int idx = 4 * (HT - 1) + r;
-      out[t][idx] = (idx == ONE_KS && (lane >> 4) == ONE_LG) ? 1.0 : 0.0;
+      for (int i = 0; i <= 4 * (HT - 1); ++i) out[0][i] = out1[0][i];
     }
-  if constexpr (ONE_KS >= 0 && ONE_KS == 4 * (HT - 1)) {
-    // the constant shares the k-step of the partial tile (50 = 48 + 2)
-    if ((lane >> 4) == ONE_LG) {
+  } else {
+    mlp_layer<1, SPLIT, KSMAX, HT, RELU, KS_LO, KS_HI>(w, ks_n, in, lane,
+                                                       out);
+  }
+  if constexpr (KS_HI == KSMAX) {
+    // registers 1..3 of the last tile: zero padding, except the constant 1
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) out[t][ONE_KS] = 1.0;
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        const int idx = 4 * (HT - 1) + r;
+        out[t][idx] = (idx == ONE_KS && (lane >> 4) == ONE_LG) ? 1.0 : 0.0;
+      }
+    if constexpr (ONE_KS >= 0 && ONE_KS == 4 * (HT - 1)) {
+      // the constant shares the k-step of the partial tile (50 = 48 + 2)
+      if ((lane >> 4) == ONE_LG) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) out[t][ONE_KS] = 1.0;
+      }
     }
   }
 }
@@ -289,6 +299,8 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   constexpr bool DBUF = (VARIANT == 1);
   constexpr int DP = 16 * DT;
   constexpr int KS1MAX = 4 * DT + 1;
+  // output tiles per block of the MLP layers (register budget, see mlp_layer)
+  constexpr int SPLIT = DT <= 2 ? NB_SPLIT_LO : (DT <= 4 ? NB_SPLIT_4 : NB_SPLIT_HI);
   constexpr int TS = 4 * KS1MAX + 1;        // LDS row stride of a gathered point
   extern __shared__ __attribute__((aligned(16))) double wlds[];
   __shared__ int wcnt[NW];
@@ -304,6 +316,13 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   const int n_dim = (int)nb_hdr(blob0, NB_H_NDIM);
   const int ks1 = (n_dim + 1 + 3) >> 2;
 
+#ifdef NB_DBG_TIMING
+  long long t_prev = clock64();
+#define NB_TS(i) do { if (a.counters != nullptr && threadIdx.x == 0 && blockIdx.x == 0) { \
+    const long long t_now = clock64(); a.counters[8 + (i)] += t_now - t_prev; t_prev = t_now; } } while (0)
+#else
+#define NB_TS(i)
+#endif
   for (long long sup = blockIdx.x; sup < n_super; sup += gridDim.x) {
     long long pt[TPW];
     bool valid[TPW];
@@ -422,6 +441,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       }
       }
 
+      NB_TS(0);
       bool outer_ok[TPW], acc_outer[TPW], neural_ok[TPW], want[TPW];
       bool any_want = false;
 #pragma unroll
@@ -463,6 +483,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             __syncthreads();
             ell_eval<DT, TPW>(wlds, n_dim, xin, lane, y, box_bad, r2);
           }
+          NB_TS(1);
           bool wave_need = false;
 #pragma unroll
           for (int t = 0; t < TPW; ++t) {
@@ -580,6 +601,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               issue(0, 0, 0);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               __syncthreads();
+              NB_TS(2);
               int q = 0;
               for (int e = 0; e < E; ++e) {
 #pragma unroll
@@ -590,33 +612,35 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                   if (wave_mlp) {
                     if (st == 0) {
                       if constexpr (TWO)
-                        l1_part<0, 4 * KA, true, false>(cur, ks1, tin[0], lane,
-                                                        h1[0]);
+                        mlp_tiles<TPW, SPLIT, KS1MAX, NB_HT1, true, 25, 0, 0,
+                                  4 * KA>(cur, ks1, tin, lane, h1, true);
                       else
-                        mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
-                            cur, ks1, tin, lane, h1, true);      // unit 100
+                        mlp_tiles<TPW, SPLIT, KS1MAX, NB_HT1, true, 25, 0>(
+                            cur, ks1, tin, lane, h1, true);  // unit 100
                     } else if (TWO && st == 1) {
                       if constexpr (TWO)
-                        l1_part<4 * KA, KS1MAX, false, true>(cur, ks1, tin[0],
-                                                             lane, h1[0]);
+                        mlp_tiles<TPW, SPLIT, KS1MAX, NB_HT1, true, 25, 0,
+                                  4 * KA, KS1MAX>(cur, ks1, tin, lane, h1, true);
                     } else {
                       const double* w2 = cur;
                       const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
                       const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
                       double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3],
                           o[TPW][4];
-                      mlp_tiles<TPW, 26, NB_HT2, true, 12, 2>(
-                          w2, 26, h1, lane, h2, true);           // unit 50
-                      mlp_tiles<TPW, 13, NB_HT3, true, 5, 0>(
-                          w3, 13, h2, lane, h3, true);           // unit 20
-                      mlp_tiles<TPW, 6, 1, false, -1, 0>(w4, 6, h3, lane, o,
-                                                         true);
+                      mlp_tiles<TPW, SPLIT, 26, NB_HT2, true, 12, 2>(
+                          w2, 26, h1, lane, h2, true);     // unit 50
+                      mlp_tiles<TPW, SPLIT, 13, NB_HT3, true, 5, 0>(
+                          w3, 13, h2, lane, h3, true);     // unit 20
+                      mlp_tiles<TPW, SPLIT, 6, 1, false, -1, 0>(
+                          w4, 6, h3, lane, o, true);
 #pragma unroll
                       for (int t = 0; t < TPW; ++t) total[t] += o[t][0];
                     }
                   }
+                  NB_TS(3 + 2 * (q & 1));
                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                   __syncthreads();
+                  NB_TS(4 + 2 * (q & 1));
                 }
               }
             } else {
@@ -627,7 +651,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                 stage_weights<NW>(w1, wlds, n_a);
                 __syncthreads();
                 if (wave_mlp)
-                  mlp_tiles<TPW, KS1MAX, NB_HT1, true, 25, 0>(
+                  mlp_tiles<TPW, SPLIT, KS1MAX, NB_HT1, true, 25, 0>(
                       wlds, ks1, tin, lane, h1, two_tiles);
                 __syncthreads();
                 stage_weights<NW>(w1 + n_a, wlds, n_b);
@@ -637,12 +661,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                   const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
                   const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
                   double h2[TPW][4 * NB_HT2], h3[TPW][4 * NB_HT3], o[TPW][4];
-                  mlp_tiles<TPW, 26, NB_HT2, true, 12, 2>(w2, 26, h1, lane, h2,
-                                                          two_tiles);
-                  mlp_tiles<TPW, 13, NB_HT3, true, 5, 0>(w3, 13, h2, lane, h3,
-                                                         two_tiles);
-                  mlp_tiles<TPW, 6, 1, false, -1, 0>(w4, 6, h3, lane, o,
-                                                     two_tiles);
+                  mlp_tiles<TPW, SPLIT, 26, NB_HT2, true, 12, 2>(
+                      w2, 26, h1, lane, h2, two_tiles);
+                  mlp_tiles<TPW, SPLIT, 13, NB_HT3, true, 5, 0>(
+                      w3, 13, h2, lane, h3, two_tiles);
+                  mlp_tiles<TPW, SPLIT, 6, 1, false, -1, 0>(
+                      w4, 6, h3, lane, o, two_tiles);
                   total[0] += o[0][0];             // unit 0 lives in lg == 0
                   if constexpr (TPW == 2) {
                     if (two_tiles) total[1] += o[1][0];
@@ -697,6 +721,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       }
     }
 
+    NB_TS(7);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       if (valid[t] && lg == 0) {
@@ -712,6 +737,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       }
     }
   }
+  NB_TS(8);
   if (a.counters != nullptr && lane == 0) {
     atomicAdd(&a.counters[0], cnt_outer);
     atomicAdd(&a.counters[1], cnt_ell);
