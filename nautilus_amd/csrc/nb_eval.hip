@@ -358,11 +358,34 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           (off_shift != 0 && (a.mode == MODE_ANY || a.mode == MODE_ASSOC))
               ? blob + off_shift : nullptr;
 
+      // Dense variant, proposals and scores (nearly every point reaches the
+      // emulator): the ellipsoid block of the first neural bound goes to
+      // region B and layer 1 of its first network to region A by DMA, issued
+      // before the points are loaded so that all three overlap.  Only if no
+      // outer member is staged in between, and only for n_dim <= 64 (beyond,
+      // keeping the points in registers until the ellipsoid test spills).
+      const double* nblk = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
+      const int kt1 = (int)nb_hdr(blob, NB_H_KT1);
+      const int n_a = kt1 * NB_HT1 * NB_TILE;                   // layer 1
+      constexpr int KA = (DT + 2) / 2;                  // k-tiles of chunk A
+      const int n_a0 = (DT >= 5) ? KA * NB_HT1 * NB_TILE : n_a;
+      const bool ell_dma = DBUF && nb_ell_block_size(DT) + 128 <= w_doubles;
+      const bool early = ell_dma && M > 0 && E > 0 &&
+                         (a.mode == MODE_SAMPLE || a.mode == MODE_SCORE);
+      const bool pre = DT <= 4 && early &&
+                       (K == 0 || (a.mode == MODE_SAMPLE && K == 1));
+      if (pre) {
+        __syncthreads();                               // LDS free
+        dma_weights<NW>(nblk, tlds, nb_ell_block_size(DT), wave, lane);
+        dma_weights<NW>(nblk + nb_ell_block_size(DT) + 2 + 2 * DP, wlds, n_a0,
+                        wave, lane);
+      }
+
       // unit-cube clip of the union (union.py:287-288 / 313-314)
       bool in_cube[TPW], active[TPW];
       int k_cnt[TPW];
+      double xin[TPW][4 * DT];
       {
-        double xin[TPW][4 * DT];
         load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
 
         // Bounding-sphere pre-test (shell exclusion / association): a point
@@ -466,17 +489,27 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
 
       // ---- neural bounds (workgroup-uniform control flow) --------------
       if (M > 0 && __syncthreads_or(any_want ? 1 : 0)) {
-        const double* nblk = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
-        const int kt1 = (int)nb_hdr(blob, NB_H_KT1);
         const long long net_stride = nb_hdr(blob, NB_H_NET_STRIDE);
-        const int n_a = kt1 * NB_HT1 * NB_TILE;                 // layer 1
         const int n_b = (NB_HT1 * NB_HT2 + NB_HT2 * NB_HT3 + NB_HT3) * NB_TILE;
         for (int m = 0; m < M; ++m) {
           const double* nb_m = nblk + m * neural_stride;
           double y[TPW][4 * DT], r2[TPW];
           bool box_bad[TPW], inside_e[TPW], need[TPW];
-          {
-            double xin[TPW][4 * DT];
+          const double* nets =
+              nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
+          if (ell_dma) {
+            // (m == 0 of a pre-issued bound: copies in flight, points loaded)
+            if (!(pre && m == 0)) {
+              __syncthreads();                         // LDS free
+              dma_weights<NW>(nb_m, tlds, nb_ell_block_size(DT), wave, lane);
+              if (early) dma_weights<NW>(nets, wlds, n_a0, wave, lane);
+              load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin,
+                                   shift);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ell_eval<DT, TPW>(tlds, n_dim, xin, lane, y, box_bad, r2);
+          } else {
             load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
             __syncthreads();
             stage_weights<NW>(nb_m, wlds, nb_ell_block_size(DT));
@@ -512,21 +545,26 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             bal[t] = __ballot(need[t] && lg == 0);
             cnt_w += __popcll(bal[t]);
           }
-          __syncthreads();
-          if (lane == 0) wcnt[wave] = cnt_w;
-          __syncthreads();
           int base = 0, n_need = 0;
+          if constexpr (COMPACT) {
+            __syncthreads();
+            if (lane == 0) wcnt[wave] = cnt_w;
+            __syncthreads();
 #pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            if (w < wave) base += wcnt[w];
-            n_need += wcnt[w];
+            for (int w = 0; w < NW; ++w) {
+              if (w < wave) base += wcnt[w];
+              n_need += wcnt[w];
+            }
+          } else {
+            // (also the barrier between the ellipsoid block's readers and the
+            // first weight DMA into its region)
+            n_need = __syncthreads_or(cnt_w > 0 ? 1 : 0);
           }
 
           if (E > 0 && n_need > 0) {
             const double thr = nb_m[nb_ell_block_size(DT)];
             const double* mean = nb_m + nb_ell_block_size(DT) + 2;
             const double* scale = mean + DP;
-            const double* nets = scale + DP;
             // standardised input (neural.py:115), constant 1 at column D
             double tin[TPW][KS1MAX];
 #pragma unroll
@@ -585,9 +623,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               // (two K chunks for n_dim > 64, where it exceeds a region), then
               // layers 2-4.
               constexpr bool TWO = (DT >= 5);
-              constexpr int KA = (DT + 2) / 2;          // k-tiles of chunk A
               constexpr int NST = TWO ? 3 : 2;
-              const int n_a0 = TWO ? KA * NB_HT1 * NB_TILE : n_a;
               double* reg[2] = {wlds, tlds};
               double h1[TPW][4 * NB_HT1];
               auto issue = [&](int e, int st, int q) {
@@ -597,10 +633,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                   dma_weights<NW>(w1 + n_a0, reg[q & 1], n_a - n_a0, wave, lane);
                 else dma_weights<NW>(w1 + n_a, reg[q & 1], n_b, wave, lane);
               };
-              __syncthreads();
-              issue(0, 0, 0);
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              __syncthreads();
+              if (!early) {
+                __syncthreads();
+                issue(0, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+              }
               NB_TS(2);
               int q = 0;
               for (int e = 0; e < E; ++e) {
@@ -699,6 +737,13 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           }
 #pragma unroll
           for (int t = 0; t < TPW; ++t) neural_ok[t] |= ok[t];
+          // the points are re-read for the next member: end their live range
+          // here so that they do not occupy registers during the MLP
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4 * DT; ++ks)
+              asm volatile("" : "=v"(xin[t][ks]));
         }
       }
 
