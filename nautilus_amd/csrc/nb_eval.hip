@@ -292,9 +292,17 @@ __device__ __forceinline__ void stage_weights(const double* __restrict__ src,
 // VARIANT 0 gather, 1 dense + DMA double buffer.  NW wavefronts x TPW tiles =
 // 128 points per workgroup pass: 4 x 2 (every A operand feeds two tiles) or
 // 8 x 1 (two wavefronts per SIMD hide each other's LDS and barrier waits).
-template <int DT, int VARIANT, int TPW, int NW>
+template <int DT, int VARIANT, int TPW, int NW, bool SPARSE>
 __global__ void __launch_bounds__(64 * NW)
 nb_eval_kernel(EvalArgs a, int w_doubles) {
+  // SPARSE: containment / association (MODE_ANY, MODE_ASSOC), where few
+  // points reach an emulator; otherwise proposals, overlap counts and scores.
+  // Compile-time so that neither instantiation carries the other's state.
+  const bool m_any = SPARSE && a.mode == MODE_ANY;
+  const bool m_assoc = SPARSE && a.mode == MODE_ASSOC;
+  const bool m_sample = !SPARSE && a.mode == MODE_SAMPLE;
+  const bool m_count = !SPARSE && a.mode == MODE_COUNT;
+  const bool m_score = !SPARSE && a.mode == MODE_SCORE;
   constexpr bool COMPACT = (VARIANT == 0);
   constexpr bool DBUF = (VARIANT == 1);
   constexpr int DP = 16 * DT;
@@ -355,7 +363,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       // proposals (SAMPLE / COUNT / SCORE) already live in the shifted frame
       const long long off_shift = nb_hdr(blob, NB_H_OFF_SHIFT);
       const double* shift =
-          (off_shift != 0 && (a.mode == MODE_ANY || a.mode == MODE_ASSOC))
+          (off_shift != 0 && SPARSE)
               ? blob + off_shift : nullptr;
 
       // Dense variant, proposals and scores (nearly every point reaches the
@@ -371,9 +379,9 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       const int n_a0 = (DT >= 5) ? KA * NB_HT1 * NB_TILE : n_a;
       const bool ell_dma = DBUF && nb_ell_block_size(DT) + 128 <= w_doubles;
       const bool early = ell_dma && M > 0 && E > 0 &&
-                         (a.mode == MODE_SAMPLE || a.mode == MODE_SCORE);
+                         (m_sample || m_score);
       const bool pre = DT <= 4 && early &&
-                       (K == 0 || (a.mode == MODE_SAMPLE && K == 1));
+                       (K == 0 || (m_sample && K == 1));
       if (pre) {
         __syncthreads();                               // LDS free
         dma_weights<NW>(nblk, tlds, nb_ell_block_size(DT), wave, lane);
@@ -393,7 +401,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
         // hence within sqrt(radius2) of that centre.  If no undecided point
         // of the workgroup passes this test the whole bound is skipped --
         // for nested bounds in high dimension all but the next few bounds.
-        if ((a.mode == MODE_ANY || a.mode == MODE_ASSOC) && M > 0) {
+        if (SPARSE && M > 0) {
           const double* nblk0 = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
           bool maybe = false;
           for (int m = 0; m < M; ++m) {
@@ -440,7 +448,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
 #pragma unroll
       for (int t = 0; t < TPW; ++t) k_cnt[t] = 0;
       const double* mblk = blob + nb_hdr(blob, NB_H_OFF_MEMBERS);
-      if (a.mode == MODE_SAMPLE && K == 1) {
+      if (m_sample && K == 1) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) k_cnt[t] = 1;   // drawn from the only member
       } else {
@@ -472,7 +480,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
         outer_ok[t] = in_cube[t] && (K == 0 || k_cnt[t] > 0);
         // acceptance of the overlap-corrected union draw (union.py:318-319)
         acc_outer[t] = false;
-        if (a.mode == MODE_SAMPLE) {
+        if (m_sample) {
           double u0, u_acc;
           nb_uniform_pair(a.seed, a.offset + (unsigned long long)pt[t], 0u,
                           NB_TAG_CTRL, u0, u_acc);
@@ -480,9 +488,9 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                          (u_acc > 1.0 - 1.0 / (double)k_cnt[t]);
         }
         neural_ok[t] = (M == 0);
-        if (a.mode == MODE_SAMPLE) want[t] = valid[t] && acc_outer[t];
-        else if (a.mode == MODE_SCORE) want[t] = valid[t];
-        else if (a.mode == MODE_COUNT) want[t] = false;
+        if (m_sample) want[t] = valid[t] && acc_outer[t];
+        else if (m_score) want[t] = valid[t];
+        else if (m_count) want[t] = false;
         else want[t] = active[t] && outer_ok[t];
         any_want |= want[t];
       }
@@ -522,7 +530,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           for (int t = 0; t < TPW; ++t) {
             inside_e[t] = !box_bad[t] && r2[t] < 1.0;
             need[t] = want[t] && inside_e[t] && !neural_ok[t];
-            if (a.mode == MODE_SCORE) need[t] = valid[t];
+            if (m_score) need[t] = valid[t];
 #ifdef NB_DBG_NO_MLP
             need[t] = false;                       // dev experiment only
 #endif
@@ -751,17 +759,17 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         const bool contained = outer_ok[t] && neural_ok[t];
-        if (a.mode == MODE_ANY || a.mode == MODE_ASSOC) {
+        if (SPARSE) {
           if (active[t] && contained) { hit[t] = true; hit_idx[t] = b; }
           all_done &= (hit[t] || !valid[t]);
-        } else if (a.mode == MODE_SAMPLE) {
+        } else if (m_sample) {
           flags[t] = (acc_outer[t] ? 1 : 0) |
                      ((acc_outer[t] && neural_ok[t]) ? 2 : 0);
-        } else if (a.mode == MODE_COUNT) {
+        } else if (m_count) {
           count_out[t] = k_cnt[t];
         }
       }
-      if (a.mode == MODE_ANY || a.mode == MODE_ASSOC) {
+      if (SPARSE) {
         if (__syncthreads_and(all_done ? 1 : 0)) break;
       }
     }
@@ -770,12 +778,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       if (valid[t] && lg == 0) {
-        if (a.mode == MODE_ANY) a.out_u8[pt[t]] = hit[t] ? 1 : 0;
-        else if (a.mode == MODE_ASSOC) a.out_i32[pt[t]] = hit_idx[t];
-        else if (a.mode == MODE_SAMPLE) a.out_u8[pt[t]] = flags[t];
-        else if (a.mode == MODE_COUNT)
+        if (m_any) a.out_u8[pt[t]] = hit[t] ? 1 : 0;
+        else if (m_assoc) a.out_i32[pt[t]] = hit_idx[t];
+        else if (m_sample) a.out_u8[pt[t]] = flags[t];
+        else if (m_count)
           a.out_u8[pt[t]] = (unsigned char)count_out[t];
-        else if (a.mode == MODE_SCORE) {
+        else if (m_score) {
           a.out_f64[2 * pt[t]] = r2_out[t];
           a.out_f64[2 * pt[t] + 1] = score_out[t];
         }
@@ -790,7 +798,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   }
 }
 
-template <int DT, int VARIANT, int TPW, int NW>
+template <int DT, int VARIANT, int TPW, int NW, bool SPARSE>
 int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   constexpr bool COMPACT = (VARIANT == 0);
   constexpr int TS = 4 * (4 * DT + 1) + 1;
@@ -804,7 +812,7 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   static size_t lds_allowed = 0;
   if (lds > lds_allowed) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_kernel<DT, VARIANT, TPW, NW>,
+        (const void*)nb_eval_kernel<DT, VARIANT, TPW, NW, SPARSE>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -820,7 +828,7 @@ int launch_eval_impl(const EvalArgs& a, int lds_tiles, hipStream_t stream) {
   long long blocks = n_super;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT, TPW, NW>),
+  hipLaunchKernelGGL((nb_eval_kernel<DT, VARIANT, TPW, NW, SPARSE>),
                      dim3((unsigned)blocks), dim3(64 * NW), lds, stream, a,
                      w_doubles);
   return NB_OK;
@@ -843,17 +851,19 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   // weight streaming is 3 % faster end to end, so it is the default;
   // NB_EVAL_GATHER=1 selects the gathered kernel for the sparse modes.
   const size_t need = ((size_t)gather_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
-  const bool sparse_mode = (a.mode == MODE_ANY || a.mode == MODE_ASSOC) &&
-                           getenv("NB_EVAL_GATHER") != nullptr;
+  const bool sparse = (a.mode == MODE_ANY || a.mode == MODE_ASSOC);
   // two tiles per wavefront up to n_dim = 64; beyond that the per-lane state
   // (y, standardised input, hidden activations of two tiles) no longer fits
   // the register file
   constexpr int TPW = (DT <= 4) ? 2 : 1;
-  if (sparse_mode && DT <= 4 && need <= 160 * 1024)
-    return launch_eval_impl<DT, 0, TPW, 4>(a, gather_tiles, stream);
+  if constexpr (DT <= 4) {
+    if (sparse && getenv("NB_EVAL_GATHER") != nullptr && need <= 160 * 1024)
+      return launch_eval_impl<DT, 0, TPW, 4, true>(a, gather_tiles, stream);
+  }
   // (8 wavefronts x 1 tile was measured as well: +7 % at D = 20, -2 % at
   // D = 50, where the 256-register budget per wavefront forces ~100 spills)
-  return launch_eval_impl<DT, 1, TPW, 4>(a, lds_tiles, stream);
+  if (sparse) return launch_eval_impl<DT, 1, TPW, 4, true>(a, lds_tiles, stream);
+  return launch_eval_impl<DT, 1, TPW, 4, false>(a, lds_tiles, stream);
 }
 
 }  // namespace
