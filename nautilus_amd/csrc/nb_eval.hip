@@ -88,6 +88,9 @@ enum { MODE_ANY = 0, MODE_ASSOC = 1, MODE_SAMPLE = 2, MODE_COUNT = 3,
 // A layer whose weights exceed an LDS region (layer 1 for n_dim > 64) runs in
 // K chunks [KS_LO, KS_HI): `out` carries the pre-activations between them, w
 // is the chunk in LDS (k-tile index relative to KS_LO / 4).
+#ifndef NB_PRE_DT
+#define NB_PRE_DT 3
+#endif
 #ifndef NB_SPLIT_LO
 #define NB_SPLIT_LO 8
 #endif
@@ -370,8 +373,9 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       // emulator): the ellipsoid block of the first neural bound goes to
       // region B and layer 1 of its first network to region A by DMA, issued
       // before the points are loaded so that all three overlap.  Only if no
-      // outer member is staged in between, and only for n_dim <= 64 (beyond,
-      // keeping the points in registers until the ellipsoid test spills).
+      // outer member is staged in between, and only for n_dim <= 48 (beyond,
+      // keeping the points in registers until the ellipsoid test spills:
+      // measured 2 % slower at n_dim = 50).
       const double* nblk = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
       const int kt1 = (int)nb_hdr(blob, NB_H_KT1);
       const int n_a = kt1 * NB_HT1 * NB_TILE;                   // layer 1
@@ -380,7 +384,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       const bool ell_dma = DBUF && nb_ell_block_size(DT) + 128 <= w_doubles;
       const bool early = ell_dma && M > 0 && E > 0 &&
                          (m_sample || m_score);
-      const bool pre = DT <= 4 && early &&
+      const bool pre = DT <= NB_PRE_DT && early &&
                        (K == 0 || (m_sample && K == 1));
       if (pre) {
         __syncthreads();                               // LDS free
