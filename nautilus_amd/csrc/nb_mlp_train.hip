@@ -207,10 +207,49 @@ __device__ __forceinline__ nb_d4 bwd_tile(const double* __restrict__ w,
   return acc;
 }
 
+// The rows of a tile's minibatch slice: permutation entry, the k-steps of the
+// input block this wavefront fills (ks % 4 == wave) and the target.  Read-only
+// data, so the resident kernel fetches the NEXT step's rows while it waits at
+// the barrier that ends the current one (two dependent global latencies off
+// the critical path).
 template <int DT>
+struct FbRows {
+  long long row;
+  double x[DT + 1];
+  double yv;
+};
+
+template <int DT>
+__device__ __forceinline__ void fb_gather(const TrainArgs& a, int net, int tile,
+                                          int ep, long long start, int nb,
+                                          FbRows<DT>& in) {
+  constexpr int KS1MAX = 4 * DT + 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int D = a.n_dim, ld0 = 16 * a.kt1;
+  const int* perm = a.perm + ((long long)net * a.n_epochs + ep) * a.n;
+  const int pt = tile * 16 + li;
+  const bool valid = pt < nb;
+  in.row = valid ? perm[start + pt] : 0;
+#pragma unroll
+  for (int j = 0; j < DT + 1; ++j) {
+    const int ks = 4 * j + wave;
+    const int f = 4 * ks + lg;
+    double v = 0.0;
+    if (ks < KS1MAX && 4 * ks < ld0)
+      v = (f < D) ? (valid ? a.X[in.row * D + f] : 0.0)
+                  : ((f == D) ? 1.0 : 0.0);
+    in.x[j] = v;
+  }
+  in.yv = (wave == 0 && lg == 0 && valid) ? a.y[in.row] : 0.0;
+}
+
+template <int DT, bool CHECK_DONE>
 __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
                                         int net, int tile, int ep,
-                                        long long start, int nb) {
+                                        long long start, int nb,
+                                        const FbRows<DT>& rows) {
   constexpr int KS1MAX = 4 * DT + 1;
   constexpr int LD0MAX = 16 * (DT + 1);
   // activations / deltas of the tile in [unit][row] layout
@@ -222,15 +261,15 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   __shared__ __attribute__((aligned(16))) double sD3[LD3 * LS];
   __shared__ __attribute__((aligned(16))) double sD2[LD2 * LS];
 
-  if (st.scal[4] != 0.0) return;                 // network already stopped
+  if (CHECK_DONE) {
+    if (st.scal[4] != 0.0) return;               // network already stopped
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int D = a.n_dim, kt1 = a.kt1;
   const int ld0 = 16 * kt1;
   const int ks1 = (D + 1 + 3) >> 2;
-  const long long n = a.n;
-  const int* perm = a.perm + ((long long)net * a.n_epochs + ep) * n;
 
   double* W1 = st.W;
   double* W2 = W1 + kt1 * NB_HT1 * NB_TILE;
@@ -247,7 +286,6 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 
   const int pt = tile * 16 + li;
   const bool valid = pt < nb;
-  const long long row = valid ? perm[start + pt] : 0;
 
   // ---- every weight operand this wavefront will need, loaded up front: the
   // loads do not depend on the other wavefronts, so their latency overlaps
@@ -271,13 +309,9 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   for (int i = threadIdx.x; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
   __syncthreads();
 #pragma unroll
-  for (int ks = 0; ks < KS1MAX; ++ks) {
-    if ((ks & 3) == wave && 4 * ks < ld0) {
-      const int f = 4 * ks + lg;
-      const double v = (f < D) ? (valid ? a.X[row * D + f] : 0.0)
-                               : ((f == D) ? 1.0 : 0.0);
-      sA0[f * LS + li] = v;
-    }
+  for (int j = 0; j < DT + 1; ++j) {
+    const int ks = 4 * j + wave;
+    if (ks < KS1MAX && 4 * ks < ld0) sA0[(4 * ks + lg) * LS + li] = rows.x[j];
   }
   __syncthreads();
 
@@ -338,7 +372,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     lds_operand<6>(sA3, lane, in);
     const nb_d4 acc = mma<6>(w4r, in);
     double d40 = 0.0;
-    if (lg == 0 && valid) d40 = acc[0] - a.y[row];   // sklearn :365
+    if (lg == 0 && valid) d40 = acc[0] - rows.yv;    // sklearn :365
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int unit = 4 * r + lg;
@@ -415,14 +449,29 @@ template <int DT>
 __global__ void __launch_bounds__(256)
 nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   const NetState st = a.nets[blockIdx.y];
-  fb_body<DT>(a, st, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb);
+  FbRows<DT> rows;
+  fb_gather<DT>(a, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb, rows);
+  fb_body<DT, true>(a, st, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb,
+                    rows);
 }
 
 // ---- G: dW of one 16x16 weight tile over the minibatch + Adam, one wavefront
+// the step's loss partials folded into the epoch sum, in tile order
+// (deterministic); one lane
+__device__ __forceinline__ void loss_fold(const NetState& st, int nb) {
+  const int n_tiles = (nb + 15) >> 4;
+  double acc = st.scal[5];
+  for (int i = 0; i < n_tiles; ++i) acc += st.scal[8 + i];
+  st.scal[5] = acc;
+}
+
+template <bool STANDALONE>
 __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
                                        int gt, int lane, int nb,
                                        long long t_adam) {
-  if (st.scal[4] != 0.0) return;
+  if (STANDALONE) {
+    if (st.scal[4] != 0.0) return;
+  }
   const int li = lane & 15, lg = lane >> 4;
   const int kt1 = a.kt1;
   const int ld0 = 16 * kt1;
@@ -439,13 +488,9 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
   const double* D3 = D2 + MAXB * LD2;
   const double* D4 = D3 + MAXB * LD3;
 
-  // the first workgroup also folds the step's loss into the epoch sum, in
-  // tile order (deterministic)
-  if (gt == 0 && lane == 0) {
-    double acc = st.scal[5];
-    for (int i = 0; i < n_tiles; ++i) acc += st.scal[8 + i];
-    st.scal[5] = acc;
-  }
+  // two-launch form: the first workgroup also folds the step's loss (the
+  // resident kernel gives that to an otherwise idle wavefront)
+  if (STANDALONE && gt == 0 && lane == 0) loss_fold(st, nb);
 
   const double* As; const double* Bs; int lda, ldb, kt, ht;
   long long woff;
@@ -480,6 +525,13 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
     av[s] = on ? ap[(long long)s * 4 * lda] : 0.0;
     bv[s] = on ? bp[(long long)s * 4 * ldb] : 0.0;
   }
+  // ... including the tile's weights and Adam moments
+  double w_old[4], m_old[4], v_old[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long idx = woff + (lg + 4 * r) * 16 + li;
+    w_old[r] = st.W[idx]; m_old[r] = st.M[idx]; v_old[r] = st.V[idx];
+  }
   nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
   for (int s = 0; s < MAXS; s += 2) {
@@ -495,18 +547,18 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
   for (int r = 0; r < 4; ++r) {
     const long long idx = woff + (lg + 4 * r) * 16 + li;
     const double g = (acc0[r] + acc1[r]) * inv_nb;
-    const double m = a.b1 * st.M[idx] + (1.0 - a.b1) * g;
-    const double v = a.b2 * st.V[idx] + (1.0 - a.b2) * (g * g);
+    const double m = a.b1 * m_old[r] + (1.0 - a.b1) * g;
+    const double v = a.b2 * v_old[r] + (1.0 - a.b2) * (g * g);
     st.M[idx] = m;
     st.V[idx] = v;
-    st.W[idx] += -lr_t * m / (sqrt(v) + a.eps);
+    st.W[idx] = w_old[r] + -lr_t * m / (sqrt(v) + a.eps);
   }
 }
 
 __global__ void __launch_bounds__(64)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
   const NetState st = a.nets[blockIdx.y];
-  g_body(a, st, (int)blockIdx.x, (int)threadIdx.x, nb, t_adam);
+  g_body<true>(a, st, (int)blockIdx.x, (int)threadIdx.x, nb, t_adam);
 }
 
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
@@ -555,14 +607,21 @@ constexpr int XCD_SLOTS = 17;            // workgroups per network
 constexpr int SYNC_WORDS = 4;            // counter, error, xcc mask, pad
 constexpr int SYNC_LIMIT = 1 << 22;
 
-__device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
-                                            int n_wg) {
+// (split into arrive / wait so that read-only prefetches can be issued in
+// between: after the workgroup has signalled, before it starts polling)
+__device__ __forceinline__ void xcd_arrive(int* counter) {
   __syncthreads();
   if (threadIdx.x == 0) {
     // stores of this workgroup are in L2 once the counters drain
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ void xcd_wait(int* counter, int* err, int& phase,
+                                         int n_wg) {
+  if (threadIdx.x == 0) {
     const int target = (++phase) * n_wg;
     int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED,
@@ -577,6 +636,12 @@ __device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+}
+
+__device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
+                                            int n_wg) {
+  xcd_arrive(counter);
+  xcd_wait(counter, err, phase, n_wg);
 }
 
 struct XcdMap {
@@ -628,6 +693,8 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
     }
   }
   long long t_adam = t_adam0;
+  FbRows<DT> rows;
+  bool have_rows = false;        // rows = the slice of the step about to run
   for (int ep = 0; ep < a.n_epochs; ++ep) {
     // uniform over the network's workgroups: the flag only changes in
     // epoch_body, which is followed by a barrier
@@ -637,11 +704,27 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
       t_adam += 1;
       if (done) continue;
-      if (slot * 16 < nb) fb_body<DT>(a, st, net, slot, ep, start, nb);
+      if (slot * 16 < nb) {
+        if (!have_rows) fb_gather<DT>(a, net, slot, ep, start, nb, rows);
+        fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows);
+      }
       xcd_barrier(counter, err, phase, XCD_SLOTS);
-      for (int gt = slot * 4 + wave; gt < n_gt; gt += XCD_SLOTS * 4)
-        g_body(a, st, gt, lane, nb, t_adam);
-      xcd_barrier(counter, err, phase, XCD_SLOTS);
+      // weight tiles 0 .. n_gt - 1, task n_gt = the loss fold
+      for (int gt = slot * 4 + wave; gt <= n_gt; gt += XCD_SLOTS * 4) {
+        if (gt < n_gt) g_body<false>(a, st, gt, lane, nb, t_adam);
+        else if (lane == 0) loss_fold(st, nb);
+      }
+      xcd_arrive(counter);
+      {
+        // rows of the next step (next epoch's permutation after the last one)
+        const bool last = sidx + 1 == steps;
+        const int ep2 = last ? ep + 1 : ep;
+        const long long start2 = last ? 0 : start + a.batch;
+        const int nb2 = (int)((n - start2 < a.batch) ? (n - start2) : a.batch);
+        have_rows = ep2 < a.n_epochs && slot * 16 < nb2;
+        if (have_rows) fb_gather<DT>(a, net, slot, ep2, start2, nb2, rows);
+      }
+      xcd_wait(counter, err, phase, XCD_SLOTS);
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
         return;
