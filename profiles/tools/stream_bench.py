@@ -1,0 +1,21 @@
+import sys, time; sys.path.insert(0,'tests'); sys.path.insert(0,'.')  # run from the repo root
+import numpy as np, torch
+from helpers import upload
+from oracle import bounds_oracle as bo
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter()-t)/n
+for d in (7, 33, 49, 50, 63, 64, 99, 100):
+    rng = np.random.default_rng(d)
+    A = rng.normal(size=(d,d)); cov = A@A.T/d + np.eye(d); B = np.linalg.cholesky(cov*0.02)
+    ell = bo.OEllipsoid.from_params(0.5*np.ones(d), B)
+    b = upload(ell)
+    n = 1<<23
+    x = torch.rand((n,d), dtype=torch.float64, device='cuda')
+    x[::2] = 0.5 + 0.6*(x[::2]-0.5)
+    m1 = b.contains_stream(x); m2 = b.contains(x[:200000])
+    t1 = timeit(lambda: b.contains_stream(x))
+    gb = n*(8*d+1)/1e9
+    print('D=%d stream: %.3f ms %.1f GB/s (%.1f%% of 8TB/s) %.2f Gpt/s  mismatch vs mfma %d inside %.3f' % (d, t1*1e3, gb/t1, gb/t1/80, n/t1/1e9, int((m1[:200000]!=m2).sum()), float(m1.double().mean())))
