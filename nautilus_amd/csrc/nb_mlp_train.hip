@@ -129,12 +129,12 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
 }
 
 // cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows)
+// (n_unit is a multiple of 16: thread -> row tid / 16, 16 consecutive units)
 __device__ __forceinline__ void flush_stash(const double* act, double* dst,
                                             int ld, int n_unit, int tile) {
-  for (int i = threadIdx.x; i < 16 * n_unit; i += 256) {
-    const int r = i / n_unit, u = i - r * n_unit;
-    dst[(long long)(tile * 16 + r) * ld + u] = act[u * LS + r];
-  }
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  double* row = dst + (long long)(tile * 16 + r) * ld;
+  for (int u = c; u < n_unit; u += 16) row[u] = act[u * LS + r];
 }
 
 // A operands of one forward output tile, loaded up front
@@ -465,10 +465,16 @@ __device__ __forceinline__ void loss_fold(const NetState& st, int nb) {
   st.scal[5] = acc;
 }
 
+// step size of Adam step t (sklearn _stochastic_optimizers.py:276-279)
+__device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) {
+  return a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
+         (1.0 - pow(a.b1, (double)t_adam));
+}
+
 template <bool STANDALONE>
 __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
                                        int gt, int lane, int nb,
-                                       long long t_adam) {
+                                       double lr_t) {
   if (STANDALONE) {
     if (st.scal[4] != 0.0) return;
   }
@@ -540,8 +546,6 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
   }
 
   // Adam (sklearn _stochastic_optimizers.py:255-287), in place
-  const double lr_t = a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
-                      (1.0 - pow(a.b1, (double)t_adam));
   const double inv_nb = 1.0 / (double)nb;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -558,7 +562,8 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
 __global__ void __launch_bounds__(64)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
   const NetState st = a.nets[blockIdx.y];
-  g_body<true>(a, st, (int)blockIdx.x, (int)threadIdx.x, nb, t_adam);
+  g_body<true>(a, st, (int)blockIdx.x, (int)threadIdx.x, nb,
+               adam_lr(a, t_adam));
 }
 
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
@@ -708,10 +713,13 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
         if (!have_rows) fb_gather<DT>(a, net, slot, ep, start, nb, rows);
         fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows);
       }
-      xcd_barrier(counter, err, phase, XCD_SLOTS);
+      // (the step size -- two pow() -- is computed while waiting)
+      xcd_arrive(counter);
+      const double lr_t = adam_lr(a, t_adam);
+      xcd_wait(counter, err, phase, XCD_SLOTS);
       // weight tiles 0 .. n_gt - 1, task n_gt = the loss fold
       for (int gt = slot * 4 + wave; gt <= n_gt; gt += XCD_SLOTS * 4) {
-        if (gt < n_gt) g_body<false>(a, st, gt, lane, nb, t_adam);
+        if (gt < n_gt) g_body<false>(a, st, gt, lane, nb, lr_t);
         else if (lane == 0) loss_fold(st, nb);
       }
       xcd_arrive(counter);
