@@ -120,6 +120,12 @@ __device__ __forceinline__ void put_stash(double* __restrict__ base, int ld,
 // ~100 instructions.
 constexpr int LS = 17;   // LDS row stride (odd: conflict-free both ways)
 
+// workgroup barrier that orders LDS traffic only: global loads already issued
+// (the weight operands of later layers) stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NREG>
 __device__ __forceinline__ void lds_operand(const double* act, int lane,
                                             double* in) {
@@ -291,29 +297,36 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   // loads do not depend on the other wavefronts, so their latency overlaps
   // with the input gather instead of being paid after every barrier --------
   double w1r[2][KS1MAX], w2r[26], w3r[13], w4r[6], b4r[1], b3r[5], b2r[2][13];
+  // (issued in the order of use: loads return in order and the barriers
+  // between the layers only wait for LDS, so a layer waits for its own
+  // operands while the later ones are still in flight)
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
     const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
     load_fwd<KS1MAX>(W1, NB_HT1, ht, ks1, lane, w1r[rep]);
-    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
   }
   load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
   load_fwd<13>(W3, NB_HT3, wave & 1, 13, lane, w3r);
   load_fwd<6>(W4, 1, 0, 6, lane, w4r);
   load_bwd<1>(W4, 1, wave & 1, lane, b4r);
   load_bwd<5>(W3, NB_HT3, wave, lane, b3r);
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
+    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
+  }
 
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
   // (all of it: rows >= ld0 are multiplied by zero weights and must not
   // hold NaN bit patterns)
   for (int i = threadIdx.x; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int j = 0; j < DT + 1; ++j) {
     const int ks = 4 * j + wave;
     if (ks < KS1MAX && 4 * ks < ld0) sA0[(4 * ks + lg) * LS + li] = rows.x[j];
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- layer 1: output tiles wave, wave + 4 ------------------------------
   {
@@ -334,7 +347,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- layer 2: output tile = wave ----------------------------------------
   {
@@ -349,7 +362,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       sA2[unit * LS + li] = v;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- layer 3: two output tiles ------------------------------------------
   if (wave < NB_HT3) {
@@ -364,7 +377,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       sA3[unit * LS + li] = v;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
   if (wave == 0) {
@@ -383,7 +396,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
     if (lane == 0) st.scal[8 + tile] = lp;
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
   if (wave < NB_HT3) {
@@ -398,7 +411,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       sD3[unit * LS + li] = v;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- delta 2 --------------------------------------------------------------
   {
@@ -413,7 +426,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       sD2[unit * LS + li] = v;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- delta 1 --------------------------------------------------------------
   {
