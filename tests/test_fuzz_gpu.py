@@ -138,3 +138,45 @@ def test_nested_nautilus_bounds(d, e, periodic):
         want[inside[i]] = i
     assert np.array_equal(first[~edge], want[~edge])
     assert 0.02 < inside.mean() < 0.98
+
+
+@pytest.mark.parametrize('d,e', [(12, 2), (33, 1), (40, 4), (48, 2), (50, 4),
+                                 (64, 1), (70, 2), (100, 1)])
+def test_nautilus_sample_dims(d, e):
+    """NautilusBound.sample (nautilus.py:199-224) in every size class of the
+    proposal path of the evaluation kernel (two / one tile per wavefront, the
+    pre-issued copies up to n_dim = 48): accepted points and counters against
+    the oracle, plus the emulator scores of the proposals."""
+    from oracle import bounds_oracle as bo
+    from oracle import mlp_oracle as mo
+    from oracle import philox
+    rng = np.random.default_rng(77 * d + e)
+    ell = bo.OEllipsoid.from_params(
+        np.full(d, 0.5) + rng.normal(size=d) * 0.01,
+        np.eye(d) * 0.2 + np.tril(rng.normal(size=(d, d))) * 0.01)
+    outer = bo.OUnion.from_members(
+        [bo.OMixture.from_params(np.zeros(d, bool), ell)], unit=True)
+    nb = bo.ONeural()
+    nb.outer_bound, nb.n_dim = ell, d
+    nb.emulator = mo.Emulator.from_weights(
+        rng.normal(size=d) * 0.05, rng.uniform(0.7, 1.3, d),
+        [mo.glorot_init(d, 3 * d + i)[:2] for i in range(e)])
+    seed, offset, n = 11 + d, 10**10 + d, 4000
+    x_all, _, _ = philox.union_sample(outer, seed, offset, n)
+    score_all = nb.emulator.predict(ell.transform(x_all))
+    nb.score_predict_min = float(np.median(score_all))
+    ob = bo.ONautilus.from_parts(outer, [nb])
+    b = upload(ob)
+    pts, counts = b.sample_launch(seed, offset, n)
+    c = counts.cpu().numpy()
+    pts_o, cnt_o = philox.nautilus_sample(ob, seed, offset, n)
+    n_edge = int(near_boundary(score_all, nb.score_predict_min - 1e-9,
+                               1e-9).sum())
+    assert int(c[0]) == int(cnt_o[2])                # proposals in the cube
+    assert abs(int(c[1]) - len(pts_o)) <= n_edge
+    assert 0.2 * len(x_all) < len(pts_o) < 0.8 * len(x_all)
+    if int(c[1]) == len(pts_o):
+        assert np.allclose(pts[:c[1]].cpu().numpy(), pts_o, rtol=0,
+                           atol=1e-11)
+    _, score = b.neural_score(x_all)
+    assert np.allclose(score.cpu().numpy(), score_all, rtol=0, atol=1e-10)
