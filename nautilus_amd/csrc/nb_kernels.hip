@@ -49,6 +49,7 @@ __device__ __forceinline__ double draw_row(const double* __restrict__ B,
   return acc;
 }
 
+template <int DT>
 __global__ void __launch_bounds__(64 * DW)
 nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
                unsigned long long offset, long long n,
@@ -132,6 +133,33 @@ nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
   }
   __syncthreads();
 
+  if (K == 1) {
+    // One member: B is wave uniform.  Every wavefront takes the whole z of
+    // its 64 proposals into registers (one LDS read per slot instead of one
+    // per term of every row) and computes the rows r = 4 i + wave with scalar
+    // B operands; same accumulation order as draw_row (j ascending, the up to
+    // three terms beyond the diagonal carry a zero weight; B is padded).
+    double z[16 * DT];
+#pragma unroll
+    for (int j = 0; j < 16 * DT; ++j) z[j] = (j < ne) ? zs[j * ZS + lane] : 0.0;
+    __syncthreads();                    // all of z is read before it is replaced
+    const double* Bp = draw + 2 + 4 * dp;
+#pragma unroll
+    for (int i = 0; i < 4 * DT; ++i) {
+      const int r = 4 * i + wave;
+      if (r < ne) {
+        const double* brow = Bp + (long long)r * (r + 1) / 2;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4 * i + 4; ++j) {
+          const double b = brow[j];
+          acc += ((j <= r) ? b : 0.0) * z[j];
+        }
+        zs[r * ZS + lane] = acc + c[r];
+      }
+    }
+    __syncthreads();
+  } else {
   // x = B z + c in place, four rows per step from the last row up; the rows
   // of a step are read completely before any of them is overwritten
   int ne_max = ne;
@@ -155,6 +183,7 @@ nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
     if (r < ne) zs[r * ZS + lane] = acc;
   }
   __syncthreads();
+  }
 
   // coalesced store of the workgroup's contiguous 64 x D block; every row
   // maps its columns to slots through its member's table
@@ -382,8 +411,20 @@ int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
   if (n <= 0) return NB_OK;
   const long long blocks = (n + 63) / 64;
   const size_t lds = (size_t)n_dim * 65 * sizeof(double);
-  hipLaunchKernelGGL(nb_draw_kernel, dim3((unsigned)blocks), dim3(64 * DW), lds,
-                     stream, blob_dev, seed, offset, n, x_out);
+#define NB_DRAW_CASE(D_T)                                                     \
+  case D_T:                                                                  \
+    hipLaunchKernelGGL(nb_draw_kernel<D_T>, dim3((unsigned)blocks),          \
+                       dim3(64 * DW), lds, stream, blob_dev, seed, offset, n, \
+                       x_out);                                               \
+    break;
+  switch ((n_dim + 15) / 16) {
+    NB_DRAW_CASE(1) NB_DRAW_CASE(2) NB_DRAW_CASE(3) NB_DRAW_CASE(4)
+    NB_DRAW_CASE(5) NB_DRAW_CASE(6) NB_DRAW_CASE(7) NB_DRAW_CASE(8)
+    default:
+      nb_set_error("n_dim > 128 is not supported by the device kernels");
+      return NB_ERR_UNSUPPORTED;
+  }
+#undef NB_DRAW_CASE
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;
 }
