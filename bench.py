@@ -287,6 +287,7 @@ def main():
     torch.cuda.synchronize()
     n_eff0, n_like0, prop0 = sampler.n_eff, sampler.n_like, proposals()
     roctx_region(True)
+    mallocs0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
     with device.EvalCounters() as counters, device.KernelTimer() as ktimer:
         t0 = time.time()
         for _ in range(args.steps):
@@ -294,6 +295,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.time() - t0
     roctx_region(False)
+    mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0) - mallocs0
     if comm is not None:
         comm.barrier()
         dt = comm.max_float(dt, 'cuda')
@@ -339,6 +341,7 @@ def main():
         n_eff=float(n_eff1), n_like=int(n_like1),
         n_bounds=len(sampler.bounds), setup_s=setup_s, shell_fill_s=fill_s,
         points_per_s=(n_like1 - n_like0) / dt,
+        device_mallocs_in_timed_region=int(mallocs),
         proposals_per_s=(prop1 - prop0) / dt,
         full_run=dict(wall_s=setup_s + fill_s + dt,
                       ess_per_s=n_eff1 / (setup_s + fill_s + dt)),

@@ -363,7 +363,8 @@ class _RejectionSampler(_DeviceBoundBase):
             n_draw = int(min(MAX_DRAW, max(MIN_DRAW, 1.2 * need / acc)))
             n_draw = (n_draw + 63) // 64 * 64
             seed, off = self._stream.take(n_draw)
-            rows, counts = self.device_bound().sample_launch(seed, off, n_draw)
+            rows, counts = self.device_bound().sample_launch(
+                seed, off, n_draw, reuse=True)     # q.push copies the rows
             c = counts.cpu().numpy()
             self._account(n_draw, int(c[0]), int(c[1]))
             rows = rows[:int(c[1])]
@@ -509,9 +510,8 @@ class Union(_RejectionSampler):
             n_draw = (n_draw + 63) // 64 * 64
             seed, off = self._stream.take(n_draw)
             dev = self.device_bound()
-            x = dev.propose(seed, off, n_draw)
-            flags = dev.accept(seed, off, x)
-            rows, counts, _ = device.compact_rows(x, flags, 1)
+            rows, counts = dev.sample_launch(seed, off, n_draw, mask=1,
+                                             reuse=True)   # push copies
             k = int(counts[1])
             self._account(n_draw, k, k)
             q.push(rows[:k])

@@ -191,25 +191,28 @@ class DeviceBound:
                                              _ptr(out), _stream()))
         return out[:, 0], out[:, 1]
 
-    def propose(self, seed, offset, n):
-        x = torch.empty((n, self.n_dim), dtype=torch.float64, device='cuda')
+    def propose(self, seed, offset, n, reuse=False):
+        x = _buffer('propose', (n, self.n_dim), torch.float64, reuse)
         _lib.check(self._lib.nb_propose(self._h, seed, offset, n, _ptr(x),
                                         _stream()))
         return x
 
-    def accept(self, seed, offset, x):
-        flags = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+    def accept(self, seed, offset, x, reuse=False):
+        flags = _buffer('accept', (x.shape[0],), torch.uint8, reuse)
         _lib.check(self._lib.nb_accept(self._h, seed, offset, _ptr(x),
                                        x.shape[0], _ptr(flags), _stream()))
         return flags
 
-    def sample_launch(self, seed, offset, n_draw):
+    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False):
         """One launch of the device ``sample`` pipeline: draw, accept,
         compact.  Returns (points, counters) with counters = int64 tensor
-        [n kept by the outer union, n kept in total] still on the device."""
-        x = self.propose(seed, offset, n_draw)
-        flags = self.accept(seed, offset, x)
-        out, counts, _ = compact_rows(x, flags, 2)
+        [n kept by the outer union, n kept in total] still on the device.
+        ``reuse=True`` (the bounds' refill loops): the launch works in the
+        process-wide scratch buffers and the returned rows are only valid
+        until the next such launch."""
+        x = self.propose(seed, offset, n_draw, reuse)
+        flags = self.accept(seed, offset, x, reuse)
+        out, counts, _ = compact_rows(x, flags, mask, reuse=reuse)
         return out, counts
 
 
@@ -344,7 +347,28 @@ def phase_shift_(x, periodic, centers, inverse=False):
     return x
 
 
-def compact_rows(x, flags, mask=1, want_index=False):
+_SCRATCH = {}
+
+
+def _buffer(role, shape, dtype, reuse):
+    """A fresh tensor, or (reuse=True) a view of the grow-only scratch buffer
+    of that role.  The refill loops of the bounds draw a different number of
+    proposals in every launch (~1 GB of proposals at n_dim = 50); fresh
+    allocations of ever-changing sizes keep sending the caching allocator back
+    to hipMalloc -- tens of milliseconds each -- in the middle of a run."""
+    if not reuse:
+        return torch.empty(shape, dtype=dtype, device='cuda')
+    n_bytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    buf = _SCRATCH.get(role)
+    if buf is None or buf.numel() < n_bytes:
+        _SCRATCH[role] = buf = None        # release before growing
+        buf = torch.empty(n_bytes + n_bytes // 4 + 512, dtype=torch.uint8,
+                          device='cuda')
+        _SCRATCH[role] = buf
+    return buf[:n_bytes].view(dtype).view(shape)
+
+
+def compact_rows(x, flags, mask=1, want_index=False, reuse=False):
     """Stable compaction of the rows of ``x`` with (flags & mask) != 0.
 
     Returns (rows, counts, src_idx): ``rows`` has x.shape[0] allocated rows of
@@ -352,10 +376,11 @@ def compact_rows(x, flags, mask=1, want_index=False):
     [rows with bit0, rows kept]."""
     lib = _lib.load()
     n, d = x.shape
-    out = torch.empty_like(x)
+    out = _buffer('compact', (n, d), torch.float64, reuse)
     counts = torch.zeros(2, dtype=torch.int64, device='cuda')
-    scratch = torch.empty(max(16, lib.nb_compact_scratch_bytes(n)),
-                          dtype=torch.uint8, device='cuda')
+    scratch = _buffer('compact_scratch',
+                      (max(16, lib.nb_compact_scratch_bytes(n)),),
+                      torch.uint8, reuse)
     src = (torch.empty(n, dtype=torch.int64, device='cuda')
            if want_index else None)
     _lib.check(lib.nb_compact_rows(
