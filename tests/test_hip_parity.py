@@ -7,6 +7,7 @@ associated differently on the matrix cores than in numpy/BLAS); floating
 point outputs agree to 1e-11 relative."""
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import load_golden
@@ -280,6 +281,26 @@ def test_nautilus_bound_contains_and_sample(dev, nautilus_d4):
     log_v = (np.logaddexp.reduce(ob.outer_bound.log_v_all) +
              np.log(c[1] / n))
     assert abs(log_v - float(g['log_v'])) < 0.1
+
+
+def test_sample_launch_scratch_reuse(dev, nautilus_d4):
+    """``reuse=True`` (the refill loops of the bounds) runs the same launch in
+    the grow-only scratch buffers: same rows and counters, the storage is
+    shared by consecutive launches."""
+    g, ob = nautilus_d4
+    b = upload(ob)
+    p1, c1 = b.sample_launch(5, 10**12, 30000)
+    p2, c2 = b.sample_launch(5, 10**12, 30000, reuse=True)
+    k = int(c1[1])
+    assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
+    assert torch.equal(p1[:k], p2[:k])
+    kept = p2[:k].clone()
+    p3, _ = b.sample_launch(6, 0, 20000, reuse=True)
+    assert p3.data_ptr() == p2.data_ptr()          # same scratch
+    assert torch.equal(p1[:k], kept)
+    p4, _ = b.sample_launch(6, 0, 40000, reuse=True)   # grows, still correct
+    p5, c5 = b.sample_launch(6, 0, 40000)
+    assert torch.equal(p4[:int(c5[1])], p5[:int(c5[1])])
 
 
 @pytest.mark.parametrize('d', [3, 20, 50])
