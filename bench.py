@@ -311,13 +311,34 @@ def main():
              work['emulator_point_evals'] * 2.0 * (100 * d + 6020))
     ev = kernels.get('nb_eval_kernel', dict(ms=0.0, launches=0))
     achieved_tf = flops / (ev['ms'] * 1e-3) / 1e12 if ev['ms'] > 0 else 0.0
+    # HBM bytes per launch: PMC counters cannot be collected from inside this
+    # process; profiles/tools/bench_traffic.sh measures them in separate
+    # rocprofv3 --pmc passes of this very command (FETCH_SIZE x 2 on gfx950,
+    # WRITE_SIZE) and commits the result.  Only quoted for that workload.
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                            'profiles', 'r01', 'bench_eval_traffic.json')
+    default_workload = (d == 50 and args.n_live == 2000 and e == 4 and
+                        args.n_batch == 65536 and world == 1 and
+                        not args.host_likelihood)
+    if default_workload and os.path.exists(pmc_file):
+        with open(pmc_file) as fh:
+            traffic = float(json.load(fh)['hbm_bytes_per_launch'])
+        traffic_src = ('profiles/r01/bench_eval_traffic.json (separate '
+                       'rocprofv3 --pmc passes of this command)')
     roofline = dict(
         kernel='nb_eval_kernel', bound='mfma', achieved=achieved_tf,
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
-        frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=None,
+        frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=traffic,
+        traffic_unit='bytes/launch', traffic_source=traffic_src,
         launches=ev['launches'],
         avg_launch_ms=ev['ms'] / max(1, ev['launches']),
         algorithmic_flops_per_launch=flops / max(1, ev['launches']),
+        # every proposal is read once (8 D bytes) and flagged (1 byte);
+        # the shell-exclusion launches add the accepted points again
+        algorithmic_bytes_per_launch=(
+            ((prop1 - prop0) / world + 2.0 * (n_like1 - n_like0) / world)
+            * (8 * d + 1) / max(1, ev['launches'])),
         point_evals=work, dominant_by_time=dominant,
         time_share={k: v['ms'] for k, v in kernels.items()})
 
