@@ -41,7 +41,8 @@ CASES = [(seed, d, k, unit) for seed, (d, k, unit) in enumerate([
     (15, 2, True), (16, 3, False), (17, 1, True), (31, 5, True),
     (32, 2, True), (33, 3, True), (48, 1, False), (50, 4, True),
     (63, 2, True), (64, 3, True), (65, 2, True), (90, 3, False),
-    (100, 2, True), (127, 2, True), (128, 3, True)])]
+    (100, 2, True), (127, 2, True), (128, 3, True), (120, 1, True),
+    (128, 1, False), (72, 1, True)])]
 
 
 @pytest.mark.parametrize('seed,d,k,unit', CASES)
