@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 2
+#define NB_ABI_VERSION 3
 
 typedef struct nb_bound nb_bound;          /* opaque bound living in HBM     */
 typedef struct nb_boundlist nb_boundlist;  /* device array of bound pointers */
@@ -219,14 +219,51 @@ int nb_mfma_f64_peak(int32_t iters, double* tflops_host);
 /* The iteration of minimum_volume_enclosing_ellipsoid (bounds/basic.py:
  * 175-232; called by Ellipsoid.compute :295 and, through it, by
  * UnitCubeEllipsoidMixture.compute and Union.compute/split): n_max sweeps of
- * up to n_batch Khachiyan updates over the n points x_dev (n > n_dim).
- * u_dev[n] receives the weights u of basic.py:231; centre, covariance and
- * scaling (basic.py:233-241) follow from u on the host.  scratch_dev: n
- * doubles.  n_dim <= 63 (NB_ERR_UNSUPPORTED above: the caller keeps its host
- * construction); the reference's defaults are n_max = 100, n_batch = 20.     */
+ * up to n_batch Khachiyan updates over the n points x_dev (n > n_dim,
+ * n_dim <= 128, n_batch <= 32).  u_dev[n] receives the weights u of
+ * basic.py:231.  The points are standardised internally (the iteration is
+ * affine invariant) and the work is spread over up to 32 workgroups.
+ * work_dev: nb_mvee_weights_work_doubles(n, n_dim, n_batch) doubles.  The
+ * reference's defaults are n_max = 100, n_batch = 20.                       */
+int64_t nb_mvee_weights_work_doubles(int64_t n, int32_t n_dim,
+                                     int32_t n_batch);
 int nb_mvee_weights(const double* x_dev, int64_t n, int32_t n_dim,
                     int32_t n_max, int32_t n_batch, double* u_dev,
-                    double* scratch_dev, void* stream);
+                    double* work_dev, void* stream);
+
+/* The same iteration for a batch of independent point sets of one dimension
+ * (the two children of Union.split, union.py:198-202; the neural-bound
+ * ellipsoids of one NautilusBound, nautilus.py:107-114), advanced side by
+ * side by the same launches.  xs_dev[b] are STANDARDISED points (zero mean,
+ * unit variance per column, e.g. from nb_standardize); u_dev[b] receives the
+ * weights of set b.  work_dev: nb_mvee_work_doubles(n_problems, max n,
+ * n_dim, n_batch) doubles.                                                   */
+int64_t nb_mvee_work_doubles(int32_t n_problems, int64_t n_points_max,
+                             int32_t n_dim, int32_t n_batch);
+int nb_mvee_khachiyan(int32_t n_problems, const double* const* xs_dev,
+                      const int64_t* n_points, int32_t n_dim, int32_t n_max,
+                      int32_t n_batch, double* const* u_dev, double* work_dev,
+                      void* stream);
+
+/* Weighted second moments of the augmented rows q_i = (x_i, 1):
+ * out_dev[(n_dim+1)^2] = scale * sum_i w_i q_i q_i^T (row-major, symmetric;
+ * w_dev == NULL: unit weights).  With the MVEE weights this is the centre and
+ * covariance of basic.py:233-234 in one pass on the matrix cores (the last
+ * row holds sum w x, the corner sum w).  work_dev:
+ * nb_moments_work_doubles(n, n_dim) doubles.                                 */
+int64_t nb_moments_work_doubles(int64_t n, int32_t n_dim);
+int nb_weighted_moments(const double* x_dev, const double* w_dev, int64_t n,
+                        int32_t n_dim, double scale, double* out_dev,
+                        double* work_dev, void* stream);
+
+/* out_dev[0] = max_i q_i^T P q_i, q_i = (x_i, 1), for a symmetric
+ * (n_dim+1)^2 matrix p_dev -- the scaling step of the MVEE (basic.py:236:
+ * with P the inverse of the second-moment matrix the largest squared
+ * Mahalanobis distance is out - 1).  work_dev: nb_quadform_work_doubles().   */
+int64_t nb_quadform_work_doubles(void);
+int nb_quadform_max(const double* x_dev, int64_t n, int32_t n_dim,
+                    const double* p_dev, double* out_dev, double* work_dev,
+                    void* stream);
 
 /* Ellipsoid.transform (bounds/basic.py:318-342, forward direction):
  * y_dev[i] = B_inv (x_i - c) for an Ellipsoid bound (or the ellipsoid of a

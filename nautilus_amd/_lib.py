@@ -98,6 +98,23 @@ _SIGNATURES = {
     'nb_mvee_weights': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    'nb_mvee_weights_work_doubles': (C.c_int64, [C.c_int64, C.c_int32,
+                                                 C.c_int32]),
+    'nb_mvee_work_doubles': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32,
+                                         C.c_int32]),
+    'nb_mvee_khachiyan': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_int64), C.c_int32,
+                                    C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_void_p), C.c_void_p,
+                                    C.c_void_p]),
+    'nb_moments_work_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
+    'nb_weighted_moments': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_double, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    'nb_quadform_work_doubles': (C.c_int64, []),
+    'nb_quadform_max': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     'nb_ellipsoid_transform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
     'nb_standardize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
@@ -137,7 +154,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.nb_abi_version() != 2:
+    if lib.nb_abi_version() != 3:
         raise RuntimeError('nautilus_amd: ABI version mismatch')
     _lib = lib
     return lib

@@ -186,13 +186,26 @@ class Ellipsoid(_DeviceBoundBase):
 
     @classmethod
     def compute(cls, points, enlarge_per_dim=1.1, rng=None):
-        self = cls()
-        self.n_dim = points.shape[1]
-        p = geometry.ellipsoid_params(np.asarray(points), enlarge_per_dim)
-        self.c, self.A, self.B, self.B_inv = p['c'], p['A'], p['B'], p['B_inv']
-        self.rng = _default_rng(rng)
-        self._stream = _PhiloxStream(self.rng)
-        return self
+        return cls.compute_many([points], enlarge_per_dim, rng)[0]
+
+    @classmethod
+    def compute_many(cls, point_sets, enlarge_per_dim=1.1, rng=None):
+        """``compute`` (basic.py:265-316) for several independent point sets;
+        their minimum-volume ellipsoids are fitted in the same GPU launches.
+        No random numbers are consumed by the fits; the Philox keys are drawn
+        in list order."""
+        params = geometry.ellipsoid_params_batch(
+            [np.asarray(p) for p in point_sets], enlarge_per_dim)
+        out = []
+        for p in params:
+            self = cls()
+            self.n_dim = len(p['c'])
+            self.c, self.A, self.B, self.B_inv = (p['c'], p['A'], p['B'],
+                                                  p['B_inv'])
+            self.rng = _default_rng(rng)
+            self._stream = _PhiloxStream(self.rng)
+            out.append(self)
+        return out
 
     @classmethod
     def from_params(cls, c, B, B_inv=None, A=None, rng=None):
@@ -253,18 +266,29 @@ class UnitCubeEllipsoidMixture(_DeviceBoundBase):
 
     @classmethod
     def compute(cls, points, enlarge_per_dim=1.1, rng=None):
-        self = cls()
-        points = np.asarray(points)
-        self.n_dim = points.shape[1]
-        self.dim_cube, ell = geometry.mixture_params(points, enlarge_per_dim)
-        self.rng = _default_rng(rng)
-        self.ellipsoid = None if ell is None else Ellipsoid.from_params(
-            ell['c'], ell['B'], ell['B_inv'], ell['A'], rng=self.rng)
-        self.cube = (UnitCube.compute(int(np.sum(self.dim_cube)),
-                                      rng=self.rng)
-                     if np.any(self.dim_cube) else None)
-        self._stream = _PhiloxStream(self.rng)
-        return self
+        return cls.compute_many([points], enlarge_per_dim, rng)[0]
+
+    @classmethod
+    def compute_many(cls, point_sets, enlarge_per_dim=1.1, rng=None):
+        """``compute`` (basic.py:471-563) for several independent point sets:
+        their greedy cube / ellipsoid searches advance in lockstep and share
+        the GPU launches of their ellipsoid fits."""
+        params = geometry.mixture_params_batch(
+            [np.asarray(p) for p in point_sets], enlarge_per_dim)
+        out = []
+        for dim_cube, ell in params:
+            self = cls()
+            self.dim_cube = dim_cube
+            self.n_dim = len(dim_cube)
+            self.rng = _default_rng(rng)
+            self.ellipsoid = None if ell is None else Ellipsoid.from_params(
+                ell['c'], ell['B'], ell['B_inv'], ell['A'], rng=self.rng)
+            self.cube = (UnitCube.compute(int(np.sum(self.dim_cube)),
+                                          rng=self.rng)
+                         if np.any(self.dim_cube) else None)
+            self._stream = _PhiloxStream(self.rng)
+            out.append(self)
+        return out
 
     @classmethod
     def from_params(cls, dim_cube, ellipsoid, rng=None):
@@ -451,9 +475,9 @@ class Union(_RejectionSampler):
             self.bounds[index].transform(pts), self.n_points_min,
             int(self.rng.integers(2**32 - 1)))
         cls = type(self.bounds[0])
-        halves = [cls.compute(pts[labels == lab],
-                              enlarge_per_dim=self.enlarge_per_dim,
-                              rng=self.rng) for lab in (0, 1)]
+        halves = cls.compute_many([pts[labels == lab] for lab in (0, 1)],
+                                  enlarge_per_dim=self.enlarge_per_dim,
+                                  rng=self.rng)
         if not allow_overlap and geometry.ellipsoids_overlap(
                 [b.params() for b in
                  self.bounds[:index] + self.bounds[index + 1:] + halves]):
@@ -563,14 +587,19 @@ class NeuralBound(_DeviceBoundBase):
         the order of the work does not matter."""
         rng = _default_rng(rng)
         bounds, train = [], []
+        xs, lives = [], []
         for points, log_l in data:
+            x = device.as_device_points(points)
+            xs.append(x)
+            lives.append(x[torch.from_numpy(
+                np.asarray(log_l) >= log_l_min).cuda()].cpu().numpy())
+        outer = Ellipsoid.compute_many(lives, enlarge_per_dim=enlarge_per_dim,
+                                       rng=rng)
+        for (points, log_l), x, ell in zip(data, xs, outer):
             self = cls()
             log_l = np.asarray(log_l)
-            x = device.as_device_points(points)
             self.n_dim = x.shape[1]
-            live = x[torch.from_numpy(log_l >= log_l_min).cuda()].cpu().numpy()
-            self.outer_bound = Ellipsoid.compute(
-                live, enlarge_per_dim=enlarge_per_dim, rng=rng)
+            self.outer_bound = ell
             bounds.append(self)
             if n_networks == 0:
                 self.emulator = None

@@ -33,8 +33,19 @@ int nb_launch_philox(unsigned long long seed, unsigned long long offset,
                      unsigned block, unsigned tag, long long n, double* u,
                      hipStream_t stream);
 int nb_run_mfma_peak(int iters, double* tflops);
-int nb_launch_mvee(const double* x, long long n, int n_dim, int n_max,
-                   int n_batch, double* u, double* g, hipStream_t stream);
+int nb_launch_mvee_batch(int n_problems, const double* const* xs,
+                         const long long* n, int d, int n_max, int n_batch,
+                         double* const* u, double* work, hipStream_t stream);
+long long nb_mvee_work_doubles_impl(int n_problems, long long n_max, int d,
+                                    int n_batch);
+int nb_launch_moments(const double* x, const double* w, long long n, int d,
+                      double scale, double* out, double* work,
+                      hipStream_t stream);
+long long nb_moments_work_doubles_impl(long long n, int d);
+int nb_launch_quadform_max(const double* x, long long n, int d,
+                           const double* p_dev, double* out, double* work,
+                           hipStream_t stream);
+long long nb_quadform_work_doubles_impl();
 int nb_launch_transform(const double* ell_block, int dt, int n_dim,
                         const double* x, long long n, double* y,
                         hipStream_t stream);
@@ -578,14 +589,83 @@ int nb_mfma_f64_peak(int32_t iters, double* tflops) {
   return nb_run_mfma_peak(iters, tflops);
 }
 
-int nb_mvee_weights(const double* x, int64_t n, int32_t n_dim, int32_t n_max,
-                    int32_t n_batch, double* u, double* scratch, void* stream) {
-  if (x == nullptr || u == nullptr || scratch == nullptr) {
+int64_t nb_mvee_work_doubles(int32_t n_problems, int64_t n_points_max,
+                             int32_t n_dim, int32_t n_batch) {
+  return nb_mvee_work_doubles_impl(n_problems, n_points_max, n_dim, n_batch);
+}
+
+int nb_mvee_khachiyan(int32_t n_problems, const double* const* xs,
+                      const int64_t* n_points, int32_t n_dim, int32_t n_max,
+                      int32_t n_batch, double* const* u, double* work,
+                      void* stream) {
+  if (n_problems < 1 || xs == nullptr || n_points == nullptr || u == nullptr ||
+      work == nullptr) {
     nb_set_error("null argument");
     return NB_ERR_ARG;
   }
-  return nb_launch_mvee(x, n, n_dim, n_max, n_batch, u, scratch,
-                        as_stream(stream));
+  std::vector<long long> n(n_points, n_points + n_problems);
+  return nb_launch_mvee_batch(n_problems, xs, n.data(), n_dim, n_max, n_batch,
+                              u, work, as_stream(stream));
+}
+
+int64_t nb_mvee_weights_work_doubles(int64_t n, int32_t n_dim,
+                                     int32_t n_batch) {
+  return 2 * 16 * NB_MAX_DT + n * n_dim + 2 +
+         nb_mvee_work_doubles_impl(1, n, n_dim, n_batch);
+}
+
+int nb_mvee_weights(const double* x, int64_t n, int32_t n_dim, int32_t n_max,
+                    int32_t n_batch, double* u, double* work, void* stream) {
+  if (x == nullptr || u == nullptr || work == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT) {
+    nb_set_error("device MVEE supports n_dim <= 128 (got %d)", n_dim);
+    return NB_ERR_UNSUPPORTED;
+  }
+  // standardised copy of the points (the iteration is affine invariant)
+  double* mean = work;
+  double* scale = work + 16 * NB_MAX_DT;
+  double* xs = scale + 16 * NB_MAX_DT;
+  double* rest = xs + ((n * n_dim + 1) & ~(int64_t)1);
+  int rc = nb_launch_standardize(x, n, n_dim, mean, scale, xs,
+                                 as_stream(stream));
+  if (rc != NB_OK) return rc;
+  const double* xs_c = xs;
+  long long nn = n;
+  return nb_launch_mvee_batch(1, &xs_c, &nn, n_dim, n_max, n_batch, &u, rest,
+                              as_stream(stream));
+}
+
+int64_t nb_moments_work_doubles(int64_t n, int32_t n_dim) {
+  return nb_moments_work_doubles_impl(n, n_dim);
+}
+
+int nb_weighted_moments(const double* x, const double* w, int64_t n,
+                        int32_t n_dim, double scale, double* out, double* work,
+                        void* stream) {
+  if (x == nullptr || out == nullptr || work == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_moments(x, w, n, n_dim, scale, out, work,
+                           as_stream(stream));
+}
+
+int64_t nb_quadform_work_doubles(void) {
+  return nb_quadform_work_doubles_impl();
+}
+
+int nb_quadform_max(const double* x, int64_t n, int32_t n_dim,
+                    const double* p_dev, double* out, double* work,
+                    void* stream) {
+  if (x == nullptr || p_dev == nullptr || out == nullptr || work == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_quadform_max(x, n, n_dim, p_dev, out, work,
+                                as_stream(stream));
 }
 
 int nb_ellipsoid_transform(const nb_bound* b, const double* x, int64_t n,

@@ -1,308 +1,929 @@
 // Minimum-volume enclosing ellipsoid: the batched Khachiyan iteration of
 // minimum_volume_enclosing_ellipsoid (reference nautilus/bounds/basic.py:
-// 175-232) for one point set, as ONE persistent workgroup.
+// 175-232) for a BATCH of independent point sets, n_dim <= 128, spread over
+// many workgroups.
 //
-//   q_i = (x_i, 1);  V = sum_i u_i q_i q_i^T;  g_i = q_i^T V^-1 q_i
+//   q_i = (x_i, 1) (m = D + 1);  V = sum_i u_i q_i q_i^T;  g_i = q_i^T V^-1 q_i
 //   per sweep (n_max = 100): the n_batch = 20 largest g_i, in descending
-//   order, each update  a = (g - (D+1)) / ((D+1)(g - 1)),
+//   order, each update  a = (g - m) / (m (g - 1)),
 //   V <- (1-a) V + a q_j q_j^T,  u <- (1-a) u + a e_j          (basic.py:217-231)
 //
-// Everything the loop touches except the points lives in LDS: V, its inverse
-// and a work matrix ((D+1)^2 doubles each), the quadratic forms g.  Per sweep
-//   1. V = L D L^T by Gaussian elimination on [V | I] (one barrier per
-//      pivot), which yields L^-1 directly; R^-1 = D^-1/2 L^-1 and
-//      V^-1 = L^-T D^-1 L^-1                                      (VALU, LDS)
-//   2. g_i = |R^-1 q_i|^2 for all points on the matrix cores: the same
-//      16-point-tile ellipsoid transform as Ellipsoid.contains (nb_tile.h),
-//      with R^-1 scattered into the tile-major K-permuted operand layout
-//   3. top-n_batch selection (block-wide arg-max rounds)
-//   4. the sequential rank-one updates, two barriers each; V^-1 follows by
-//      Sherman-Morrison (the reference re-factorises after every update,
-//      basic.py:230 -- the same matrix up to rounding)
-// The kernel returns the weights u; centre, covariance and the final scaling
-// (basic.py:233-241) are a handful of (D x D) host operations on top of u.
+// What the reference does with one LAPACK inversion per update is done here
+// with P = V^-1 carried along (the updates only ever ADD positive rank-one
+// terms, the benign direction of Sherman-Morrison), on standardised points
+// (the iteration is affine invariant; centring removes the cancellation the
+// homogeneous coordinate otherwise causes):
+//
+//   nb_moments_kernel   S = sum_i w_i q_i q_i^T on the matrix cores, partial
+//                       sums per workgroup (fixed reduction order)
+//   nb_spd_inverse_kernel  P_0 = (S / n)^-1, in-place Gauss-Jordan in LDS
+//   nb_mvee_sweep_kernel   launched n_max + 1 times; grid = (workgroups per
+//                       problem, problems).  Call k, every workgroup:
+//     A. reads the candidates of call k-1 (the n_batch largest g of every
+//        workgroup), merges them into the global top n_batch, and replays the
+//        sequential rank-one updates in the n_batch-dimensional space spanned
+//        by the selected points: with W = P Q_sel^T and G = Q_sel P Q_sel^T
+//        every update is a rank-one update of the (n_batch x n_batch) Gram
+//        matrix -- one wavefront, registers and readlane only, no barriers.
+//        The result is P_new = s (P - sum_k kappa_k (W z_k)(W z_k)^T), a
+//        rank-n_batch product on the matrix cores.  All workgroups do this
+//        redundantly (bit-identical), workgroup 0 publishes P_new and u.
+//     B. g_i = q_i^T P_new q_i for its own points on the matrix cores
+//        (y = T q with T = lower triangle of P_new, off-diagonal doubled, so
+//        that g = q . y needs the lower-triangular tiles only), then its own
+//        n_batch largest -> candidates of call k+1.
+//   The kernel boundary is the grid synchronisation (1.5-2 us, cheaper than
+//   any in-kernel grid barrier on this part).
+//   nb_mvee_finish_kernel  u <- scale * u (the (1-a) factors are applied
+//                       lazily)
+//
+// Centre, covariance and the final scaling (basic.py:233-241) follow from u
+// with one more nb_moments launch and one "B only" call (nb_quadform_max).
 #include "nb_tile.h"
+
+#include <cstring>
 
 namespace {
 
-constexpr int MV_THREADS = 512;          // 8 wavefronts, 2 per SIMD
+constexpr int MV_THREADS = 512;
 constexpr int MV_WAVES = MV_THREADS / 64;
-constexpr int MV_EPT = 8;                // matrix elements per thread (m <= 64)
-constexpr int MV_SEL = 64;               // upper limit of n_batch
+constexpr int MV_MAXB = 16;        // problems per launch
+constexpr int MV_MAXW = 32;        // workgroups (candidate lists) per problem
+constexpr int MV_MAXPPW = 2048;    // points per workgroup
+constexpr int MV_GJ_EPT = 33;      // ceil(129^2 / 512)
 
-__device__ __forceinline__ int mv_slot(int f) {      // slot_of_feature (nb_api)
+struct MvProb {
+  const double* xs;      // standardised points [n][d]
+  double* u;             // weights [n] (lazy scale until the finish kernel)
+  double* P;             // 2 x (m*m) row-major, ping-pong
+  double* cand_g;        // 2 x W x NSC
+  int* cand_i;           // 2 x W x (NSC+1), last = entries of the list
+  double* state;         // [0] lazy scale of u  [1] accepted updates
+  int n, W, ppw, pad;
+};
+struct MvBatch { MvProb p[MV_MAXB]; };
+
+struct MomProb {
+  const double* x;       // [n][d]
+  const double* w;       // [n] or null (unit weights)
+  double* partial;       // [VW][NT][256]
+  double* out;           // [m*m] (reduce kernel) or null
+  int n, pad;
+};
+struct MomBatch { MomProb p[MV_MAXB]; };
+
+__host__ __device__ inline int mv_tri(int ht, int kt) {
+  return ht * (ht + 1) / 2 + kt;
+}
+// position of feature offset o (0..15) of a k-tile in the operand tile:
+// slot s = 2 (o >> 3) + (o & 1), lane group (o >> 1) & 3   (nb_tile.h, perm)
+__device__ __forceinline__ int mv_kpos(int o) {
+  return (2 * (o >> 3) + (o & 1)) * 64 + ((o >> 1) & 3) * 16;
+}
+// row position of feature offset o of an h-tile: the accumulator register r
+// of lane group lg then holds feature 8 (r >> 1) + 2 lg + (r & 1), i.e. the
+// feature the lane holds in input slot 4 ht + r
+__device__ __forceinline__ int mv_hpos(int o) {
+  return ((o >> 1) & 3) + 4 * (2 * (o >> 3) + (o & 1));
+}
+__device__ __forceinline__ int mv_slot(int f) {       // slot_of_feature
   const int j = f >> 3, r = f & 7;
   return 4 * (2 * j + (r & 1)) + (r >> 1);
 }
 
-template <int DT>
+__device__ __forceinline__ bool mv_before(double yg, int yi, double xg, int xi) {
+  return yg > xg || (yg == xg && yi > xi);
+}
+// number of entries of a list sorted in "before" order that rank before x
+__device__ __forceinline__ int mv_count_before(const double* lg, const int* li,
+                                               int len, double xg, int xi) {
+  int lo = 0, hi = len;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (mv_before(lg[mid], li[mid], xg, xi)) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ double mv_readlane(double v, int l) {
+  const unsigned long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// LDS layout (doubles) shared by host and device
+struct MvLds {
+  int T, Wt, Qs, G0, Zs, misc, gwg, L1g, L1i, total;
+};
+__host__ __device__ inline MvLds mv_layout(int dt, int nsc, int ppw_max) {
+  MvLds l;
+  const int ldw = 16 * dt + 1;
+  int off = 0;
+  l.T = off; off += dt * (dt + 1) / 2 * NB_TILE;
+  int wt = nsc * ldw;
+  const int stage = MV_MAXW * nsc + (MV_MAXW * nsc + MV_MAXW + 1) / 2 + 2;
+  if (wt < stage) wt = stage;            // candidate staging aliases Wt
+  l.Wt = off; off += (wt + 1) & ~1;
+  l.Qs = off; off += (nsc * ldw + 1) & ~1;
+  l.G0 = off; off += nsc * nsc;
+  l.Zs = off; off += nsc * nsc;
+  l.misc = off; off += 4 * nsc + 16;     // sel_g, kap, sel_i (ints), scalars
+  l.gwg = off; off += (ppw_max + 1) & ~1;
+  l.L1g = off; off += MV_WAVES * nsc;
+  l.L1i = off; off += (MV_WAVES * nsc + MV_WAVES + 1) / 2 + 1;
+  l.total = off;
+  return l;
+}
+
+// second level of a selection: MV_WAVES sorted lists -> the k best overall,
+// written through `emit(rank, g, i)`; returns the number of valid entries
+template <typename Emit>
+__device__ __forceinline__ void mv_select_l2(const double* L1g, const int* L1i,
+                                             const int* L1n, int nsc, int k,
+                                             int tid, Emit emit) {
+  if (tid < MV_WAVES * nsc) {
+    const int a = tid / nsc, p = tid - a * nsc;
+    if (p < L1n[a]) {
+      const double xg = L1g[a * nsc + p];
+      const int xi = L1i[a * nsc + p];
+      int rank = p;
+#pragma unroll
+      for (int b = 0; b < MV_WAVES; ++b)
+        if (b != a && rank < k)
+          rank += mv_count_before(L1g + b * nsc, L1i + b * nsc, L1n[b], xg, xi);
+      if (rank < k) emit(rank, xg, xi);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the sweep kernel
+//   mode 0: Khachiyan call `call` of n_calls
+//   mode 1: phase B only with the matrix in P[0] and k = 1 (largest g)
+// ---------------------------------------------------------------------------
+template <int DT, int NSC>
 __global__ void __launch_bounds__(MV_THREADS)
-nb_mvee_kernel(const double* __restrict__ x, int n, int d, int n_max,
-               int n_batch, volatile double* u, volatile double* g_glob,
-               int g_in_lds) {
+nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
+                     int mode, int ppw_max) {
   constexpr int DP = 16 * DT;
+  constexpr int LDW = DP + 1;
+  constexpr int NT = DT * (DT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ double wv[64], pr[64], piv[64], sel_g[MV_SEL], red_v[2 * MV_WAVES];
-  __shared__ int sel_i[MV_SEL], red_i[2 * MV_WAVES];
+  const MvProb pb = batch.p[blockIdx.y];
+  const int wg = blockIdx.x;
+  if (wg >= pb.W) return;
+  const bool last = (mode == 0 && call > 0 && call == n_calls - 1);
+  if (last && wg != 0) return;
+
+  const MvLds L = mv_layout(DT, NSC, ppw_max);
+  double* T = lds + L.T;
+  double* Wt = lds + L.Wt;
+  double* Qs = lds + L.Qs;           // later Yt
+  double* G0 = lds + L.G0;
+  double* Zs = lds + L.Zs;
+  double* sel_g = lds + L.misc;
+  double* kap = sel_g + NSC;
+  int* sel_i = (int*)(kap + NSC);
+  double* scal = kap + NSC + NSC;    // [0] s_fin [1] n_acc [2] n_sel_eff
+  double* gwg = lds + L.gwg;
+  double* L1g = lds + L.L1g;
+  int* L1i = (int*)(lds + L.L1i);
+  int* L1n = L1i + MV_WAVES * NSC;
+  // candidate staging (merge) aliases Wt
+  double* cg = Wt;
+  int* ci = (int*)(Wt + MV_MAXW * NSC);
+  int* cn = ci + MV_MAXW * NSC;
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lg = lane >> 4;
-  const int m = d + 1;
-  const int mm = (m * m + 1) & ~1;
-  double* V = lds;
-  double* A = V + mm;          // elimination work matrix, then V^-1
-  double* B = A + mm;          // L^-1 of V = L D L^T
-  double* ell = B + mm;        // ell block: n_ell, pad, lo, hi, c, tiles
-  double* tiles = ell + 2 + 3 * DP;
-  double* qsel = ell + nb_ell_block_size(DT);       // [MV_SEL][DP] selected rows
-  double* g_lds = qsel + (n_batch < MV_SEL ? n_batch : MV_SEL) * DP;
+  const int lg = lane >> 4, lj = lane & 15;
+  const int n = pb.n, m = d + 1, W = pb.W;
   const double inf = __builtin_huge_val();
+  const int K = mode == 1 ? 1 : (n_batch < n ? n_batch : n);
+  const int cur = call & 1, prev = cur ^ 1;
+  const double* P_old = pb.P + (size_t)(mode == 1 ? 0 : cur) * m * m;
+  double* P_new = pb.P + (size_t)(cur ^ 1) * m * m;
+  const bool phase_a = (mode == 0 && call > 0);
 
-  // the (row, column) pairs this thread owns in every element-wise pass
-  int er[MV_EPT], ec[MV_EPT];
-#pragma unroll
-  for (int q = 0; q < MV_EPT; ++q) {
-    const int e = tid + q * MV_THREADS;
-    er[q] = (e < m * m) ? e / m : -1;
-    ec[q] = (e < m * m) ? e - er[q] * m : 0;
+  int n_acc = 0;
+  double s_fin = 1.0;
+
+  if (mode == 0 && call == 0) {
+    // u = 1/n (basic.py:216), the workgroup's own slice
+    const int base = wg * pb.ppw;
+    for (int i = tid; i < pb.ppw && base + i < n; i += MV_THREADS)
+      pb.u[base + i] = 1.0 / (double)n;
+    if (wg == 0 && tid == 0) { pb.state[0] = 1.0; pb.state[1] = 0.0; }
   }
 
-  // ---- initialisation ----------------------------------------------------
-  for (int e = tid; e < nb_ell_block_size(DT); e += MV_THREADS) ell[e] = 0.0;
-  __syncthreads();
-  if (tid == 0) ((long long*)ell)[0] = m;
-  for (int f = tid; f < DP; f += MV_THREADS) {
-    ell[2 + f] = -inf;
-    ell[2 + DP + f] = inf;
-  }
-  for (int i = tid; i < n; i += MV_THREADS) u[i] = 1.0 / (double)n;
-  // V = sum_i u_i q_i q_i^T (basic.py:218), lower triangle then mirrored
-#pragma unroll
-  for (int q = 0; q < MV_EPT; ++q) {
-    const int r = er[q], c = ec[q];
-    if (r < 0 || c > r) continue;
-    double acc = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double qr = (r < d) ? x[(long long)i * d + r] : 1.0;
-      const double qc = (c < d) ? x[(long long)i * d + c] : 1.0;
-      acc += qr * qc;
+  if (phase_a) {
+    // ---- A0: stage the candidate lists of the previous call ----------------
+    const double* pg = pb.cand_g + (size_t)prev * W * NSC;
+    const int* pi = pb.cand_i + (size_t)prev * W * (NSC + 1);
+    for (int e = tid; e < W * NSC; e += MV_THREADS) {
+      const int w = e / NSC, q = e - w * NSC;
+      const int cnt = pi[w * (NSC + 1) + NSC];
+      cg[e] = q < cnt ? pg[e] : -inf;
+      ci[e] = q < cnt ? pi[w * (NSC + 1) + q] : -1;
+      if (q == 0) cn[w] = cnt;
     }
-    acc /= (double)n;
-    V[r * m + c] = acc;
-    V[c * m + r] = acc;
+    for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS) {
+      L1g[e] = -inf;
+      L1i[e] = -1;
+    }
+    __syncthreads();
+    // ---- A1: first level, wave w merges the lists w, w+8, ... --------------
+    {
+      int total = 0;
+      for (int w = wave; w < W; w += MV_WAVES) total += cn[w];
+      const int nl = (W - wave + MV_WAVES - 1) / MV_WAVES;     // lists here
+      for (int c = lane; c < nl * NSC; c += 64) {
+        const int li = c / NSC, p = c - li * NSC;
+        const int w = wave + MV_WAVES * li;
+        if (p < cn[w]) {
+          const double xg = cg[w * NSC + p];
+          const int xi = ci[w * NSC + p];
+          int rank = p;
+          for (int b = wave; b < W; b += MV_WAVES)
+            if (b != w && rank < K)
+              rank += mv_count_before(cg + b * NSC, ci + b * NSC, cn[b], xg, xi);
+          if (rank < K) {
+            L1g[wave * NSC + rank] = xg;
+            L1i[wave * NSC + rank] = xi;
+          }
+        }
+      }
+      if (lane == 0) L1n[wave] = total < K ? total : K;
+    }
+    __syncthreads();
+    // ---- A2: second level ---------------------------------------------------
+    mv_select_l2(L1g, L1i, L1n, NSC, K, tid,
+                 [&](int rank, double g, int i) { sel_g[rank] = g; sel_i[rank] = i; });
+    __syncthreads();
+    int n_sel = 0;
+#pragma unroll
+    for (int w = 0; w < MV_WAVES; ++w) n_sel += L1n[w];
+    if (n_sel > K) n_sel = K;
+
+    // ---- A3: the selected rows q_t = (x_t, 1) ------------------------------
+    for (int e = tid; e < n_sel * DP; e += MV_THREADS) {
+      const int t = e / DP, c = e - t * DP;
+      double v = 0.0;
+      if (c < d) v = pb.xs[(size_t)sel_i[t] * d + c];
+      else if (c == d) v = 1.0;
+      Qs[t * LDW + c] = v;
+    }
+    __syncthreads();
+
+    // ---- A4: W = P Q_sel^T on the matrix cores -> Wt[t][feature] ----------
+    for (int ht = wave; ht < DT; ht += MV_WAVES) {
+      double a[4 * DT];
+      const int row = 16 * ht + lj;
+#pragma unroll
+      for (int ks = 0; ks < 4 * DT; ++ks) {
+        const int col = 4 * ks + lg;
+        a[ks] = (row < m && col < m) ? P_old[(size_t)row * m + col] : 0.0;
+      }
+      for (int pt = 0; 16 * pt < n_sel; ++pt) {
+        const int t = 16 * pt + lj;
+        nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4 * DT; ++ks) {
+          const int f = 4 * ks + lg;
+          const double b = t < n_sel ? Qs[t * LDW + f] : 0.0;
+          acc = MFMA(a[ks], b, acc);
+        }
+        if (t < n_sel) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Wt[t * LDW + 16 * ht + lg + 4 * r] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- A5: G0 = Q_sel W --------------------------------------------------
+    for (int e = tid; e < n_sel * n_sel; e += MV_THREADS) {
+      const int s = e / n_sel, t = e - s * n_sel;
+      double acc = 0.0;
+      for (int c = 0; c < m; ++c) acc += Qs[s * LDW + c] * Wt[t * LDW + c];
+      G0[s * NSC + t] = acc;
+    }
+    __syncthreads();
+
+    // ---- A6: the sequential updates in the Gram space (one wavefront) ------
+    if (wave == 0) {
+      // lane l holds row l of the current Gram matrix Gk (q_l^T P_k q_r) and
+      // of H = C G0 (z_t = e_t - H[:, t]); Zk collects the vectors z of the
+      // accepted updates
+      double Gk[NSC], H[NSC];
+#pragma unroll
+      for (int r = 0; r < NSC; ++r) {
+        Gk[r] = (lane < n_sel && r < n_sel) ? G0[lane * NSC + r] : 0.0;
+        H[r] = 0.0;
+      }
+      double s = 1.0;
+      double us = pb.state[0];
+      const double md = (double)m;
+      int acc_n = 0;
+#pragma unroll
+      for (int t = 0; t < NSC; ++t) {
+        if (t < n_sel) {
+          double g = mv_readlane(Gk[t], t);
+          if (t == 0) g = mv_readlane(sel_g[0], 0);   // basic.py:222-223
+          if (g >= md) {
+            const double a = (g - md) / (md * (g - 1.0));
+            const double ratio = a / (1.0 - a);
+            const double coef = ratio / (1.0 + ratio * g);
+            const double inv1a = 1.0 / (1.0 - a);
+            const double z = (lane == t ? 1.0 : 0.0) - H[t];
+            const double gt = Gk[t];              // Gk[l][t]
+#pragma unroll
+            for (int r = 0; r < NSC; ++r) {
+              if (r > t) {
+                const double v = mv_readlane(Gk[r], t);      // Gk[t][r]
+                Gk[r] = (Gk[r] - coef * gt * v) * inv1a;
+                H[r] += coef * z * v;
+              }
+            }
+            // record z (column acc_n of Zs) and kappa = coef * s
+            if (lane < NSC) Zs[lane * NSC + acc_n] = z;
+            if (lane == 0) {
+              kap[acc_n] = coef * s;
+              if (wg == 0) {
+                us *= (1.0 - a);
+                pb.u[sel_i[t]] += a / us;
+              }
+            }
+            s *= inv1a;
+            ++acc_n;
+          }
+        }
+      }
+      if (lane == 0) {
+        scal[0] = s;
+        scal[1] = (double)acc_n;
+        if (wg == 0) {
+          pb.state[0] = us;
+          pb.state[1] += (double)acc_n;
+        }
+      }
+    }
+    __syncthreads();
+    s_fin = scal[0];
+    n_acc = (int)scal[1];
+    if (last) return;
+
+    // ---- A7: Y = W Z  (Yt[k][feature], aliases Qs) -------------------------
+    double* Yt = Qs;
+    for (int e = tid; e < n_acc * DP; e += MV_THREADS) {
+      const int k = e / DP, f = e - k * DP;
+      double acc = 0.0;
+      for (int b = 0; b < n_sel; ++b) acc += Zs[b * NSC + k] * Wt[b * LDW + f];
+      Yt[k * LDW + f] = acc;
+    }
+    __syncthreads();
   }
-  double scale = 1.0;          // true weights = scale * u (lazy (1-a) factors)
+
+  // ---- A8: P_new = s (P - sum_k kappa_k y_k y_k^T) -> operand tiles T ------
+  {
+    const double* Yt = Qs;
+    for (int q = wave; q < NT; q += MV_WAVES) {
+      int ht = 0;
+      while (mv_tri(ht + 1, 0) <= q) ++ht;
+      const int kt = q - mv_tri(ht, 0);
+      nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
+      for (int ka = 0; 4 * ka < n_acc; ++ka) {
+        const int k = 4 * ka + lg;
+        const double a = k < n_acc ? kap[k] * Yt[k * LDW + 16 * ht + lj] : 0.0;
+        const double b = k < n_acc ? Yt[k * LDW + 16 * kt + lj] : 0.0;
+        acc = MFMA(a, b, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int R = 16 * ht + lg + 4 * r, Cc = 16 * kt + lj;
+        const bool in = R < m && Cc < m;
+        const double pold = in ? P_old[(size_t)R * m + Cc] : 0.0;
+        const double v = s_fin * (pold - acc[r]);
+        if (mode == 0 && wg == 0 && in && Cc <= R) {
+          P_new[(size_t)R * m + Cc] = v;
+          P_new[(size_t)Cc * m + R] = v;
+        }
+        double tv = 0.0;
+        if (in) tv = Cc < R ? 2.0 * v : (Cc == R ? v : 0.0);
+        T[q * NB_TILE + mv_kpos(Cc & 15) + mv_hpos(R & 15)] = tv;
+      }
+    }
+  }
   __syncthreads();
 
-  const int n_sel = n_batch < n ? (n_batch < MV_SEL ? n_batch : MV_SEL) : n;
+  // ---- B1: g_i = q_i^T P q_i for the workgroup's points ---------------------
+  const int base = wg * pb.ppw;
+  const int cnt = (n - base) < pb.ppw ? (n - base) : pb.ppw;
   const int ks_one = mv_slot(d) >> 2, lg_one = mv_slot(d) & 3;
-
-  for (int it = 0; it < n_max; ++it) {
-    // ---- 1. V = L D L^T by elimination on [V | I]: A -> D L^T, B -> L^-1 ---
+  for (int tile = wave; tile * 16 < cnt; tile += MV_WAVES) {
+    long long pt[1] = {(long long)base + tile * 16 + lj};
+    bool valid[1] = {tile * 16 + lj < cnt};
+    double xin[1][4 * DT];
+    load_points<DT, 1>(pb.xs, pt, valid, d, (long long)n, lane, xin);
 #pragma unroll
-    for (int q = 0; q < MV_EPT; ++q)
-      if (er[q] >= 0) {
-        A[er[q] * m + ec[q]] = V[er[q] * m + ec[q]];
-        B[er[q] * m + ec[q]] = (er[q] == ec[q]) ? 1.0 : 0.0;
-      }
-    __syncthreads();
-    for (int k = 0; k < m - 1; ++k) {
-      const double inv_d = 1.0 / A[k * m + k];
+    for (int ks = 0; ks < 4 * DT; ++ks)
+      if (ks == ks_one && lg == lg_one) xin[0][ks] = valid[0] ? 1.0 : 0.0;
+    double part = 0.0;
 #pragma unroll
-      for (int q = 0; q < MV_EPT; ++q) {
-        const int i = er[q], j = ec[q];
-        if (i > k) {
-          const double f = A[i * m + k] * inv_d;
-          if (j > k) A[i * m + j] -= f * A[k * m + j];
-          else B[i * m + j] -= f * B[k * m + j];
+    for (int ht = 0; ht < DT; ++ht) {
+      if (16 * ht < m) {
+        nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4 * (ht + 1); ++ks) {
+          const double a =
+              T[mv_tri(ht, ks >> 2) * NB_TILE + (ks & 3) * 64 + lane];
+          acc = MFMA(a, xin[0][ks], acc);
         }
-      }
-      __syncthreads();
-    }
-    if (tid < m) piv[tid] = 1.0 / A[tid * m + tid];       // 1 / d_k
-    __syncthreads();
-    // R^-1 = D^-1/2 L^-1 -> operand tiles;  V^-1 = L^-T D^-1 L^-1 -> A
 #pragma unroll
-    for (int q = 0; q < MV_EPT; ++q) {
-      const int r = er[q], c = ec[q];
-      if (r < 0) continue;
-      if (c <= r) {
-        const int sl = mv_slot(c), ks = sl >> 2, lgk = sl & 3;
-        tiles[((ks >> 2) * DT + (r >> 4)) * NB_TILE + (ks & 3) * 64 +
-              lgk * 16 + (r & 15)] = B[r * m + c] * sqrt(piv[r]);
+        for (int r = 0; r < 4; ++r) part += acc[r] * xin[0][4 * ht + r];
       }
     }
-    __syncthreads();           // A (D L^T) is dead from here
-#pragma unroll
-    for (int q = 0; q < MV_EPT; ++q) {
-      const int r = er[q], c = ec[q];
-      if (r < 0) continue;
-      double s = 0.0;
-      for (int k = (r > c ? r : c); k < m; ++k)
-        s += B[k * m + r] * B[k * m + c] * piv[k];
-      A[r * m + c] = s;
-    }
-
-    // ---- 2. g_i = |R^-1 q_i|^2 on the matrix cores (basic.py:220) ---------
-    for (int tile = wave; tile * 16 < n; tile += MV_WAVES) {
-      long long pt[1] = {(long long)tile * 16 + (lane & 15)};
-      bool valid[1] = {pt[0] < n};
-      double xin[1][4 * DT], y[1][4 * DT], r2[1];
-      bool box_bad[1];
-      load_points<DT, 1>(x, pt, valid, d, (long long)n, lane, xin);
-#pragma unroll
-      for (int ks = 0; ks < 4 * DT; ++ks)
-        if (ks == ks_one && lg == lg_one) xin[0][ks] = 1.0;
-      ell_eval<DT, 1>(ell, m, xin, lane, y, box_bad, r2);
-      if (valid[0] && lg == 0) {
-        if (g_in_lds) g_lds[pt[0]] = r2[0];
-        else g_glob[pt[0]] = r2[0];
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- 3. the n_batch largest g, descending (basic.py:221) --------------
-    for (int t = 0; t < n_sel; ++t) {
-      double bv = -inf;
-      int bi = -1;
-      for (int i = tid; i < n; i += MV_THREADS) {
-        const double v = g_in_lds ? g_lds[i] : g_glob[i];
-        if (v > bv || (v == bv && i > bi)) { bv = v; bi = i; }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(bv, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
-      }
-      // per-wave results are double buffered on the parity of t, so one
-      // barrier per round is enough; every thread merges them identically
-      double* rv = red_v + (t & 1) * MV_WAVES;
-      int* ri = red_i + (t & 1) * MV_WAVES;
-      if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
-      __syncthreads();
-      bv = rv[0]; bi = ri[0];
-#pragma unroll
-      for (int w = 1; w < MV_WAVES; ++w)
-        if (rv[w] > bv || (rv[w] == bv && ri[w] > bi)) { bv = rv[w]; bi = ri[w]; }
-      if (tid == 0) { sel_g[t] = bv; sel_i[t] = bi; }
-      // the thread that scans element bi retires it before its next scan
-      if ((bi % MV_THREADS) == tid) {
-        if (g_in_lds) g_lds[bi] = -inf;
-        else g_glob[bi] = -inf;
-      }
-    }
-    __syncthreads();
-    // the selected rows q_j = (x_j, 1), fetched in one go
-    for (int e = tid; e < n_sel * m; e += MV_THREADS) {
-      const int t = e / m, c = e - t * m;
-      qsel[t * DP + c] = (c < d) ? x[(long long)sel_i[t] * d + c] : 1.0;
-    }
-    __syncthreads();
-
-    // ---- 4. rank-one updates (basic.py:221-231) ---------------------------
-    for (int t = 0; t < n_sel; ++t) {
-      const double* qj = qsel + t * DP;
-      {  // w = V^-1 q_j: 8 lanes per row, products q_j[r] w[r] for g
-        const int r = tid >> 3, p = tid & 7;
-        double s = 0.0;
-        if (r < m)
-          for (int c = p; c < m; c += 8) s += A[r * m + c] * qj[c];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (p == 0 && r < 64) {
-          wv[r] = (r < m) ? s : 0.0;
-          pr[r] = (r < m) ? s * qj[r] : 0.0;
-        }
-      }
-      __syncthreads();
-      double gq = pr[lane];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) gq += __shfl_xor(gq, o);
-      if (t == 0) gq = sel_g[0];
-      if (gq >= (double)m) {
-        const double a = (gq - m) / ((double)m * (gq - 1.0));
-        const double ratio = a / (1.0 - a);
-        const double coef = ratio / (1.0 + ratio * gq);
-        const double inv1a = 1.0 / (1.0 - a);
-#pragma unroll
-        for (int q = 0; q < MV_EPT; ++q) {
-          const int r = er[q], c = ec[q];
-          if (r < 0) continue;
-          V[r * m + c] = V[r * m + c] * (1.0 - a) + a * (qj[r] * qj[c]);
-          A[r * m + c] = (A[r * m + c] - wv[r] * wv[c] * coef) * inv1a;
-        }
-        scale *= (1.0 - a);
-        if (tid == 0) u[sel_i[t]] += a / scale;
-      }
-      __syncthreads();
-    }
+    const double g = lane_group_sum(part);
+    if (valid[0] && lg == 0) gwg[tile * 16 + lj] = g;
   }
-  __threadfence_block();
+  for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS) {
+    L1g[e] = -inf;
+    L1i[e] = -1;
+  }
   __syncthreads();
-  for (int i = tid; i < n; i += MV_THREADS) u[i] *= scale;
+
+  // ---- B2: first level, wave w ranks its slice of the g values --------------
+  {
+    const int slice = (cnt + MV_WAVES - 1) / MV_WAVES;
+    const int s0 = wave * slice;
+    const int s1 = (s0 + slice) < cnt ? (s0 + slice) : cnt;
+    for (int i = s0 + lane; i < s1; i += 64) {
+      const double xg = gwg[i];
+      int rank = 0;
+      for (int j = s0; j < s1; ++j) rank += mv_before(gwg[j], j, xg, i) ? 1 : 0;
+      if (rank < K) {
+        L1g[wave * NSC + rank] = xg;
+        L1i[wave * NSC + rank] = base + i;
+      }
+    }
+    const int have = s1 > s0 ? s1 - s0 : 0;
+    if (lane == 0) L1n[wave] = have < K ? have : K;
+  }
+  __syncthreads();
+  // ---- B3: second level -> candidates of the next call ----------------------
+  {
+    double* og = pb.cand_g + ((size_t)cur * W + wg) * NSC;
+    int* oi = pb.cand_i + ((size_t)cur * W + wg) * (NSC + 1);
+    mv_select_l2(L1g, L1i, L1n, NSC, K, tid,
+                 [&](int rank, double g, int i) { og[rank] = g; oi[rank] = i; });
+    if (tid == 0) oi[NSC] = cnt < K ? cnt : K;
+  }
 }
 
+// u <- scale u (mode 0) / out = largest g over the lists (mode 1)
+__global__ void __launch_bounds__(256)
+nb_mvee_finish_kernel(MvBatch batch, int nsc, int mode, double* out) {
+  const MvProb pb = batch.p[blockIdx.y];
+  if (mode == 0) {
+    const double s = pb.state[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pb.n;
+         i += gridDim.x * blockDim.x)
+      pb.u[i] *= s;
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double best = -__builtin_huge_val();
+    for (int w = 0; w < pb.W; ++w) {
+      const double v = pb.cand_g[(size_t)w * nsc];
+      if (v > best) best = v;
+    }
+    out[blockIdx.y] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// S = sum_i w_i q_i q_i^T, q = (x, 1): lower block triangle of 16x16 tiles in
+// the accumulator layout, one partial sum per sub-group of wavefronts.  Wave w
+// of a sub-group owns the tile rows w and DT-1-w (balanced triangle).
+// ---------------------------------------------------------------------------
 template <int DT>
-int launch_mvee(const double* x, int n, int d, int n_max, int n_batch,
-                double* u, double* g, hipStream_t stream) {
+__global__ void __launch_bounds__(MV_THREADS)
+nb_moments_kernel(MomBatch batch, int d, int pts_per_wg) {
+  constexpr int GW = (DT + 1) / 2;            // waves per sub-group
+  constexpr int SG = MV_WAVES / GW;           // sub-groups per workgroup
+  constexpr int NT = DT * (DT + 1) / 2;
+  const MomProb pb = batch.p[blockIdx.y];
+  const int n = pb.n;
+  const int p0 = blockIdx.x * pts_per_wg;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sg = wave / GW, w = wave - sg * GW;
+  if (sg >= SG) return;
+  const int kp = lane >> 4, fi = lane & 15;
+  const int row_lo = w, row_hi = DT - 1 - w;
+  const bool two = row_hi != row_lo;
+
+  nb_d4 acc_lo[DT], acc_hi[DT];
+#pragma unroll
+  for (int j = 0; j < DT; ++j) {
+    acc_lo[j] = nb_d4{0.0, 0.0, 0.0, 0.0};
+    acc_hi[j] = nb_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const int p1 = (p0 + pts_per_wg) < n ? (p0 + pts_per_wg) : n;
+  for (int s = p0 + 4 * sg; s < p1; s += 4 * SG) {
+    const int p = s + kp;
+    const bool on = p < p1;
+    const double wp = on ? (pb.w != nullptr ? pb.w[p] : 1.0) : 0.0;
+    double b[DT];
+#pragma unroll
+    for (int ft = 0; ft < DT; ++ft) {
+      const int f = 16 * ft + fi;
+      double v = 0.0;
+      if (on && f < d) v = pb.x[(size_t)p * d + f];
+      else if (on && f == d) v = 1.0;
+      b[ft] = v;
+    }
+    double a_lo, a_hi;
+    {
+      const int f = 16 * row_lo + fi;
+      double v = 0.0;
+      if (on && f < d) v = pb.x[(size_t)p * d + f];
+      else if (on && f == d) v = 1.0;
+      a_lo = v * wp;
+      const int f2 = 16 * row_hi + fi;
+      v = 0.0;
+      if (on && f2 < d) v = pb.x[(size_t)p * d + f2];
+      else if (on && f2 == d) v = 1.0;
+      a_hi = v * wp;
+    }
+#pragma unroll
+    for (int jt = 0; jt < DT; ++jt) {
+      if (jt <= row_lo) acc_lo[jt] = MFMA(a_lo, b[jt], acc_lo[jt]);
+      if (two && jt <= row_hi) acc_hi[jt] = MFMA(a_hi, b[jt], acc_hi[jt]);
+    }
+  }
+  double* out = pb.partial + ((size_t)blockIdx.x * SG + sg) * NT * NB_TILE;
+#pragma unroll
+  for (int jt = 0; jt < DT; ++jt) {
+    if (jt <= row_lo) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[mv_tri(row_lo, jt) * NB_TILE + r * 64 + lane] = acc_lo[jt][r];
+    }
+    if (two && jt <= row_hi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[mv_tri(row_hi, jt) * NB_TILE + r * 64 + lane] = acc_hi[jt][r];
+    }
+  }
+}
+
+__device__ __forceinline__ double mom_element(const double* partial, int vw,
+                                              int nt, int r, int c) {
+  // entry (r, c) with r >= c summed over the partial results in fixed order
+  const int it = r >> 4, jt = c >> 4, i = r & 15, j = c & 15;
+  const int off = mv_tri(it, jt) * NB_TILE + (i >> 2) * 64 + (i & 3) * 16 + j;
+  double s = 0.0;
+  for (int v = 0; v < vw; ++v) s += partial[(size_t)v * nt * NB_TILE + off];
+  return s;
+}
+
+// out[r][c] = S[r][c] * scale, full symmetric row-major (m x m)
+__global__ void __launch_bounds__(256)
+nb_moments_reduce_kernel(MomBatch batch, int d, int vw, int nt, double scale) {
+  const MomProb pb = batch.p[blockIdx.y];
   const int m = d + 1;
-  const int mm = (m * m + 1) & ~1;
-  size_t lds = ((size_t)3 * mm + nb_ell_block_size(DT) +
-                (size_t)(n_batch < MV_SEL ? n_batch : MV_SEL) * 16 * DT) *
-               sizeof(double);
-  // the quadratic forms g stay in LDS when they fit next to the matrices
-  const size_t room = (size_t)156 * 1024;
-  const int g_in_lds = lds + (size_t)n * sizeof(double) <= room ? 1 : 0;
-  if (g_in_lds) lds += (size_t)n * sizeof(double);
-  static size_t allowed = 0;
-  if (lds > allowed) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m * m;
+       e += gridDim.x * blockDim.x) {
+    const int r = e / m, c = e - r * m;
+    const int hi = r > c ? r : c, lo = r > c ? c : r;
+    pb.out[e] = mom_element(pb.partial, vw, nt, hi, lo) * scale;
+  }
+}
+
+// P_0 = (S / n)^-1: in-place Gauss-Jordan of a symmetric positive definite
+// matrix held in LDS, one workgroup per problem
+__global__ void __launch_bounds__(MV_THREADS)
+nb_spd_inverse_kernel(MomBatch batch, int d, int vw, int nt) {
+  extern __shared__ __attribute__((aligned(16))) double A[];
+  const MomProb pb = batch.p[blockIdx.y];
+  const int m = d + 1, tid = threadIdx.x;
+  const double inv_n = 1.0 / (double)pb.n;
+  int er[MV_GJ_EPT], ec[MV_GJ_EPT];
+#pragma unroll
+  for (int q = 0; q < MV_GJ_EPT; ++q) {
+    const int e = tid + q * MV_THREADS;
+    er[q] = e < m * m ? e / m : -1;
+    ec[q] = e < m * m ? e - er[q] * m : 0;
+    if (er[q] >= 0) {
+      const int hi = er[q] > ec[q] ? er[q] : ec[q];
+      const int lo = er[q] > ec[q] ? ec[q] : er[q];
+      A[e] = mom_element(pb.partial, vw, nt, hi, lo) * inv_n;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    const double p = 1.0 / A[k * m + k];
+#pragma unroll
+    for (int q = 0; q < MV_GJ_EPT; ++q) {
+      const int i = er[q], j = ec[q];
+      if (i >= 0 && i != k && j != k)
+        A[i * m + j] -= A[i * m + k] * A[k * m + j] * p;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MV_GJ_EPT; ++q) {
+      const int i = er[q], j = ec[q];
+      if (i < 0) continue;
+      if (i == k && j == k) A[k * m + k] = p;
+      else if (i == k) A[k * m + j] *= p;
+      else if (j == k) A[i * m + k] *= -p;
+    }
+    __syncthreads();
+  }
+  // symmetrise on the way out (the two triangles agree to rounding)
+#pragma unroll
+  for (int q = 0; q < MV_GJ_EPT; ++q) {
+    const int i = er[q], j = ec[q];
+    if (i < 0) continue;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    pb.out[i * m + j] = A[hi * m + lo];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct MvPlan {
+  int W, ppw;
+};
+
+inline bool mv_plan(long long n, MvPlan* pl) {
+  long long ppw = 128;
+  long long W = (n + ppw - 1) / ppw;
+  if (W > MV_MAXW) {
+    W = MV_MAXW;
+    ppw = ((n + W - 1) / W + 15) / 16 * 16;
+    W = (n + ppw - 1) / ppw;
+  }
+  if (ppw > MV_MAXPPW) return false;
+  pl->W = (int)W;
+  pl->ppw = (int)ppw;
+  return true;
+}
+
+inline int mom_pts_per_wg(long long n_max) {
+  long long p = 512;
+  while ((n_max + p - 1) / p > 64) p *= 2;
+  return (int)p;
+}
+inline int mom_sg(int dt) { return MV_WAVES / ((dt + 1) / 2); }
+
+template <typename F>
+int set_lds(F* fn, size_t bytes, size_t* allowed) {
+  if (bytes > *allowed) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_mvee_kernel<DT>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
-      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
+      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", bytes,
                    hipGetErrorString(e));
       return NB_ERR_HIP;
     }
-    allowed = lds;
+    *allowed = bytes;
   }
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(nb_mvee_kernel<DT>, dim3(1), dim3(MV_THREADS), lds, stream,
-                     x, n, d, n_max, n_batch, u, g, g_in_lds);
   return NB_OK;
+}
+
+template <int DT, int NSC>
+int launch_sweep(const MvBatch& b, int nb, int wmax, int d, int n_batch,
+                 int call, int n_calls, int mode, int ppw_max,
+                 hipStream_t stream) {
+  static size_t allowed = 0;
+  const size_t bytes = (size_t)mv_layout(DT, NSC, ppw_max).total * sizeof(double);
+  if (bytes > 160 * 1024) {
+    nb_set_error("device MVEE: %zu bytes of LDS needed (n_batch too large for "
+                 "this n_dim)", bytes);
+    return NB_ERR_UNSUPPORTED;
+  }
+  const int rc = set_lds(nb_mvee_sweep_kernel<DT, NSC>, bytes, &allowed);
+  if (rc != NB_OK) return rc;
+  const bool last = mode == 0 && call > 0 && call == n_calls - 1;
+  hipLaunchKernelGGL((nb_mvee_sweep_kernel<DT, NSC>), dim3(last ? 1 : wmax, nb),
+                     dim3(MV_THREADS), bytes, stream, b, d, n_batch, call,
+                     n_calls, mode, ppw_max);
+  return NB_OK;
+}
+
+template <int NSC>
+int dispatch_sweep(int dt, const MvBatch& b, int nb, int wmax, int d,
+                   int n_batch, int call, int n_calls, int mode, int ppw_max,
+                   hipStream_t stream) {
+  switch (dt) {
+#define NB_CASE(DT_)                                                          \
+    case DT_:                                                                 \
+      return launch_sweep<DT_, NSC>(b, nb, wmax, d, n_batch, call, n_calls,   \
+                                    mode, ppw_max, stream);
+    NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
+    NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
+#undef NB_CASE
+  }
+  nb_set_error("device MVEE supports n_dim <= 128");
+  return NB_ERR_UNSUPPORTED;
+}
+
+int launch_moments(int dt, const MomBatch& b, int nb, int d, int wg, int ppw,
+                   hipStream_t stream) {
+  switch (dt) {
+#define NB_CASE(DT_)                                                          \
+    case DT_:                                                                 \
+      hipLaunchKernelGGL(nb_moments_kernel<DT_>, dim3(wg, nb),                \
+                         dim3(MV_THREADS), 0, stream, b, d, ppw);             \
+      return NB_OK;
+    NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
+    NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
+#undef NB_CASE
+  }
+  nb_set_error("device moments support n_dim <= 128");
+  return NB_ERR_UNSUPPORTED;
+}
+
+inline long long mom_partial_doubles(long long n_max, int dt) {
+  const int ppw = mom_pts_per_wg(n_max);
+  const long long wg = (n_max + ppw - 1) / ppw;
+  return wg * mom_sg(dt) * (long long)(dt * (dt + 1) / 2) * NB_TILE;
+}
+
+inline int nsc_of(int n_batch) { return n_batch <= 20 ? 20 : 32; }
+
+inline long long mv_prob_doubles(long long n_max, int d, int nsc) {
+  const int m = d + 1, dt = (m + 15) / 16;
+  long long t = 2LL * m * m + 2;                          // P
+  t += 2LL * MV_MAXW * nsc;                               // cand_g
+  t += (2LL * MV_MAXW * (nsc + 1) + 1) / 2 + 1;           // cand_i
+  t += 4;                                                 // state
+  t += mom_partial_doubles(n_max, dt);
+  return (t + 1) & ~1LL;
 }
 
 }  // namespace
 
-// host entry used by nb_api.hip.  n_dim + 1 <= 64 (the three matrices and the
-// operand tiles must fit the 160 KB of LDS).
-int nb_launch_mvee(const double* x, long long n, int n_dim, int n_max,
-                   int n_batch, double* u, double* g, hipStream_t stream) {
-  if (n_dim < 1 || n_dim + 1 > 64) {
-    nb_set_error("device MVEE supports n_dim <= 63 (got %d)", n_dim);
-    return NB_ERR_UNSUPPORTED;
-  }
-  if (n <= n_dim || n > 2147483647LL / (n_dim > 0 ? n_dim : 1)) {
-    nb_set_error("device MVEE needs n_dim < n (n=%lld, n_dim=%d)", n, n_dim);
+long long nb_mvee_work_doubles_impl(int n_problems, long long n_max, int d,
+                                    int n_batch) {
+  return (long long)n_problems * mv_prob_doubles(n_max, d, nsc_of(n_batch)) + 64;
+}
+
+long long nb_moments_work_doubles_impl(long long n, int d) {
+  const int dt = (d + 1 + 15) / 16;
+  return mom_partial_doubles(n, dt) + 16;
+}
+
+// S = sum_i w_i q_i q_i^T (w = null: unit weights), scaled, into out[m*m]
+int nb_launch_moments(const double* x, const double* w, long long n, int d,
+                      double scale, double* out, double* work,
+                      hipStream_t stream) {
+  if (d < 1 || d > 128 || n < 1 || n > 2147483647LL / (d + 1)) {
+    nb_set_error("device moments: bad shape (n=%lld, n_dim=%d)", n, d);
     return NB_ERR_ARG;
   }
-  if (n_batch < 1 || n_batch > 64 || n_max < 0) {
-    nb_set_error("device MVEE: n_batch must be in 1..64");
-    return NB_ERR_ARG;
-  }
-  const int dt = (n_dim + 1 + 15) / 16;
-  int rc = NB_OK;
-  switch (dt) {
-    case 1: rc = launch_mvee<1>(x, (int)n, n_dim, n_max, n_batch, u, g, stream); break;
-    case 2: rc = launch_mvee<2>(x, (int)n, n_dim, n_max, n_batch, u, g, stream); break;
-    case 3: rc = launch_mvee<3>(x, (int)n, n_dim, n_max, n_batch, u, g, stream); break;
-    default: rc = launch_mvee<4>(x, (int)n, n_dim, n_max, n_batch, u, g, stream); break;
-  }
+  const int dt = (d + 1 + 15) / 16;
+  const int ppw = mom_pts_per_wg(n);
+  const int wg = (int)((n + ppw - 1) / ppw);
+  MomBatch b;
+  memset(&b, 0, sizeof(b));
+  b.p[0].x = x; b.p[0].w = w; b.p[0].n = (int)n;
+  b.p[0].partial = work; b.p[0].out = out;
+  int rc = launch_moments(dt, b, 1, d, wg, ppw, stream);
   if (rc != NB_OK) return rc;
+  const int m = d + 1;
+  hipLaunchKernelGGL(nb_moments_reduce_kernel, dim3((m * m + 255) / 256, 1),
+                     dim3(256), 0, stream, b, d, wg * mom_sg(dt),
+                     dt * (dt + 1) / 2, scale);
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;
+}
+
+// The Khachiyan iteration for n_problems point sets (standardised points).
+int nb_launch_mvee_batch(int n_problems, const double* const* xs,
+                         const long long* n, int d, int n_max, int n_batch,
+                         double* const* u, double* work, hipStream_t stream) {
+  if (d < 1 || d > 128) {
+    nb_set_error("device MVEE supports n_dim <= 128 (got %d)", d);
+    return NB_ERR_UNSUPPORTED;
+  }
+  if (n_batch < 1 || n_batch > 32 || n_max < 0) {
+    nb_set_error("device MVEE: n_batch must be in 1..32");
+    return NB_ERR_ARG;
+  }
+  const int m = d + 1, dt = (m + 15) / 16, nsc = nsc_of(n_batch);
+  long long n_hi = 0;
+  for (int b = 0; b < n_problems; ++b) {
+    if (n[b] <= d || n[b] > 2147483647LL / m) {
+      nb_set_error("device MVEE needs n_dim < n (n=%lld, n_dim=%d)", n[b], d);
+      return NB_ERR_ARG;
+    }
+    if (n[b] > n_hi) n_hi = n[b];
+  }
+  const long long stride = mv_prob_doubles(n_hi, d, nsc);
+  const int mom_ppw = mom_pts_per_wg(n_hi);
+  const int nt = dt * (dt + 1) / 2;
+
+  for (int b0 = 0; b0 < n_problems; b0 += MV_MAXB) {
+    const int nb = (n_problems - b0) < MV_MAXB ? (n_problems - b0) : MV_MAXB;
+    MvBatch mb;
+    MomBatch qb;
+    memset(&mb, 0, sizeof(mb));
+    memset(&qb, 0, sizeof(qb));
+    int wmax = 0, ppw_max = 0, mom_wg = 0;
+    for (int b = 0; b < nb; ++b) {
+      MvPlan pl;
+      if (!mv_plan(n[b0 + b], &pl)) {
+        nb_set_error("device MVEE: too many points (n=%lld)", n[b0 + b]);
+        return NB_ERR_UNSUPPORTED;
+      }
+      double* base = work + (size_t)(b0 + b) * stride;
+      MvProb& p = mb.p[b];
+      p.xs = xs[b0 + b];
+      p.u = u[b0 + b];
+      p.n = (int)n[b0 + b];
+      p.W = pl.W;
+      p.ppw = pl.ppw;
+      p.P = base; base += 2LL * m * m + 2;
+      p.cand_g = base; base += 2LL * MV_MAXW * nsc;
+      p.cand_i = (int*)base; base += (2LL * MV_MAXW * (nsc + 1) + 1) / 2 + 1;
+      p.state = base; base += 4;
+      MomProb& q = qb.p[b];
+      q.x = xs[b0 + b];
+      q.w = nullptr;
+      q.n = p.n;
+      q.partial = base;
+      q.out = p.P;                 // P[0] = (S / n)^-1
+      if (pl.W > wmax) wmax = pl.W;
+      if (pl.ppw > ppw_max) ppw_max = pl.ppw;
+      const int wg = (p.n + mom_ppw - 1) / mom_ppw;
+      if (wg > mom_wg) mom_wg = wg;
+    }
+    // every problem uses mom_wg workgroups (idle ones write zeros)
+    int rc = launch_moments(dt, qb, nb, d, mom_wg, mom_ppw, stream);
+    if (rc != NB_OK) return rc;
+    {
+      static size_t allowed = 0;
+      const size_t bytes = (size_t)m * m * sizeof(double);
+      rc = set_lds(nb_spd_inverse_kernel, bytes, &allowed);
+      if (rc != NB_OK) return rc;
+      hipLaunchKernelGGL(nb_spd_inverse_kernel, dim3(1, nb), dim3(MV_THREADS),
+                         bytes, stream, qb, d, mom_wg * mom_sg(dt), nt);
+    }
+    const int n_calls = n_max + 1;
+    for (int call = 0; call < n_calls; ++call) {
+      rc = nsc == 20
+               ? dispatch_sweep<20>(dt, mb, nb, wmax, d, n_batch, call, n_calls,
+                                    0, ppw_max, stream)
+               : dispatch_sweep<32>(dt, mb, nb, wmax, d, n_batch, call, n_calls,
+                                    0, ppw_max, stream);
+      if (rc != NB_OK) return rc;
+    }
+    hipLaunchKernelGGL(nb_mvee_finish_kernel, dim3(8, nb), dim3(256), 0, stream,
+                       mb, nsc, 0, (double*)nullptr);
+  }
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+// out[0] = max_i q_i^T P q_i, q = (x, 1), P (m x m) symmetric in p_dev
+int nb_launch_quadform_max(const double* x, long long n, int d,
+                           const double* p_dev, double* out, double* work,
+                           hipStream_t stream) {
+  if (d < 1 || d > 128 || n < 1 || n > 2147483647LL / (d + 1)) {
+    nb_set_error("quadratic form: bad shape (n=%lld, n_dim=%d)", n, d);
+    return NB_ERR_ARG;
+  }
+  const int m = d + 1, dt = (m + 15) / 16;
+  MvPlan pl;
+  if (!mv_plan(n, &pl)) {
+    nb_set_error("quadratic form: too many points (n=%lld)", n);
+    return NB_ERR_UNSUPPORTED;
+  }
+  MvBatch mb;
+  memset(&mb, 0, sizeof(mb));
+  MvProb& p = mb.p[0];
+  p.xs = x;
+  p.n = (int)n;
+  p.W = pl.W;
+  p.ppw = pl.ppw;
+  p.P = const_cast<double*>(p_dev);
+  p.cand_g = work;
+  p.cand_i = (int*)(work + 2LL * MV_MAXW * 20);
+  p.state = work;                       // unused in mode 1
+  int rc = dispatch_sweep<20>(dt, mb, 1, pl.W, d, 1, 0, 1, 1, pl.ppw, stream);
+  if (rc != NB_OK) return rc;
+  hipLaunchKernelGGL(nb_mvee_finish_kernel, dim3(1, 1), dim3(256), 0, stream,
+                     mb, 20, 1, out);
+  NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+long long nb_quadform_work_doubles_impl() {
+  return 2LL * MV_MAXW * 20 + (2LL * MV_MAXW * 21 + 1) / 2 + 8;
 }

@@ -252,20 +252,112 @@ class DeviceBoundList:
         return idx
 
 
-MVEE_MAX_DIM = 63     # nb_mvee_weights keeps three (D+1)^2 matrices in LDS
+MAX_DIM = 128          # n_dim limit of the device kernels
+
+
+def _work(n_doubles):
+    return torch.empty(int(n_doubles), dtype=torch.float64, device='cuda')
 
 
 def mvee_weights(x, n_max=100, n_batch=20):
     """Weights u of the batched Khachiyan iteration (reference
-    bounds/basic.py:175-232) for the rows of the cuda tensor / array ``x``."""
+    bounds/basic.py:175-232) for the rows of the cuda tensor / array ``x``
+    -- ``nb_mvee_weights``."""
     lib = _lib.load()
     x = as_device_points(x)
     n, d = x.shape
     u = torch.empty(n, dtype=torch.float64, device='cuda')
-    scratch = torch.empty(n, dtype=torch.float64, device='cuda')
+    work = _work(lib.nb_mvee_weights_work_doubles(n, d, n_batch))
     _lib.check(lib.nb_mvee_weights(_ptr(x), n, d, n_max, n_batch, _ptr(u),
-                                   _ptr(scratch), _stream()))
+                                   _ptr(work), _stream()))
     return u
+
+
+def weighted_moments(x, w=None, scale=1.0):
+    """scale * sum_i w_i q_i q_i^T with q_i = (x_i, 1) as an (n_dim+1)^2 cuda
+    tensor -- ``nb_weighted_moments``."""
+    lib = _lib.load()
+    x = as_device_points(x)
+    n, d = x.shape
+    out = torch.empty((d + 1, d + 1), dtype=torch.float64, device='cuda')
+    work = _work(lib.nb_moments_work_doubles(n, d))
+    _lib.check(lib.nb_weighted_moments(
+        _ptr(x), _ptr(w) if w is not None else None, n, d, float(scale),
+        _ptr(out), _ptr(work), _stream()))
+    return out
+
+
+def quadform_max(x, p):
+    """max_i q_i^T P q_i, q_i = (x_i, 1), as a one-element cuda tensor --
+    ``nb_quadform_max``."""
+    lib = _lib.load()
+    x = as_device_points(x)
+    n, d = x.shape
+    p = torch.as_tensor(p, dtype=torch.float64).to('cuda').contiguous()
+    out = torch.empty(1, dtype=torch.float64, device='cuda')
+    work = _work(lib.nb_quadform_work_doubles())
+    _lib.check(lib.nb_quadform_max(_ptr(x), n, d, _ptr(p), _ptr(out),
+                                   _ptr(work), _stream()))
+    return out
+
+
+def mvee_fit_batch(point_sets, n_max=100, n_batch=20):
+    """minimum_volume_enclosing_ellipsoid (reference bounds/basic.py:175-241)
+    for several point sets of one dimension at once.
+
+    Every set is standardised on the device (``nb_standardize``), the
+    Khachiyan iterations of all sets advance side by side in the same
+    launches (``nb_mvee_khachiyan``), centre and covariance follow from the
+    weights with one matrix-core pass (``nb_weighted_moments``, basic.py:
+    233-234) and the scaling from the largest quadratic form
+    (``nb_quadform_max``, basic.py:236).  Only (n_dim+1)^2 numbers per set
+    cross PCIe.  Returns a list of (c, A, A_inv) like the reference."""
+    lib = _lib.load()
+    xs, means, sds, us = [], [], [], []
+    for pts in point_sets:
+        x = as_device_points(pts)
+        mean, sd, x_std = standardize(x)
+        xs.append(x_std)
+        means.append(mean)
+        sds.append(sd)
+        us.append(torch.empty(x.shape[0], dtype=torch.float64, device='cuda'))
+    nb = len(xs)
+    d = xs[0].shape[1]
+    n_arr = (C.c_int64 * nb)(*[x.shape[0] for x in xs])
+    work = _work(lib.nb_mvee_work_doubles(nb, max(n_arr), d, n_batch))
+    _lib.check(lib.nb_mvee_khachiyan(
+        nb, (C.c_void_p * nb)(*[x.data_ptr() for x in xs]), n_arr, d, n_max,
+        n_batch, (C.c_void_p * nb)(*[u.data_ptr() for u in us]), _ptr(work),
+        _stream()))
+    moments = torch.stack([weighted_moments(x, u) for x, u in zip(xs, us)])
+    moments = moments.cpu().numpy()
+    stats = torch.stack(means + sds).cpu().numpy()
+    # host: (n_dim+1)^2 matrices only
+    p_all, c_all, cov_all = [], [], []
+    for s in moments:
+        su = s[d, d]
+        c = s[d, :d] / su                               # basic.py:233
+        cov = s[:d, :d] / su - np.outer(c, c)           # basic.py:234
+        cov = 0.5 * (cov + cov.T)
+        v = np.empty((d + 1, d + 1))
+        v[:d, :d] = s[:d, :d] / su
+        v[d, :d] = v[:d, d] = c
+        v[d, d] = 1.0
+        p_all.append(np.linalg.inv(v))
+        c_all.append(c)
+        cov_all.append(cov)
+    gmax = torch.cat([quadform_max(x, p) for x, p in zip(xs, p_all)])
+    gmax = gmax.cpu().numpy()
+    out = []
+    for b in range(nb):
+        mean, sd = stats[b], stats[nb + b]
+        scale = gmax[b] - 1.0                           # basic.py:236
+        a_std = np.linalg.inv(cov_all[b])
+        c = mean + sd * c_all[b]
+        a = a_std / np.outer(sd, sd) / scale
+        a_inv = cov_all[b] * np.outer(sd, sd) * scale
+        out.append((c, a, a_inv))
+    return out
 
 
 def standardize(x):

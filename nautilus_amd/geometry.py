@@ -1,11 +1,13 @@
 """Host-side construction of the bound geometry (small, sequential numerics).
 
-Bound *construction* runs a handful of times per bound on ~n_live points.  Its
-numerically heavy piece, the Khachiyan iteration of the minimum-volume
-enclosing ellipsoid, runs on the GPU (``nb_mvee_weights``); the O(D^3)
-finishing steps, the greedy cube/ellipsoid choice, the two-component mixture
-split and the ellipsoid overlap test stay on the host (SURVEY.md section 8,
-rows f1/f2).  What is built here is uploaded once through ``nb_bound_create``;
+Bound *construction* runs a handful of times per bound on ~n_live points.
+Everything that touches the points -- the Khachiyan iteration of the
+minimum-volume enclosing ellipsoid, its weighted moments and scaling, the
+two-component mixture fit -- runs on the GPU (``nb_mvee_khachiyan``,
+``nb_weighted_moments``, ``nb_quadform_max``, ``nb_gmm_fit``), batched over the
+point sets that are independent of each other; O(D^3) operations on single
+(D x D) matrices, the greedy cube/ellipsoid choice and the ellipsoid overlap
+test stay on the host.  What is built here is uploaded once through ``nb_bound_create``;
 every per-point operation afterwards (draw, contains, emulator, compaction)
 runs on the GPU.
 
@@ -16,8 +18,10 @@ bounds/basic.py:154-241 (MVEE), 265-316 (Ellipsoid.compute), 471-563
 """
 
 import itertools
+from collections import OrderedDict
 
 import numpy as np
+import xxhash
 from scipy.linalg.lapack import dpotrf, dpotri
 from scipy.optimize import minimize
 from scipy.special import gammaln, logsumexp
@@ -30,71 +34,56 @@ def inv_spd(m):
     return tri + tri.T - np.diag(np.diag(tri))
 
 
-def khachiyan_weights_host(points, n_max=100, n_batch=20):
-    """Weights u of the batched Khachiyan iteration (reference
-    bounds/basic.py:175-232) on the host -- used for n_dim > 63, where the
-    device kernel's matrices no longer fit the LDS.  Unlike the reference the
-    (n, D+1, D+1) tensor of outer products is never materialised: the
-    quadratic forms are computed as row sums of (Q V^-1) * Q."""
-    n, d = points.shape
-    q = np.empty((n, d + 1))
-    q[:, :d] = points
-    q[:, d] = 1.0
-    u = np.full(n, 1.0 / n)
-    v = (q * u[:, None]).T @ q
-    for _ in range(n_max):
-        # V^-1 is re-factorised once per sweep and then tracked through the
-        # <= n_batch rank-one updates with the Sherman-Morrison identity
-        # (the reference re-factorises after every update, basic.py:230)
-        v_inv = inv_spd(v)
-        g_all = np.einsum('ij,ij->i', q @ v_inv, q)
-        first = True
-        for j in np.argsort(g_all)[-n_batch:][::-1]:
-            qj = q[j]
-            w = v_inv @ qj
-            g = g_all[j] if first else qj @ w
-            first = False
-            if g < d + 1:
-                continue
-            step = (g - (d + 1)) / ((d + 1) * (g - 1))
-            v = v * (1 - step) + step * np.outer(qj, qj)
-            ratio = step / (1 - step)
-            v_inv = (v_inv - np.outer(w, w) * (ratio / (1 + ratio * g))) / \
-                (1 - step)
-            u *= (1 - step)
-            u[j] += step
-    return u
-
-
-def khachiyan_weights(points, n_max=100, n_batch=20):
-    """The iteration runs on the GPU (``nb_mvee_weights``: one persistent
-    workgroup, quadratic forms on the matrix cores) whenever the dimension
-    allows it."""
+def mvee_batch(point_sets, n_max=100, n_batch=20):
+    """Minimum-volume enclosing ellipsoids (reference bounds/basic.py:175-241)
+    of several point sets at once; everything that touches the points runs on
+    the GPU (``device.mvee_fit_batch``).  Returns a list of (c, A, A^-1)."""
     from . import device
-    if points.shape[1] <= device.MVEE_MAX_DIM:
-        return device.mvee_weights(points, n_max, n_batch).cpu().numpy()
-    return khachiyan_weights_host(points, n_max, n_batch)
+    out = [None] * len(point_sets)
+    by_dim = {}
+    for i, pts in enumerate(point_sets):
+        by_dim.setdefault(pts.shape[1], []).append(i)
+    for idx in by_dim.values():
+        res = device.mvee_fit_batch([point_sets[i] for i in idx], n_max,
+                                    n_batch)
+        for i, r in zip(idx, res):
+            out[i] = r
+    return out
 
 
 def mvee(points, n_max=100, n_batch=20):
-    """Minimum-volume enclosing ellipsoid (reference bounds/basic.py:175-241):
-    Khachiyan weights, then centre / covariance / scaling (:233-241).
-
-    Returns centre c, shape matrix A ((x-c)^T A (x-c) <= 1) and A^-1.
-    """
-    points = np.ascontiguousarray(points, dtype=float)
-    u = khachiyan_weights(points, n_max, n_batch)
-    c = np.atleast_1d(np.average(points, weights=u, axis=0))
-    a_inv = np.atleast_2d(np.cov(points, aweights=u, rowvar=False, bias=True))
-    a = np.linalg.inv(a_inv)
-    diff = points - c
-    scale = np.amax(np.einsum('ij,ij->i', diff @ a, diff))
-    return c, a / scale, a_inv * scale
+    """One minimum-volume enclosing ellipsoid: centre c, shape matrix A
+    ((x-c)^T A (x-c) <= 1) and A^-1."""
+    return mvee_batch([points], n_max, n_batch)[0]
 
 
-def ellipsoid_params(points, enlarge_per_dim=1.1):
-    """Ellipsoid.compute (bounds/basic.py:265-316): returns dict(c, A, B,
-    B_inv) with B = chol(A^-1) lower triangular and B_inv = B^-1."""
+# Ellipsoids are functions of (point set, enlargement) only -- no random
+# numbers are consumed -- and the construction of one NautilusBound asks for
+# the ellipsoid of the same rows several times (the decomposition, the neural
+# bounds and the sampling envelope all start from the live points,
+# nautilus.py:100-133).  A few recent results are kept.
+_ELL_CACHE = OrderedDict()
+_ELL_CACHE_SIZE = 16
+
+
+def _host_rows(points):
+    if hasattr(points, 'is_cuda'):
+        return None
+    return np.ascontiguousarray(points, dtype=float)
+
+
+def _cache_key(points, enlarge_per_dim):
+    rows = _host_rows(points)
+    if rows is None:
+        return None
+    return (rows.shape, xxhash.xxh64(rows.view(np.uint8).reshape(-1)).digest(),
+            float(enlarge_per_dim))
+
+
+def _ellipsoid_task(points, enlarge_per_dim):
+    """Ellipsoid.compute (bounds/basic.py:265-316) as a coroutine: yields the
+    point set whose MVEE it needs, receives (c, A, A^-1) and returns
+    dict(c, A, B, B_inv) with B = chol(A^-1) lower triangular, B_inv = B^-1."""
     n, d = points.shape
     if enlarge_per_dim < 1.0:
         raise ValueError("The 'enlarge_per_dim' factor cannot be smaller "
@@ -102,13 +91,57 @@ def ellipsoid_params(points, enlarge_per_dim=1.1):
     if not n > d:
         raise ValueError('Number of points must be larger than number '
                          'dimensions.')
-    with threadpool_limits(limits=1):
-        c, a, a_inv = mvee(points)
+    key = _cache_key(points, enlarge_per_dim)
+    if key is not None and key in _ELL_CACHE:
+        _ELL_CACHE.move_to_end(key)
+        return dict(_ELL_CACHE[key])
+    c, a, a_inv = yield points
     a = a / enlarge_per_dim**2.0
     a_inv = a_inv * enlarge_per_dim**2.0
     b = np.linalg.cholesky(a_inv)
     b_inv = np.tril(np.linalg.inv(b))
-    return dict(c=c, A=a, B=b, B_inv=b_inv)
+    out = dict(c=c, A=a, B=b, B_inv=b_inv)
+    if key is not None:
+        _ELL_CACHE[key] = dict(out)
+        while len(_ELL_CACHE) > _ELL_CACHE_SIZE:
+            _ELL_CACHE.popitem(last=False)
+    return out
+
+
+def run_tasks(tasks):
+    """Drive several construction coroutines in lockstep: the MVEE requests
+    they have pending at the same time (the two children of a split, the
+    neural-bound ellipsoids of one NautilusBound) go to the GPU as ONE batch.
+    Returns the coroutines' return values."""
+    out = [None] * len(tasks)
+    pending = {}
+    for i, task in enumerate(tasks):
+        try:
+            pending[i] = next(task)
+        except StopIteration as stop:
+            out[i] = stop.value
+    while pending:
+        idx = list(pending)
+        with threadpool_limits(limits=1):
+            res = mvee_batch([pending[i] for i in idx])
+        pending = {}
+        for i, r in zip(idx, res):
+            try:
+                pending[i] = tasks[i].send(r)
+            except StopIteration as stop:
+                out[i] = stop.value
+    return out
+
+
+def ellipsoid_params_batch(point_sets, enlarge_per_dim=1.1):
+    return run_tasks([_ellipsoid_task(p, enlarge_per_dim)
+                      for p in point_sets])
+
+
+def ellipsoid_params(points, enlarge_per_dim=1.1):
+    """Ellipsoid.compute (bounds/basic.py:265-316): returns dict(c, A, B,
+    B_inv) with B = chol(A^-1) lower triangular and B_inv = B^-1."""
+    return ellipsoid_params_batch([points], enlarge_per_dim)[0]
 
 
 def ellipsoid_log_volume(b):
@@ -118,11 +151,12 @@ def ellipsoid_log_volume(b):
             gammaln(d / 2.0 + 1))
 
 
-def mixture_params(points, enlarge_per_dim=1.1):
+def _mixture_task(points, enlarge_per_dim):
     """Greedy choice of the dimensions bounded by the unit cube
-    (bounds/basic.py:471-563).  Returns (dim_cube, ellipsoid dict or None)."""
+    (bounds/basic.py:471-563) as a coroutine (see ``_ellipsoid_task``).
+    Returns (dim_cube, ellipsoid dict or None)."""
     d = points.shape[1]
-    ell = ellipsoid_params(points, enlarge_per_dim)
+    ell = yield from _ellipsoid_task(points, enlarge_per_dim)
     log_v = ellipsoid_log_volume(ell['B'])
     dim_cube = np.zeros(d, dtype=bool)
 
@@ -145,7 +179,8 @@ def mixture_params(points, enlarge_per_dim=1.1):
                    (k - 1) * np.log(scale))
         dim = free[np.argmin(trial_v)]
         dim_cube[dim] = True
-        cand = ellipsoid_params(points[:, ~dim_cube], enlarge_per_dim)
+        cand = yield from _ellipsoid_task(points[:, ~dim_cube],
+                                          enlarge_per_dim)
         cand_v = ellipsoid_log_volume(cand['B'])
         if cand_v < log_v:
             ell, log_v = cand, cand_v
@@ -163,7 +198,8 @@ def mixture_params(points, enlarge_per_dim=1.1):
             for dim in np.flatnonzero(~tested):
                 dim_cube[dim] = False
                 tested[dim] = True
-                cand = ellipsoid_params(points[:, ~dim_cube], enlarge_per_dim)
+                cand = yield from _ellipsoid_task(points[:, ~dim_cube],
+                                                  enlarge_per_dim)
                 cand_v = ellipsoid_log_volume(cand['B'])
                 if log_v > cand_v:
                     ell, log_v = cand, cand_v
@@ -173,6 +209,17 @@ def mixture_params(points, enlarge_per_dim=1.1):
     if np.all(dim_cube):
         ell = None
     return dim_cube, ell
+
+
+def mixture_params_batch(point_sets, enlarge_per_dim=1.1):
+    return run_tasks([_mixture_task(np.asarray(p), enlarge_per_dim)
+                      for p in point_sets])
+
+
+def mixture_params(points, enlarge_per_dim=1.1):
+    """UnitCubeEllipsoidMixture.compute (bounds/basic.py:471-563): returns
+    (dim_cube, ellipsoid dict or None)."""
+    return mixture_params_batch([points], enlarge_per_dim)[0]
 
 
 def ellipsoids_overlap(params):

@@ -105,3 +105,55 @@ def nautilus_from_golden(g):
     if 'centers' in g:
         shift = bo.OPhaseShift.from_params(g['periodic'], g['centers'])
     return bo.ONautilus.from_parts(outer, neural, shift=shift)
+
+
+def khachiyan_weights_numpy(points, n_max=100, n_batch=20):
+    """Weights u of the batched Khachiyan iteration (reference
+    bounds/basic.py:175-232) in numpy, with the inverse tracked through the
+    rank-one updates of a sweep (the reference re-inverts after every
+    update).  Test-side comparison for the device kernels."""
+    from scipy.linalg.lapack import dpotrf, dpotri
+    n, d = points.shape
+    q = np.empty((n, d + 1))
+    q[:, :d] = points
+    q[:, d] = 1.0
+    u = np.full(n, 1.0 / n)
+    v = (q * u[:, None]).T @ q
+    for _ in range(n_max):
+        tri = dpotri(dpotrf(v)[0])[0]
+        v_inv = tri + tri.T - np.diag(np.diag(tri))
+        g_all = np.einsum('ij,ij->i', q @ v_inv, q)
+        first = True
+        for j in np.argsort(g_all)[-n_batch:][::-1]:
+            qj = q[j]
+            w = v_inv @ qj
+            g = g_all[j] if first else qj @ w
+            first = False
+            if g < d + 1:
+                continue
+            step = (g - (d + 1)) / ((d + 1) * (g - 1))
+            v = v * (1 - step) + step * np.outer(qj, qj)
+            ratio = step / (1 - step)
+            v_inv = (v_inv - np.outer(w, w) * (ratio / (1 + ratio * g))) / \
+                (1 - step)
+            u *= (1 - step)
+            u[j] += step
+    return u
+
+
+def mvee_numpy_batch(point_sets, n_max=100, n_batch=20):
+    """Stand-in for ``geometry.mvee_batch`` in the CPU-only tests of the host
+    logic: the finishing steps of basic.py:233-241 on top of
+    ``khachiyan_weights_numpy``."""
+    out = []
+    for points in point_sets:
+        points = np.ascontiguousarray(points, dtype=float)
+        u = khachiyan_weights_numpy(points, n_max, n_batch)
+        c = np.atleast_1d(np.average(points, weights=u, axis=0))
+        a_inv = np.atleast_2d(np.cov(points, aweights=u, rowvar=False,
+                                     bias=True))
+        a = np.linalg.inv(a_inv)
+        diff = points - c
+        scale = np.amax(np.einsum('ij,ij->i', diff @ a, diff))
+        out.append((c, a / scale, a_inv * scale))
+    return out

@@ -23,7 +23,7 @@ def test_library_exports_all_declared_symbols():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_lib.exported_symbols()) == names
-    assert lib.nb_abi_version() == 2
+    assert lib.nb_abi_version() == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -11,7 +11,8 @@ import torch
 import pytest
 
 from conftest import load_golden
-from helpers import upload, near_boundary, nautilus_from_golden
+from helpers import (upload, near_boundary, nautilus_from_golden,
+                     khachiyan_weights_numpy)
 
 pytestmark = pytest.mark.gpu
 
@@ -315,7 +316,7 @@ def test_mvee_kernel_matches_reference(dev, d):
     u = dev.mvee_weights(pts).cpu().numpy()
     assert u.shape == (len(pts),) and abs(u.sum() - 1.0) < 1e-12
     assert np.all(u >= 0)
-    u_h = geometry.khachiyan_weights_host(pts)
+    u_h = khachiyan_weights_numpy(pts)
     assert np.allclose(u, u_h, rtol=0, atol=1e-9)
     c, a, a_inv = geometry.mvee(pts)
     assert np.allclose(c, c_o, rtol=0, atol=1e-9)
@@ -331,14 +332,17 @@ def test_mvee_kernel_matches_reference(dev, d):
 def test_mvee_kernel_shapes(dev):
     """Known answers and ragged sizes: points on a sphere (reference
     tests/test_bounds.py), n barely above n_dim, n not a multiple of 16, odd
-    and even dimensions up to the kernel's limit; above it the host form."""
+    and even dimensions up to the kernels' limit of 128, more points than one
+    workgroup per 128 handles."""
     from nautilus_amd import geometry
     rng = np.random.default_rng(5)
     for d, n in [(2, 3), (2, 100), (7, 9), (15, 333), (16, 200), (31, 64),
-                 (33, 1000), (62, 300), (63, 129)]:
+                 (33, 1000), (62, 300), (63, 129), (64, 200), (79, 700),
+                 (100, 1500), (127, 400), (128, 300), (20, 6000)]:
         pts = rng.normal(size=(n, d)) * rng.uniform(0.5, 2.0, size=d) + 0.3
         u = dev.mvee_weights(pts).cpu().numpy()
-        u_h = geometry.khachiyan_weights_host(pts)
+        u_h = khachiyan_weights_numpy(pts)
+        assert abs(u.sum() - 1.0) < 1e-12, (d, n)
         assert np.allclose(u, u_h, rtol=0, atol=1e-8), (d, n)
     x = rng.normal(size=(500, 10))
     x /= np.linalg.norm(x, axis=1)[:, None]
@@ -346,10 +350,53 @@ def test_mvee_kernel_shapes(dev):
     assert np.allclose(c, 0, atol=0.05)
     assert np.allclose(a, np.eye(10), atol=0.1)
     with pytest.raises(RuntimeError):
-        dev.mvee_weights(rng.normal(size=(200, 64)))
-    big = rng.normal(size=(300, 70))
-    assert np.allclose(geometry.khachiyan_weights(big),
-                       geometry.khachiyan_weights_host(big))
+        dev.mvee_weights(rng.normal(size=(200, 129)))
+    # n_batch other than the default, fewer points than n_batch
+    pts = rng.normal(size=(300, 6))
+    for nb in (1, 5, 32):
+        assert np.allclose(dev.mvee_weights(pts, n_batch=nb).cpu().numpy(),
+                           khachiyan_weights_numpy(pts, n_batch=nb),
+                           rtol=0, atol=1e-9)
+    few = rng.normal(size=(12, 4))
+    assert np.allclose(dev.mvee_weights(few).cpu().numpy(),
+                       khachiyan_weights_numpy(few), rtol=0, atol=1e-9)
+
+
+def test_mvee_batch_equals_single_fits(dev):
+    """nb_mvee_khachiyan advances several point sets in the same launches
+    (the children of Union.split): every set gets exactly the result of a
+    fit of its own, whatever the sizes of its neighbours."""
+    from nautilus_amd import geometry
+    rng = np.random.default_rng(11)
+    sets = [rng.normal(size=(n, 24)) * rng.uniform(0.2, 3.0, size=24)
+            for n in (40, 1000, 333, 5000)]
+    geometry._ELL_CACHE.clear()
+    batch = geometry.mvee_batch(sets)
+    for pts, (c, a, a_inv) in zip(sets, batch):
+        c1, a1, a_inv1 = geometry.mvee(pts)
+        assert np.array_equal(c, c1) and np.array_equal(a, a1)
+        r2 = np.einsum('ij,jk,ik->i', pts - c, a, pts - c)
+        assert abs(r2.max() - 1.0) < 1e-12
+        assert np.allclose(a @ a_inv, np.eye(24), atol=1e-9)
+
+
+def test_weighted_moments_and_quadform(dev):
+    """nb_weighted_moments / nb_quadform_max against numpy (basic.py:233-236)."""
+    rng = np.random.default_rng(3)
+    for n, d in [(5, 2), (1000, 17), (3000, 50), (777, 100), (4500, 128)]:
+        x = rng.normal(size=(n, d)) * 0.3 + 0.1
+        w = rng.random(n)
+        q = np.hstack([x, np.ones((n, 1))])
+        s = dev.weighted_moments(x, torch.from_numpy(w).cuda(), 0.5)
+        ref = 0.5 * (q * w[:, None]).T @ q
+        assert np.allclose(s.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+        s1 = dev.weighted_moments(x).cpu().numpy()
+        assert np.allclose(s1, q.T @ q, rtol=1e-12, atol=1e-12)
+        p = np.linalg.inv(q.T @ q / n)
+        p = 0.5 * (p + p.T)
+        g = np.einsum('ij,jk,ik->i', q, p, q)
+        got = float(dev.quadform_max(x, p).cpu()[0])
+        assert abs(got - g.max()) < 1e-10 * g.max()
 
 
 def _sklearn_em_from_labels(x, labels, **kw):

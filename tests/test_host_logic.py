@@ -10,13 +10,15 @@ from conftest import load_golden
 
 @pytest.fixture(autouse=True)
 def host_khachiyan(monkeypatch):
-    """No GPU here: the host logic around the MVEE (finishing steps, greedy
-    cube/ellipsoid choice, overlap test) is exercised with the host form of
-    the Khachiyan iteration, which the product uses for n_dim > 63; the device
-    kernel itself is pinned under -m gpu (tests/test_hip_parity.py)."""
+    """No GPU here: the host logic around the MVEE (enlargement, Cholesky
+    factors, greedy cube/ellipsoid choice, overlap test, batching of the
+    construction coroutines) is exercised with a numpy stand-in for the device
+    fit; the device kernels themselves are pinned under -m gpu
+    (tests/test_hip_parity.py)."""
     from nautilus_amd import geometry
-    monkeypatch.setattr(geometry, 'khachiyan_weights',
-                        geometry.khachiyan_weights_host)
+    import helpers
+    monkeypatch.setattr(geometry, 'mvee_batch', helpers.mvee_numpy_batch)
+    geometry._ELL_CACHE.clear()
 
 
 @pytest.mark.parametrize('d', [3, 20, 50])
