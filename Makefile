@@ -19,6 +19,19 @@ $(LIB): $(OBJS)
 	@mkdir -p nautilus_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# Debug / instrumented build (in-kernel cycle stamps etc.), never shipped:
+#   make debug DEFS="-DNB_MVEE_TIMING"  ->  nautilus_amd/lib/libnautilus_hip_dbg.so
+# (select it with NAUTILUS_HIP_LIB=<path>)
+DBGDIR := build/obj_dbg
+DBGLIB := nautilus_amd/lib/libnautilus_hip_dbg.so
+DBGOBJS := $(patsubst $(CSRC)/%.hip,$(DBGDIR)/%.o,$(SRCS))
+$(DBGDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h $(CSRC)/nb_tile.h include/nautilus_hip.h FORCE
+	@mkdir -p $(DBGDIR)
+	$(HIPCC) $(FLAGS) $(DEFS) -c $< -o $@
+debug: $(DBGOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(DBGLIB) $(DBGOBJS)
+FORCE:
+
 clean:
-	rm -rf build $(LIB)
-.PHONY: all clean
+	rm -rf build $(LIB) $(DBGLIB)
+.PHONY: all clean debug FORCE

@@ -91,19 +91,55 @@ __device__ __forceinline__ int mv_slot(int f) {       // slot_of_feature
   return 4 * (2 * j + (r & 1)) + (r >> 1);
 }
 
+typedef double mv_c2 __attribute__((ext_vector_type(2)));   // (g, index bits)
+
+__device__ __forceinline__ mv_c2 mv_cand(double g, int i) {
+  return mv_c2{g, __longlong_as_double((long long)i)};
+}
+__device__ __forceinline__ int mv_idx(mv_c2 c) {
+  return (int)__double_as_longlong(c.y);
+}
 __device__ __forceinline__ bool mv_before(double yg, int yi, double xg, int xi) {
   return yg > xg || (yg == xg && yi > xi);
 }
-// number of entries of a list sorted in "before" order that rank before x
-__device__ __forceinline__ int mv_count_before(const double* lg, const int* li,
-                                               int len, double xg, int xi) {
-  int lo = 0, hi = len;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (mv_before(lg[mid], li[mid], xg, xi)) lo = mid + 1;
-    else hi = mid;
+
+// Number of entries of NL lists (sorted in "before" order, list b at
+// base + b * stride with len[b] <= 32 entries) that rank before x.  The
+// bisections of all lists advance in lock step: per round NL independent
+// 16-byte LDS reads, one wait.  (Written as nested ifs the compiler emits one
+// branch + wait per probe, ~100 dependent LDS round trips per candidate.)
+template <int NL>
+__device__ __forceinline__ int mv_count_lists(const mv_c2* base, int stride,
+                                              const int (&len)[NL], double xg,
+                                              int xi) {
+  int pos[NL];
+#pragma unroll
+  for (int b = 0; b < NL; ++b) pos[b] = 0;
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) {
+    mv_c2 v[NL];
+#pragma unroll
+    for (int b = 0; b < NL; ++b) {
+      const int cand = pos[b] + step;
+      const int at = (cand <= len[b] ? cand : 1) - 1;
+      v[b] = base[b * stride + at];
+    }
+    // all loads issued; pin them (otherwise they sink into branches again)
+#pragma unroll
+    for (int b = 0; b < NL; ++b)
+      asm volatile("" : "+v"(v[b].x), "+v"(v[b].y));
+#pragma unroll
+    for (int b = 0; b < NL; ++b) {
+      const int cand = pos[b] + step;
+      const bool ok = (cand <= len[b]) &
+                      mv_before(v[b].x, mv_idx(v[b]), xg, xi);
+      pos[b] = ok ? cand : pos[b];
+    }
   }
-  return lo;
+  int total = 0;
+#pragma unroll
+  for (int b = 0; b < NL; ++b) total += pos[b];
+  return total;
 }
 
 __device__ __forceinline__ double mv_readlane(double v, int l) {
@@ -115,7 +151,7 @@ __device__ __forceinline__ double mv_readlane(double v, int l) {
 
 // LDS layout (doubles) shared by host and device
 struct MvLds {
-  int T, Wt, Qs, G0, Zs, misc, gwg, L1g, L1i, total;
+  int T, Wt, Qs, G0, Zs, misc, gwg, L1c, L1n, total;
 };
 __host__ __device__ inline MvLds mv_layout(int dt, int nsc, int ppw_max) {
   MvLds l;
@@ -123,37 +159,37 @@ __host__ __device__ inline MvLds mv_layout(int dt, int nsc, int ppw_max) {
   int off = 0;
   l.T = off; off += dt * (dt + 1) / 2 * NB_TILE;
   int wt = nsc * ldw;
-  const int stage = MV_MAXW * nsc + (MV_MAXW * nsc + MV_MAXW + 1) / 2 + 2;
+  const int stage = 2 * MV_MAXW * nsc + MV_MAXW / 2 + 2;
   if (wt < stage) wt = stage;            // candidate staging aliases Wt
   l.Wt = off; off += (wt + 1) & ~1;
   l.Qs = off; off += (nsc * ldw + 1) & ~1;
-  l.G0 = off; off += nsc * nsc;
+  l.G0 = off; off += 2 * nsc * nsc;      // two K halves
   l.Zs = off; off += nsc * nsc;
   l.misc = off; off += 4 * nsc + 16;     // sel_g, kap, sel_i (ints), scalars
-  l.gwg = off; off += (ppw_max + 1) & ~1;
-  l.L1g = off; off += MV_WAVES * nsc;
-  l.L1i = off; off += (MV_WAVES * nsc + MV_WAVES + 1) / 2 + 1;
+  off = (off + 3) & ~3;
+  l.gwg = off; off += (ppw_max + 3) & ~3;
+  l.L1c = off; off += 2 * MV_WAVES * nsc;
+  l.L1n = off; off += MV_WAVES / 2 + 2;
   l.total = off;
   return l;
 }
 
 // second level of a selection: MV_WAVES sorted lists -> the k best overall,
-// written through `emit(rank, g, i)`; returns the number of valid entries
+// written through `emit(rank, g, i)`
 template <typename Emit>
-__device__ __forceinline__ void mv_select_l2(const double* L1g, const int* L1i,
-                                             const int* L1n, int nsc, int k,
-                                             int tid, Emit emit) {
+__device__ __forceinline__ void mv_select_l2(const mv_c2* L1c, const int* L1n,
+                                             int nsc, int k, int tid,
+                                             Emit emit) {
   if (tid < MV_WAVES * nsc) {
     const int a = tid / nsc, p = tid - a * nsc;
     if (p < L1n[a]) {
-      const double xg = L1g[a * nsc + p];
-      const int xi = L1i[a * nsc + p];
-      int rank = p;
+      const mv_c2 x = L1c[a * nsc + p];
+      int len[MV_WAVES];
 #pragma unroll
-      for (int b = 0; b < MV_WAVES; ++b)
-        if (b != a && rank < k)
-          rank += mv_count_before(L1g + b * nsc, L1i + b * nsc, L1n[b], xg, xi);
-      if (rank < k) emit(rank, xg, xi);
+      for (int b = 0; b < MV_WAVES; ++b) len[b] = b != a ? L1n[b] : 0;
+      const int rank =
+          p + mv_count_lists<MV_WAVES>(L1c, nsc, len, x.x, mv_idx(x));
+      if (rank < k) emit(rank, x.x, mv_idx(x));
     }
   }
 }
@@ -163,6 +199,16 @@ __device__ __forceinline__ void mv_select_l2(const double* L1g, const int* L1i,
 //   mode 0: Khachiyan call `call` of n_calls
 //   mode 1: phase B only with the matrix in P[0] and k = 1 (largest g)
 // ---------------------------------------------------------------------------
+#ifdef NB_MVEE_TIMING
+#define MV_STAMP(k)                                                           \
+  do {                                                                        \
+    if (wg == 0 && tid == 0 && call == 5)                                     \
+      pb.state[8 + (k)] = (double)__builtin_amdgcn_s_memtime();               \
+  } while (0)
+#else
+#define MV_STAMP(k)
+#endif
+
 template <int DT, int NSC>
 __global__ void __launch_bounds__(MV_THREADS)
 nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
@@ -170,6 +216,7 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
   constexpr int DP = 16 * DT;
   constexpr int LDW = DP + 1;
   constexpr int NT = DT * (DT + 1) / 2;
+  constexpr int TPWV = (NT + MV_WAVES - 1) / MV_WAVES;   // T tiles per wave
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const MvProb pb = batch.p[blockIdx.y];
   const int wg = blockIdx.x;
@@ -181,20 +228,18 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
   double* T = lds + L.T;
   double* Wt = lds + L.Wt;
   double* Qs = lds + L.Qs;           // later Yt
-  double* G0 = lds + L.G0;
+  double* G0 = lds + L.G0;           // two partial sums (K halves)
   double* Zs = lds + L.Zs;
   double* sel_g = lds + L.misc;
   double* kap = sel_g + NSC;
   int* sel_i = (int*)(kap + NSC);
-  double* scal = kap + NSC + NSC;    // [0] s_fin [1] n_acc [2] n_sel_eff
+  double* scal = kap + NSC + NSC;    // [0] s_fin [1] n_acc
   double* gwg = lds + L.gwg;
-  double* L1g = lds + L.L1g;
-  int* L1i = (int*)(lds + L.L1i);
-  int* L1n = L1i + MV_WAVES * NSC;
+  mv_c2* L1c = (mv_c2*)(lds + L.L1c);
+  int* L1n = (int*)(lds + L.L1n);
   // candidate staging (merge) aliases Wt
-  double* cg = Wt;
-  int* ci = (int*)(Wt + MV_MAXW * NSC);
-  int* cn = ci + MV_MAXW * NSC;
+  mv_c2* cc = (mv_c2*)Wt;
+  int* cn = (int*)(Wt + 2 * MV_MAXW * NSC);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -219,6 +264,35 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     if (wg == 0 && tid == 0) { pb.state[0] = 1.0; pb.state[1] = 0.0; }
   }
 
+  // ---- prefetch (global loads that depend on nothing computed here) --------
+  // the P tiles this wave rewrites in A8
+  double pold[TPWV][4];
+#pragma unroll
+  for (int jq = 0; jq < TPWV; ++jq) {
+    const int q = wave + MV_WAVES * jq;
+    int ht = 0;
+    while (mv_tri(ht + 1, 0) <= q) ++ht;
+    const int kt = q - mv_tri(ht, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int R = 16 * ht + lg + 4 * r, Cc = 16 * kt + lj;
+      pold[jq][r] = (q < NT && !last && R < m && Cc < m)
+                        ? P_old[(size_t)R * m + Cc] : 0.0;
+    }
+  }
+  // the rows of P for this wave's first (row tile, point tile) pair of A4
+  double apre[4 * DT];
+  {
+    const int row = 16 * (wave >> 1) + lj;
+#pragma unroll
+    for (int ks = 0; ks < 4 * DT; ++ks) {
+      const int col = 4 * ks + lg;
+      apre[ks] = (phase_a && wave < 2 * DT && row < m && col < m)
+                     ? P_old[(size_t)row * m + col] : 0.0;
+    }
+  }
+
+  MV_STAMP(0);
   if (phase_a) {
     // ---- A0: stage the candidate lists of the previous call ----------------
     const double* pg = pb.cand_g + (size_t)prev * W * NSC;
@@ -226,15 +300,13 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     for (int e = tid; e < W * NSC; e += MV_THREADS) {
       const int w = e / NSC, q = e - w * NSC;
       const int cnt = pi[w * (NSC + 1) + NSC];
-      cg[e] = q < cnt ? pg[e] : -inf;
-      ci[e] = q < cnt ? pi[w * (NSC + 1) + q] : -1;
+      cc[e] = q < cnt ? mv_cand(pg[e], pi[w * (NSC + 1) + q]) : mv_cand(-inf, -1);
       if (q == 0) cn[w] = cnt;
     }
-    for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS) {
-      L1g[e] = -inf;
-      L1i[e] = -1;
-    }
+    for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS)
+      L1c[e] = mv_cand(-inf, -1);
     __syncthreads();
+    MV_STAMP(1);
     // ---- A1: first level, wave w merges the lists w, w+8, ... --------------
     {
       int total = 0;
@@ -244,23 +316,25 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
         const int li = c / NSC, p = c - li * NSC;
         const int w = wave + MV_WAVES * li;
         if (p < cn[w]) {
-          const double xg = cg[w * NSC + p];
-          const int xi = ci[w * NSC + p];
-          int rank = p;
-          for (int b = wave; b < W; b += MV_WAVES)
-            if (b != w && rank < K)
-              rank += mv_count_before(cg + b * NSC, ci + b * NSC, cn[b], xg, xi);
-          if (rank < K) {
-            L1g[wave * NSC + rank] = xg;
-            L1i[wave * NSC + rank] = xi;
+          const mv_c2 x = cc[w * NSC + p];
+          int len[MV_MAXW / MV_WAVES];
+#pragma unroll
+          for (int bl = 0; bl < MV_MAXW / MV_WAVES; ++bl) {
+            const int b = wave + MV_WAVES * bl;
+            len[bl] = (b < W && b != w) ? cn[b] : 0;
           }
+          const int rank = p + mv_count_lists<MV_MAXW / MV_WAVES>(
+                                   cc + wave * NSC, MV_WAVES * NSC, len, x.x,
+                                   mv_idx(x));
+          if (rank < K) L1c[wave * NSC + rank] = x;
         }
       }
       if (lane == 0) L1n[wave] = total < K ? total : K;
     }
     __syncthreads();
+    MV_STAMP(2);
     // ---- A2: second level ---------------------------------------------------
-    mv_select_l2(L1g, L1i, L1n, NSC, K, tid,
+    mv_select_l2(L1c, L1n, NSC, K, tid,
                  [&](int rank, double g, int i) { sel_g[rank] = g; sel_i[rank] = i; });
     __syncthreads();
     int n_sel = 0;
@@ -268,6 +342,7 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     for (int w = 0; w < MV_WAVES; ++w) n_sel += L1n[w];
     if (n_sel > K) n_sel = K;
 
+    MV_STAMP(3);
     // ---- A3: the selected rows q_t = (x_t, 1) ------------------------------
     for (int e = tid; e < n_sel * DP; e += MV_THREADS) {
       const int t = e / DP, c = e - t * DP;
@@ -277,55 +352,81 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
       Qs[t * LDW + c] = v;
     }
     __syncthreads();
+    MV_STAMP(4);
 
     // ---- A4: W = P Q_sel^T on the matrix cores -> Wt[t][feature] ----------
-    for (int ht = wave; ht < DT; ht += MV_WAVES) {
+    // one (row tile, point tile) pair per wave and round
+    for (int pair = wave; pair < 2 * DT; pair += MV_WAVES) {
+      const int ht = pair >> 1, pt = pair & 1;
+      if (16 * pt >= n_sel) continue;
       double a[4 * DT];
-      const int row = 16 * ht + lj;
+      if (pair == wave) {
 #pragma unroll
-      for (int ks = 0; ks < 4 * DT; ++ks) {
-        const int col = 4 * ks + lg;
-        a[ks] = (row < m && col < m) ? P_old[(size_t)row * m + col] : 0.0;
-      }
-      for (int pt = 0; 16 * pt < n_sel; ++pt) {
-        const int t = 16 * pt + lj;
-        nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < 4 * DT; ++ks) a[ks] = apre[ks];
+      } else {
+        const int row = 16 * ht + lj;
 #pragma unroll
         for (int ks = 0; ks < 4 * DT; ++ks) {
-          const int f = 4 * ks + lg;
-          const double b = t < n_sel ? Qs[t * LDW + f] : 0.0;
-          acc = MFMA(a[ks], b, acc);
+          const int col = 4 * ks + lg;
+          a[ks] = (row < m && col < m) ? P_old[(size_t)row * m + col] : 0.0;
         }
-        if (t < n_sel) {
+      }
+      const int t = 16 * pt + lj;
+      nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Wt[t * LDW + 16 * ht + lg + 4 * r] = acc[r];
+      for (int ks = 0; ks < 4 * DT; ++ks) {
+        const double b = t < n_sel ? Qs[t * LDW + 4 * ks + lg] : 0.0;
+        acc = MFMA(a[ks], b, acc);
+      }
+      if (t < n_sel) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wt[t * LDW + 16 * ht + lg + 4 * r] = acc[r];
+      }
+    }
+    __syncthreads();
+    MV_STAMP(5);
+
+    // ---- A5: G0 = Q_sel W on the matrix cores, K split over two halves ------
+    {
+      const int si = wave & 1, ti = (wave >> 1) & 1, half = wave >> 2;
+      const int ksn = (m + 3) >> 2;
+      const int k0 = half == 0 ? 0 : ksn >> 1;
+      const int k1 = half == 0 ? ksn >> 1 : ksn;
+      if (16 * si < n_sel && 16 * ti < n_sel) {
+        const int srow = 16 * si + lj, trow = 16 * ti + lj;
+        nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
+        for (int ks = k0; ks < k1; ++ks) {
+          const int c = 4 * ks + lg;
+          const double a = srow < n_sel ? Qs[srow * LDW + c] : 0.0;
+          const double b = trow < n_sel ? Wt[trow * LDW + c] : 0.0;
+          acc = MFMA(a, b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int sr = 16 * si + lg + 4 * r;
+          if (sr < n_sel && trow < n_sel)
+            G0[half * NSC * NSC + sr * NSC + trow] = acc[r];
         }
       }
     }
     __syncthreads();
-
-    // ---- A5: G0 = Q_sel W --------------------------------------------------
-    for (int e = tid; e < n_sel * n_sel; e += MV_THREADS) {
-      const int s = e / n_sel, t = e - s * n_sel;
-      double acc = 0.0;
-      for (int c = 0; c < m; ++c) acc += Qs[s * LDW + c] * Wt[t * LDW + c];
-      G0[s * NSC + t] = acc;
-    }
-    __syncthreads();
+    MV_STAMP(6);
 
     // ---- A6: the sequential updates in the Gram space (one wavefront) ------
     if (wave == 0) {
       // lane l holds row l of the current Gram matrix Gk (q_l^T P_k q_r) and
-      // of H = C G0 (z_t = e_t - H[:, t]); Zk collects the vectors z of the
-      // accepted updates
+      // of H = C G0 (z_t = e_t - H[:, t]); the vectors z of the accepted
+      // updates go to Zs
       double Gk[NSC], H[NSC];
 #pragma unroll
       for (int r = 0; r < NSC; ++r) {
-        Gk[r] = (lane < n_sel && r < n_sel) ? G0[lane * NSC + r] : 0.0;
+        Gk[r] = (lane < n_sel && r < n_sel)
+                    ? G0[lane * NSC + r] + G0[NSC * NSC + lane * NSC + r] : 0.0;
         H[r] = 0.0;
       }
-      double s = 1.0;
+      double s = 1.0, uinc = 0.0;
       double us = pb.state[0];
+      double inv_us = 1.0 / us;
       const double md = (double)m;
       int acc_n = 0;
 #pragma unroll
@@ -334,10 +435,15 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
           double g = mv_readlane(Gk[t], t);
           if (t == 0) g = mv_readlane(sel_g[0], 0);   // basic.py:222-223
           if (g >= md) {
-            const double a = (g - md) / (md * (g - 1.0));
-            const double ratio = a / (1.0 - a);
-            const double coef = ratio / (1.0 + ratio * g);
-            const double inv1a = 1.0 / (1.0 - a);
+            // a = (g - m) / (m (g - 1));  with it  1 - a = g (m-1) / (m (g-1))
+            // and coef = ratio / (1 + ratio g) = (g - m) / (g (g - 1))  (ratio
+            // = a / (1 - a)): ONE division per update instead of a chain of
+            // five (the wavefront executes them in order)
+            const double gm1 = g - 1.0;
+            const double rr = 1.0 / (g * gm1 * md * (md - 1.0));
+            const double a = (g - md) * g * (md - 1.0) * rr;
+            const double coef = (g - md) * md * (md - 1.0) * rr;
+            const double inv1a = md * md * gm1 * gm1 * rr;
             const double z = (lane == t ? 1.0 : 0.0) - H[t];
             const double gt = Gk[t];              // Gk[l][t]
 #pragma unroll
@@ -350,18 +456,16 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
             }
             // record z (column acc_n of Zs) and kappa = coef * s
             if (lane < NSC) Zs[lane * NSC + acc_n] = z;
-            if (lane == 0) {
-              kap[acc_n] = coef * s;
-              if (wg == 0) {
-                us *= (1.0 - a);
-                pb.u[sel_i[t]] += a / us;
-              }
-            }
+            us *= (1.0 - a);
+            inv_us *= inv1a;
+            if (lane == t) uinc = a * inv_us;     // u[sel_i[t]] += a / scale
+            if (lane == 0) kap[acc_n] = coef * s;
             s *= inv1a;
             ++acc_n;
           }
         }
       }
+      if (wg == 0 && lane < n_sel && uinc != 0.0) pb.u[sel_i[lane]] += uinc;
       if (lane == 0) {
         scal[0] = s;
         scal[1] = (double)acc_n;
@@ -375,22 +479,38 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     s_fin = scal[0];
     n_acc = (int)scal[1];
     if (last) return;
+    MV_STAMP(7);
 
-    // ---- A7: Y = W Z  (Yt[k][feature], aliases Qs) -------------------------
+    // ---- A7: Y = W Z on the matrix cores (Yt[k][feature], aliases Qs) -------
     double* Yt = Qs;
-    for (int e = tid; e < n_acc * DP; e += MV_THREADS) {
-      const int k = e / DP, f = e - k * DP;
-      double acc = 0.0;
-      for (int b = 0; b < n_sel; ++b) acc += Zs[b * NSC + k] * Wt[b * LDW + f];
-      Yt[k * LDW + f] = acc;
+    for (int item = wave; item < 2 * DT; item += MV_WAVES) {
+      const int ft = item >> 1, kt = item & 1;
+      if (16 * kt >= n_acc) continue;
+      nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
+      for (int kb = 0; 4 * kb < n_sel; ++kb) {
+        const int b = 4 * kb + lg;
+        const double a = b < n_sel ? Wt[b * LDW + 16 * ft + lj] : 0.0;
+        const double bz = (b < n_sel && 16 * kt + lj < n_acc)
+                              ? Zs[b * NSC + 16 * kt + lj] : 0.0;
+        acc = MFMA(a, bz, acc);
+      }
+      const int k = 16 * kt + lj;
+      if (k < n_acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Yt[k * LDW + 16 * ft + lg + 4 * r] = acc[r];
+      }
     }
     __syncthreads();
   }
 
+  MV_STAMP(8);
   // ---- A8: P_new = s (P - sum_k kappa_k y_k y_k^T) -> operand tiles T ------
   {
     const double* Yt = Qs;
-    for (int q = wave; q < NT; q += MV_WAVES) {
+#pragma unroll
+    for (int jq = 0; jq < TPWV; ++jq) {
+      const int q = wave + MV_WAVES * jq;
+      if (q >= NT) continue;
       int ht = 0;
       while (mv_tri(ht + 1, 0) <= q) ++ht;
       const int kt = q - mv_tri(ht, 0);
@@ -405,8 +525,7 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
       for (int r = 0; r < 4; ++r) {
         const int R = 16 * ht + lg + 4 * r, Cc = 16 * kt + lj;
         const bool in = R < m && Cc < m;
-        const double pold = in ? P_old[(size_t)R * m + Cc] : 0.0;
-        const double v = s_fin * (pold - acc[r]);
+        const double v = s_fin * (pold[jq][r] - acc[r]);
         if (mode == 0 && wg == 0 && in && Cc <= R) {
           P_new[(size_t)R * m + Cc] = v;
           P_new[(size_t)Cc * m + R] = v;
@@ -418,6 +537,7 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     }
   }
   __syncthreads();
+  MV_STAMP(9);
 
   // ---- B1: g_i = q_i^T P q_i for the workgroup's points ---------------------
   const int base = wg * pb.ppw;
@@ -449,38 +569,41 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     const double g = lane_group_sum(part);
     if (valid[0] && lg == 0) gwg[tile * 16 + lj] = g;
   }
-  for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS) {
-    L1g[e] = -inf;
-    L1i[e] = -1;
-  }
+  for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS)
+    L1c[e] = mv_cand(-inf, -1);
   __syncthreads();
+  MV_STAMP(10);
 
   // ---- B2: first level, wave w ranks its slice of the g values --------------
   {
-    const int slice = (cnt + MV_WAVES - 1) / MV_WAVES;
+    const int slice = ((cnt + MV_WAVES - 1) / MV_WAVES + 3) & ~3;
     const int s0 = wave * slice;
     const int s1 = (s0 + slice) < cnt ? (s0 + slice) : cnt;
     for (int i = s0 + lane; i < s1; i += 64) {
       const double xg = gwg[i];
       int rank = 0;
-      for (int j = s0; j < s1; ++j) rank += mv_before(gwg[j], j, xg, i) ? 1 : 0;
-      if (rank < K) {
-        L1g[wave * NSC + rank] = xg;
-        L1i[wave * NSC + rank] = base + i;
+      for (int j = s0; j < s1; j += 4) {          // s0 is a multiple of 4
+        const nb_d4 v = *(const nb_d4*)(gwg + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rank += (j + q < s1 && mv_before(v[q], j + q, xg, i)) ? 1 : 0;
       }
+      if (rank < K) L1c[wave * NSC + rank] = mv_cand(xg, base + i);
     }
     const int have = s1 > s0 ? s1 - s0 : 0;
     if (lane == 0) L1n[wave] = have < K ? have : K;
   }
   __syncthreads();
+  MV_STAMP(11);
   // ---- B3: second level -> candidates of the next call ----------------------
   {
     double* og = pb.cand_g + ((size_t)cur * W + wg) * NSC;
     int* oi = pb.cand_i + ((size_t)cur * W + wg) * (NSC + 1);
-    mv_select_l2(L1g, L1i, L1n, NSC, K, tid,
+    mv_select_l2(L1c, L1n, NSC, K, tid,
                  [&](int rank, double g, int i) { og[rank] = g; oi[rank] = i; });
     if (tid == 0) oi[NSC] = cnt < K ? cnt : K;
   }
+  MV_STAMP(12);
 }
 
 // u <- scale u (mode 0) / out = largest g over the lists (mode 1)
@@ -762,7 +885,7 @@ inline long long mv_prob_doubles(long long n_max, int d, int nsc) {
   long long t = 2LL * m * m + 2;                          // P
   t += 2LL * MV_MAXW * nsc;                               // cand_g
   t += (2LL * MV_MAXW * (nsc + 1) + 1) / 2 + 1;           // cand_i
-  t += 4;                                                 // state
+  t += 32;                                                // state
   t += mom_partial_doubles(n_max, dt);
   return (t + 1) & ~1LL;
 }
@@ -852,7 +975,7 @@ int nb_launch_mvee_batch(int n_problems, const double* const* xs,
       p.P = base; base += 2LL * m * m + 2;
       p.cand_g = base; base += 2LL * MV_MAXW * nsc;
       p.cand_i = (int*)base; base += (2LL * MV_MAXW * (nsc + 1) + 1) / 2 + 1;
-      p.state = base; base += 4;
+      p.state = base; base += 32;
       MomProb& q = qb.p[b];
       q.x = xs[b0 + b];
       q.w = nullptr;
