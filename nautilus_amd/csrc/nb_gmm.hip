@@ -6,23 +6,25 @@
 // then EM with tol = 1e-3 on the mean log-likelihood, reg_covar = 1e-6,
 // max_iter = 100 (mixture/_base.py:fit_predict, _gaussian_mixture.py).
 //
-// One workgroup per restart, all restarts of a fit run concurrently.
-//   E-step: Sigma_k = L D L^T by elimination in LDS, R^-1 = D^-1/2 L^-1 scattered
-//           into MFMA operand tiles, |R^-1 (x - mu_k)|^2 for all points on the
-//           matrix cores (the Ellipsoid.contains tile code, nb_tile.h)
+// One workgroup per restart, all restarts of a fit run concurrently;
+// n_dim <= 128.
 //   M-step: ONE weighted second-moment product on the matrix cores over the
 //           augmented rows q = (x, 1):  S0 = sum_i r_i0 q_i q_i^T  holds
-//           sum r x x^T, sum r x and sum r at once; component 1 follows from
-//           S_all - S0 (S_all = sum q q^T, computed once)
+//           sum r x x^T, sum r x and sum r at once (nb_sym.h, sy_moments);
+//           component 1 follows from S_all - S0 (S_all computed once)
+//   E-step: Sigma_k is built in LDS as lower-triangular operand tiles and
+//           inverted in place with the symmetric sweep operator (the pivots
+//           give log det Sigma_k); (x - mu_k)^T Sigma_k^-1 (x - mu_k) for all
+//           points on the matrix cores (sy_quadform)
 // Everything is deterministic (fixed reduction orders, Philox for the seeding).
-#include "nb_tile.h"
+#include "nb_sym.h"
 
 namespace {
 
 constexpr int GM_THREADS = 512;
 constexpr int GM_WAVES = GM_THREADS / 64;
-constexpr int GM_EPT = 8;                 // matrix elements per thread (<= 64^2)
 constexpr unsigned GM_TAG = 3u;           // Philox tag of the seeding draws
+constexpr int GM_SWEEP_EPT = 17;          // ceil(128 * 129 / 2 / 512)
 
 struct GmmArgs {
   const double* x;
@@ -35,11 +37,6 @@ struct GmmArgs {
   double* scratch;            // [n_init][scratch_stride]
   long long out_stride, scratch_stride;
 };
-
-__device__ __forceinline__ int gm_slot(int f) {
-  const int j = f >> 3, r = f & 7;
-  return 4 * (2 * j + (r & 1)) + (r >> 1);
-}
 
 // deterministic block sum: shuffle tree inside a wave, fixed order across waves
 __device__ __forceinline__ double block_sum(double v, double* red, int wave,
@@ -55,84 +52,30 @@ __device__ __forceinline__ double block_sum(double v, double* red, int wave,
   return s;
 }
 
-// S = sum_p w_p q_p q_p^T, q = (x, 1) (m = d + 1), lower block triangle valid:
-// read entry (r, c) as S[max(r,c) * m + min(r,c)]
-template <int DT>
-__device__ __forceinline__ void syrk_aug(const double* __restrict__ x, int n,
-                                         int d, const volatile double* w,
-                                         double* S, int wave, int lane) {
-  const int m = d + 1;
-  nb_d4 acc[DT * (DT + 1) / 2];
-#pragma unroll
-  for (int q = 0; q < DT * (DT + 1) / 2; ++q) acc[q] = nb_d4{0.0, 0.0, 0.0, 0.0};
-  const int kp = lane >> 4, fi = lane & 15;
-  for (int s = wave; 4 * s < n; s += GM_WAVES) {
-    const int p = 4 * s + kp;
-    const bool on = p < n;
-    const double wp = on ? (w != nullptr ? w[p] : 1.0) : 0.0;
-    double a[DT], aw[DT];
-#pragma unroll
-    for (int ft = 0; ft < DT; ++ft) {
-      const int f = 16 * ft + fi;
-      double v = 0.0;
-      if (on && f < d) v = x[(long long)p * d + f];
-      else if (on && f == d) v = 1.0;
-      a[ft] = v;
-      aw[ft] = v * wp;
-    }
-    int q = 0;
-#pragma unroll
-    for (int it = 0; it < DT; ++it)
-#pragma unroll
-      for (int jt = 0; jt <= it; ++jt) {
-        acc[q] = MFMA(aw[it], a[jt], acc[q]);
-        ++q;
-      }
-  }
-  for (int w8 = 0; w8 < GM_WAVES; ++w8) {
-    if (wave == w8) {
-      int q = 0;
-#pragma unroll
-      for (int it = 0; it < DT; ++it)
-#pragma unroll
-        for (int jt = 0; jt <= it; ++jt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * it + (lane >> 4) + 4 * r;
-            const int col = 16 * jt + (lane & 15);
-            if (row < m && col < m) {
-              double* dst = &S[row * m + col];
-              *dst = (w8 == 0 ? 0.0 : *dst) + acc[q][r];
-            }
-          }
-          ++q;
-        }
-    }
-    __syncthreads();
-  }
-}
-
+// DT = ceil((d + 1) / 16): tiles of the augmented rows
 template <int DT>
 __global__ void __launch_bounds__(GM_THREADS)
 nb_gmm_kernel(GmmArgs a) {
   constexpr int DP = 16 * DT;
+  constexpr int NT = DT * (DT + 1) / 2;
+  constexpr int GW = (DT + 1) / 2;          // waves per moment sub-group
+  constexpr int SG = GM_WAVES / GW;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ double red[GM_WAVES], piv[64], cen[2][64], cpart[GM_WAVES][2][64];
-  __shared__ double sh_val[4];
+  __shared__ double red[GM_WAVES], sh_val[4];
   __shared__ int sh_idx[2], sh_bad;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lg = lane >> 4;
+  const int lg = lane >> 4, lj = lane & 15;
   const int init = blockIdx.x;
   const double* __restrict__ x = a.x;
   const int n = a.n, d = a.d, m = d + 1;
   const int mm = (m * m + 1) & ~1;
-  double* S = lds;             // weighted second moments (m x m)
-  double* A = S + mm;          // covariance being factorised (d x d)
-  double* B = A + mm;          // L^-1
-  double* ell = B + mm;        // ell block for the matrix-core pass
-  double* tiles = ell + 2 + 3 * DP;
+  double* T = lds;                         // NT tiles: Sigma_k -> -Sigma_k^-1 -> T
+  double* colk = T + NT * NB_TILE;         // [DP] pivot column of the sweep
+  double* mus = colk + DP;                 // [DP] mu_k in slot order
+  double* cen = mus + DP;                  // [2][DP] k-means centres
+  double* cpart = T;                       // [GM_WAVES][2][DP] (seeding only)
   const double inf = __builtin_huge_val();
 
   double* out = a.out + (long long)init * a.out_stride;
@@ -143,38 +86,42 @@ nb_gmm_kernel(GmmArgs a) {
   volatile double* r0 = lp1 + n;
   volatile double* d2 = r0 + n;
   volatile int* lab = (volatile int*)(d2 + n);       // [n] ints
+  double* part = scr + mm + 5LL * n + 2;             // [SG][NT][256]
   double* o_mean = out + 6;                          // [2][d]
   double* o_cov = o_mean + 2 * d;                    // [2][d*d]
 
-  int er[GM_EPT], ec[GM_EPT];
-#pragma unroll
-  for (int q = 0; q < GM_EPT; ++q) {
-    const int e = tid + q * GM_THREADS;
-    er[q] = (e < d * d) ? e / d : -1;
-    ec[q] = (e < d * d) ? e - er[q] * d : 0;
-  }
-
-  for (int e = tid; e < nb_ell_block_size(DT); e += GM_THREADS) ell[e] = 0.0;
   if (tid == 0) sh_bad = 0;
   __syncthreads();
-  if (tid == 0) ((long long*)ell)[0] = d;
-  for (int f = tid; f < DP; f += GM_THREADS) {
-    ell[2 + f] = -inf;
-    ell[2 + DP + f] = inf;
-  }
-  __syncthreads();
 
-  // S_all = sum q q^T, kept in global scratch
-  syrk_aug<DT>(x, n, d, nullptr, S, wave, lane);
-  for (int e = tid; e < m * m; e += GM_THREADS) sall[e] = S[e];
+  // weighted second moments of all points into `part` (every wave of a
+  // sub-group owns two tile rows)
+  auto moments = [&](const volatile double* w) {
+    const int sg = wave / GW, wv = wave - sg * GW;
+    if (sg < SG)
+      sy_moments<DT>(x, w, d, 0, n, sg, SG, wv, lane,
+                     part + (size_t)sg * NT * NB_TILE);
+    __threadfence_block();
+    __syncthreads();
+  };
+  auto moment = [&](int r, int c) {        // entry (r, c), r >= c
+    return mom_element((const volatile double*)part, SG, NT, r, c);
+  };
+
+  // S_all = sum q q^T, kept in global scratch (lower triangle + mirror)
+  moments(nullptr);
+  for (int e = tid; e < m * m; e += GM_THREADS) {
+    const int r = e / m, c = e - r * m;
+    sall[e] = moment(r > c ? r : c, r > c ? c : r);
+  }
+  __threadfence_block();
+  __syncthreads();
   // mean feature variance (tolerance scale of k-means, cluster/_kmeans.py:_tolerance)
   double mean_var = 0.0;
   for (int f = 0; f < d; ++f) {
-    const double mu = S[d * m + f] / n;
-    mean_var += S[f * m + f] / n - mu * mu;
+    const double mu = sall[d * m + f] / n;
+    mean_var += sall[f * m + f] / n - mu * mu;
   }
   mean_var /= d;
-  __syncthreads();
 
   // ---- initial hard assignment ---------------------------------------------
   if (a.init_labels != nullptr) {
@@ -186,21 +133,22 @@ nb_gmm_kernel(GmmArgs a) {
     nb_uniform_pair(a.seed, (unsigned long long)init, 1u, GM_TAG, u2, u3);
     int first = (int)(u0 * n);
     if (first > n - 1) first = n - 1;
-    if (tid < d) cen[0][tid] = x[(long long)first * d + tid];
+    for (int f = tid; f < d; f += GM_THREADS)
+      cen[f] = x[(long long)first * d + f];
     __syncthreads();
     // squared distances to the first centre, k-means++ potential
-    double part = 0.0;
+    double pot_part = 0.0;
     for (int i = tid; i < n; i += GM_THREADS) {
       double s = 0.0;
       for (int f = 0; f < d; ++f) {
-        const double t = x[(long long)i * d + f] - cen[0][f];
+        const double t = x[(long long)i * d + f] - cen[f];
         s += t * t;
       }
       d2[i] = s;
-      part += s;
+      pot_part += s;
     }
     __threadfence_block();
-    const double pot = block_sum(part, red, wave, lane);
+    const double pot = block_sum(pot_part, red, wave, lane);
     // two candidates drawn with probability ~ d2 (greedy k-means++,
     // cluster/_kmeans.py:_kmeans_plusplus with n_local_trials = 2)
     const int chunk = (n + GM_THREADS - 1) / GM_THREADS;
@@ -251,7 +199,8 @@ nb_gmm_kernel(GmmArgs a) {
     }
     const int second = sh_idx[cand_pot[1] < cand_pot[0] ? 1 : 0];
     __syncthreads();
-    if (tid < d) cen[1][tid] = x[(long long)second * d + tid];
+    for (int f = tid; f < d; f += GM_THREADS)
+      cen[DP + f] = x[(long long)second * d + f];
     for (int i = tid; i < n; i += GM_THREADS) lab[i] = -1;
     __threadfence_block();
     __syncthreads();
@@ -263,7 +212,7 @@ nb_gmm_kernel(GmmArgs a) {
         double s0 = 0.0, s1 = 0.0;
         for (int f = 0; f < d; ++f) {
           const double xv = x[(long long)i * d + f];
-          const double t0 = xv - cen[0][f], t1 = xv - cen[1][f];
+          const double t0 = xv - cen[f], t1 = xv - cen[DP + f];
           s0 += t0 * t0;
           s1 += t1 * t1;
         }
@@ -274,20 +223,28 @@ nb_gmm_kernel(GmmArgs a) {
       __threadfence_block();
       changed = block_sum(changed, red, wave, lane);
       __syncthreads();
-      // new centres: (feature, chunk of points) decomposition
+      // new centres: (feature, chunk of points) decomposition, the features
+      // in passes of 64
       {
-        const int f = lane, ch = wave;
+        const int ch = wave;
         const int per = (n + GM_WAVES - 1) / GM_WAVES;
         const int i0 = ch * per, i1 = (i0 + per < n) ? i0 + per : n;
-        double s0 = 0.0, s1 = 0.0, c1 = 0.0;
-        for (int i = i0; i < i1; ++i) {
-          const int l = lab[i];
-          const double xv = (f < d) ? x[(long long)i * d + f] : 0.0;
-          if (l) { s1 += xv; c1 += 1.0; } else s0 += xv;
+        double c1 = 0.0;
+        for (int fb = 0; fb < DP; fb += 64) {
+          const int f = fb + lane;
+          double s0 = 0.0, s1 = 0.0;
+          c1 = 0.0;
+          for (int i = i0; i < i1; ++i) {
+            const int l = lab[i];
+            const double xv = (f < d) ? x[(long long)i * d + f] : 0.0;
+            if (l) { s1 += xv; c1 += 1.0; } else s0 += xv;
+          }
+          if (f < DP) {
+            cpart[(ch * 2 + 0) * DP + f] = s0;
+            cpart[(ch * 2 + 1) * DP + f] = s1;
+          }
         }
-        cpart[ch][0][f] = s0;
-        cpart[ch][1][f] = s1;
-        if (f == 0) red[ch] = c1;
+        if (lane == 0) red[ch] = c1;
       }
       __syncthreads();
       double n1 = 0.0;
@@ -299,14 +256,14 @@ nb_gmm_kernel(GmmArgs a) {
         break;
       }
       double shift = 0.0;
-      if (tid < 2 * 64) {
-        const int k = tid >> 6, f = tid & 63;
+      if (tid < 2 * DP) {
+        const int k = tid / DP, f = tid - k * DP;
         double s = 0.0;
-        for (int w = 0; w < GM_WAVES; ++w) s += cpart[w][k][f];
+        for (int w = 0; w < GM_WAVES; ++w) s += cpart[(w * 2 + k) * DP + f];
         const double c_new = (f < d) ? s / (k ? n1 : n0) : 0.0;
-        const double dlt = c_new - ((f < d) ? cen[k][f] : 0.0);
+        const double dlt = c_new - ((f < d) ? cen[k * DP + f] : 0.0);
         shift = dlt * dlt;
-        cen[k][f] = c_new;     // only this thread reads or writes cen[k][f] here
+        cen[k * DP + f] = c_new;   // only this thread touches cen[k][f] here
       }
       shift = block_sum(shift, red, wave, lane);
       __syncthreads();
@@ -318,37 +275,62 @@ nb_gmm_kernel(GmmArgs a) {
   __threadfence_block();
   __syncthreads();
 
+  // the entries (r >= c) of the lower triangle this thread owns in the sweeps
+  int sw_r[GM_SWEEP_EPT], sw_c[GM_SWEEP_EPT], sw_p[GM_SWEEP_EPT];
+  {
+    const int n_low = d * (d + 1) / 2;
+#pragma unroll
+    for (int q = 0; q < GM_SWEEP_EPT; ++q) {
+      const int e = tid + q * GM_THREADS;
+      int r = -1, c = 0;
+      if (e < n_low) {
+        r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > e) --r;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        c = e - r * (r + 1) / 2;
+      }
+      sw_r[q] = r;
+      sw_c[q] = c;
+      sw_p[q] = r >= 0 ? sy_pos(r, c) : 0;
+    }
+  }
+
   // ---- EM ------------------------------------------------------------------
   const double eps10 = 10.0 * 2.220446049250313e-16;
   double lower = -inf;
   int n_iter = 0, converged = 0;
   double pi0 = 0.5, pi1 = 0.5;
   bool failed = sh_bad != 0;
+  const int ks_max = 4 * DT;
   for (int it = 0; it <= a.max_iter && !failed; ++it) {
     // M-step (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters)
-    syrk_aug<DT>(x, n, d, r0, S, wave, lane);
-    const double nk0 = S[d * m + d] + eps10;
-    const double nk1 = ((double)n - S[d * m + d]) + eps10;
+    moments(r0);
+    const double s00 = moment(d, d);
+    const double nk0 = s00 + eps10;
+    const double nk1 = ((double)n - s00) + eps10;
     pi0 = nk0 / (nk0 + nk1);      // _m_step: weights_ /= weights_.sum()
     pi1 = nk1 / (nk0 + nk1);
-    if (tid < d) {
-      o_mean[tid] = S[d * m + tid] / nk0;
-      o_mean[d + tid] = (sall[d * m + tid] - S[d * m + tid]) / nk1;
+    for (int f = tid; f < d; f += GM_THREADS) {
+      const double s0 = moment(d, f);
+      o_mean[f] = s0 / nk0;
+      o_mean[d + f] = (sall[d * m + f] - s0) / nk1;
     }
     __threadfence_block();
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < GM_EPT; ++q) {
-      const int r = er[q], c = ec[q];
-      if (r < 0) continue;
-      const int hi_ = r > c ? r : c, lo_ = r > c ? c : r;
-      const double s0 = S[hi_ * m + lo_];
-      const double s1 = sall[hi_ * m + lo_] - s0;
+    for (int e = tid; e < d * d; e += GM_THREADS) {
+      const int r = e / d, c = e - r * d;
+      if (c > r) continue;
+      const double s0 = moment(r, c);
+      const double s1 = sall[r * m + c] - s0;
       const double reg = (r == c) ? a.reg : 0.0;
       const double m0r = ((volatile double*)o_mean)[r], m0c = ((volatile double*)o_mean)[c];
       const double m1r = ((volatile double*)o_mean)[d + r], m1c = ((volatile double*)o_mean)[d + c];
-      o_cov[r * d + c] = s0 / nk0 - m0r * m0c + reg;
-      o_cov[d * d + r * d + c] = s1 / nk1 - m1r * m1c + reg;
+      const double c0 = s0 / nk0 - m0r * m0c + reg;
+      const double c1 = s1 / nk1 - m1r * m1c + reg;
+      o_cov[r * d + c] = c0;
+      o_cov[c * d + r] = c0;
+      o_cov[d * d + r * d + c] = c1;
+      o_cov[d * d + c * d + r] = c1;
     }
     __threadfence_block();
     __syncthreads();
@@ -358,72 +340,74 @@ nb_gmm_kernel(GmmArgs a) {
     for (int k = 0; k < 2; ++k) {
       const volatile double* cov = (volatile double*)o_cov + k * d * d;
       const volatile double* mean = (volatile double*)o_mean + k * d;
-#pragma unroll
-      for (int q = 0; q < GM_EPT; ++q)
-        if (er[q] >= 0) {
-          A[er[q] * d + ec[q]] = cov[er[q] * d + ec[q]];
-          B[er[q] * d + ec[q]] = (er[q] == ec[q]) ? 1.0 : 0.0;
-        }
+      for (int e = tid; e < NT * NB_TILE; e += GM_THREADS) T[e] = 0.0;
       __syncthreads();
-      for (int p = 0; p < d - 1; ++p) {
-        const double inv_d = 1.0 / A[p * d + p];
 #pragma unroll
-        for (int q = 0; q < GM_EPT; ++q) {
-          const int i = er[q], j = ec[q];
-          if (i > p) {
-            const double f = A[i * d + p] * inv_d;
-            if (j > p) A[i * d + j] -= f * A[p * d + j];
-            else B[i * d + j] -= f * B[p * d + j];
-          }
+      for (int q = 0; q < GM_SWEEP_EPT; ++q)
+        if (sw_r[q] >= 0) T[sw_p[q]] = cov[sw_r[q] * d + sw_c[q]];
+      for (int f = tid; f < DP; f += GM_THREADS)
+        mus[mv_slot(f)] = (f < d) ? mean[f] : 0.0;
+      __syncthreads();
+      // symmetric sweep operator over all pivots: T <- -Sigma^-1, the pivots
+      // are those of the L D L^T factorisation (log det = sum log d_p)
+      double logdet = 0.0;
+      for (int p = 0; p < d; ++p) {
+        for (int i = tid; i < d; i += GM_THREADS)
+          colk[i] = T[i >= p ? sy_pos(i, p) : sy_pos(p, i)];
+        __syncthreads();
+        const double dp = colk[p];
+        if (!(dp > 0.0)) {                   // not positive definite
+          if (tid == 0) sh_bad = 1;
+        }
+        const double inv_d = 1.0 / dp;
+        logdet += log(dp);
+#pragma unroll
+        for (int q = 0; q < GM_SWEEP_EPT; ++q) {
+          const int r = sw_r[q], c = sw_c[q];
+          if (r < 0) continue;
+          double v;
+          if (r == p && c == p) v = -inv_d;
+          else if (r == p) v = colk[c] * inv_d;
+          else if (c == p) v = colk[r] * inv_d;
+          else v = T[sw_p[q]] - colk[r] * colk[c] * inv_d;
+          T[sw_p[q]] = v;
         }
         __syncthreads();
       }
-      if (tid < 64) {
-        const double dv = (tid < d) ? A[tid * d + tid] : 1.0;
-        if (!(dv > 0.0)) sh_bad = 1;           // not positive definite
-        piv[tid] = 1.0 / dv;
-        double ld = (tid < d) ? log(dv) : 0.0;
+      // -> T form: -(...) and doubled off-diagonal entries
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ld += __shfl_xor(ld, o);
-        if (tid == 0) sh_val[k] = ld;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < GM_EPT; ++q) {
-        const int r = er[q], c = ec[q];
-        if (r < 0 || c > r) continue;
-        const int sl = gm_slot(c), ks = sl >> 2, lgk = sl & 3;
-        tiles[((ks >> 2) * DT + (r >> 4)) * NB_TILE + (ks & 3) * 64 + lgk * 16 +
-              (r & 15)] = B[r * d + c] * sqrt(piv[r]);
-      }
-      if (tid < DP) ell[2 + 2 * DP + gm_slot(tid)] = (tid < d) ? mean[tid] : 0.0;
+      for (int q = 0; q < GM_SWEEP_EPT; ++q)
+        if (sw_r[q] >= 0)
+          T[sw_p[q]] *= (sw_r[q] == sw_c[q]) ? -1.0 : -2.0;
       __syncthreads();
       const double konst = log(k == 0 ? pi0 : pi1) -
-                           0.5 * (d * 1.8378770664093453 + sh_val[k]);
+                           0.5 * (d * 1.8378770664093453 + logdet);
       volatile double* lp = k == 0 ? lp0 : lp1;
       for (int tile = wave; tile * 16 < n; tile += GM_WAVES) {
-        long long pt[1] = {(long long)tile * 16 + (lane & 15)};
+        long long pt[1] = {(long long)tile * 16 + lj};
         bool valid[1] = {pt[0] < n};
-        double xin[1][4 * DT], y[1][4 * DT], r2[1];
-        bool box_bad[1];
+        double xin[1][4 * DT];
         load_points<DT, 1>(x, pt, valid, d, (long long)n, lane, xin);
-        ell_eval<DT, 1>(ell, d, xin, lane, y, box_bad, r2);
-        if (valid[0] && lg == 0) lp[pt[0]] = konst - 0.5 * r2[0];
+#pragma unroll
+        for (int ks = 0; ks < ks_max; ++ks)
+          xin[0][ks] = valid[0] ? xin[0][ks] - mus[4 * ks + lg] : 0.0;
+        const double g = sy_quadform<DT>(T, xin[0], d, lane);
+        if (valid[0] && lg == 0) lp[pt[0]] = konst - 0.5 * g;
       }
       __threadfence_block();
       __syncthreads();
     }
     failed = sh_bad != 0;
-    double part = 0.0;
+    double lse_part = 0.0;
     for (int i = tid; i < n; i += GM_THREADS) {
       const double l0 = lp0[i], l1 = lp1[i];
       const double mx = l0 > l1 ? l0 : l1;
       const double lse = mx + log(exp(l0 - mx) + exp(l1 - mx));
       r0[i] = exp(l0 - lse);
-      part += lse;
+      lse_part += lse;
     }
     __threadfence_block();
-    const double lb = block_sum(part, red, wave, lane) / n;
+    const double lb = block_sum(lse_part, red, wave, lane) / n;
     __syncthreads();
     n_iter = it + 1;
     if (fabs(lb - lower) < a.tol) converged = 1;
@@ -439,11 +423,16 @@ nb_gmm_kernel(GmmArgs a) {
   }
 }
 
+inline int gm_dt(int d) { return (d + 1 + 15) / 16; }
+inline size_t gm_lds_doubles(int dt) {
+  const size_t tiles = (size_t)dt * (dt + 1) / 2 * NB_TILE;
+  const size_t seed = (size_t)GM_WAVES * 2 * 16 * dt;      // cpart aliases T
+  return (tiles > seed ? tiles : seed) + 4 * 16 * dt;
+}
+
 template <int DT>
 int launch_gmm(const GmmArgs& a, hipStream_t stream) {
-  const int m = a.d + 1;
-  const int mm = (m * m + 1) & ~1;
-  const size_t lds = ((size_t)3 * mm + nb_ell_block_size(DT)) * sizeof(double);
+  const size_t lds = gm_lds_doubles(DT) * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
     const hipError_t e = hipFuncSetAttribute(
@@ -466,17 +455,19 @@ int launch_gmm(const GmmArgs& a, hipStream_t stream) {
 
 long long nb_gmm_out_stride_impl(int d) { return 6 + 2LL * d + 2LL * d * d; }
 long long nb_gmm_scratch_stride_impl(long long n, int d) {
-  const int m = d + 1;
+  const int m = d + 1, dt = gm_dt(d);
   const long long mm = (m * m + 1) & ~1;
-  return mm + 5 * n + 2;
+  const long long part = (long long)(GM_WAVES / ((dt + 1) / 2)) *
+                         (dt * (dt + 1) / 2) * NB_TILE;
+  return mm + 5 * n + 2 + part;
 }
 
 int nb_launch_gmm(const double* x, long long n, int d, int n_init,
                   unsigned long long seed, double tol, double reg, int max_iter,
                   const int* init_labels, double* out, double* scratch,
                   hipStream_t stream) {
-  if (d < 1 || d + 1 > 64) {
-    nb_set_error("device mixture fit supports n_dim <= 63 (got %d)", d);
+  if (d < 1 || d > 128) {
+    nb_set_error("device mixture fit supports n_dim <= 128 (got %d)", d);
     return NB_ERR_UNSUPPORTED;
   }
   if (n < 2 || n > 100000000LL || n_init < 1 || max_iter < 0) {
@@ -489,13 +480,17 @@ int nb_launch_gmm(const double* x, long long n, int d, int n_init,
   a.out = out; a.scratch = scratch;
   a.out_stride = nb_gmm_out_stride_impl(d);
   a.scratch_stride = nb_gmm_scratch_stride_impl(n, d);
-  const int dt = (d + 1 + 15) / 16;
   int rc = NB_OK;
-  switch (dt) {
+  switch (gm_dt(d)) {
     case 1: rc = launch_gmm<1>(a, stream); break;
     case 2: rc = launch_gmm<2>(a, stream); break;
     case 3: rc = launch_gmm<3>(a, stream); break;
-    default: rc = launch_gmm<4>(a, stream); break;
+    case 4: rc = launch_gmm<4>(a, stream); break;
+    case 5: rc = launch_gmm<5>(a, stream); break;
+    case 6: rc = launch_gmm<6>(a, stream); break;
+    case 7: rc = launch_gmm<7>(a, stream); break;
+    case 8: rc = launch_gmm<8>(a, stream); break;
+    default: rc = launch_gmm<9>(a, stream); break;
   }
   if (rc != NB_OK) return rc;
   NB_HIP_CHECK(hipGetLastError());

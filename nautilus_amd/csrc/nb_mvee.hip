@@ -39,7 +39,7 @@
 //
 // Centre, covariance and the final scaling (basic.py:233-241) follow from u
 // with one more nb_moments launch and one "B only" call (nb_quadform_max).
-#include "nb_tile.h"
+#include "nb_sym.h"
 
 #include <cstring>
 
@@ -71,25 +71,6 @@ struct MomProb {
   int n, pad;
 };
 struct MomBatch { MomProb p[MV_MAXB]; };
-
-__host__ __device__ inline int mv_tri(int ht, int kt) {
-  return ht * (ht + 1) / 2 + kt;
-}
-// position of feature offset o (0..15) of a k-tile in the operand tile:
-// slot s = 2 (o >> 3) + (o & 1), lane group (o >> 1) & 3   (nb_tile.h, perm)
-__device__ __forceinline__ int mv_kpos(int o) {
-  return (2 * (o >> 3) + (o & 1)) * 64 + ((o >> 1) & 3) * 16;
-}
-// row position of feature offset o of an h-tile: the accumulator register r
-// of lane group lg then holds feature 8 (r >> 1) + 2 lg + (r & 1), i.e. the
-// feature the lane holds in input slot 4 ht + r
-__device__ __forceinline__ int mv_hpos(int o) {
-  return ((o >> 1) & 3) + 4 * (2 * (o >> 3) + (o & 1));
-}
-__device__ __forceinline__ int mv_slot(int f) {       // slot_of_feature
-  const int j = f >> 3, r = f & 7;
-  return 4 * (2 * j + (r & 1)) + (r >> 1);
-}
 
 typedef double mv_c2 __attribute__((ext_vector_type(2)));   // (g, index bits)
 
@@ -551,22 +532,7 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
 #pragma unroll
     for (int ks = 0; ks < 4 * DT; ++ks)
       if (ks == ks_one && lg == lg_one) xin[0][ks] = valid[0] ? 1.0 : 0.0;
-    double part = 0.0;
-#pragma unroll
-    for (int ht = 0; ht < DT; ++ht) {
-      if (16 * ht < m) {
-        nb_d4 acc = nb_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 4 * (ht + 1); ++ks) {
-          const double a =
-              T[mv_tri(ht, ks >> 2) * NB_TILE + (ks & 3) * 64 + lane];
-          acc = MFMA(a, xin[0][ks], acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += acc[r] * xin[0][4 * ht + r];
-      }
-    }
-    const double g = lane_group_sum(part);
+    const double g = sy_quadform<DT>(T, xin[0], m, lane);
     if (valid[0] && lg == 0) gwg[tile * 16 + lj] = g;
   }
   for (int e = tid; e < MV_WAVES * NSC; e += MV_THREADS)
@@ -637,80 +603,14 @@ nb_moments_kernel(MomBatch batch, int d, int pts_per_wg) {
   constexpr int SG = MV_WAVES / GW;           // sub-groups per workgroup
   constexpr int NT = DT * (DT + 1) / 2;
   const MomProb pb = batch.p[blockIdx.y];
-  const int n = pb.n;
   const int p0 = blockIdx.x * pts_per_wg;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sg = wave / GW, w = wave - sg * GW;
   if (sg >= SG) return;
-  const int kp = lane >> 4, fi = lane & 15;
-  const int row_lo = w, row_hi = DT - 1 - w;
-  const bool two = row_hi != row_lo;
-
-  nb_d4 acc_lo[DT], acc_hi[DT];
-#pragma unroll
-  for (int j = 0; j < DT; ++j) {
-    acc_lo[j] = nb_d4{0.0, 0.0, 0.0, 0.0};
-    acc_hi[j] = nb_d4{0.0, 0.0, 0.0, 0.0};
-  }
-  const int p1 = (p0 + pts_per_wg) < n ? (p0 + pts_per_wg) : n;
-  for (int s = p0 + 4 * sg; s < p1; s += 4 * SG) {
-    const int p = s + kp;
-    const bool on = p < p1;
-    const double wp = on ? (pb.w != nullptr ? pb.w[p] : 1.0) : 0.0;
-    double b[DT];
-#pragma unroll
-    for (int ft = 0; ft < DT; ++ft) {
-      const int f = 16 * ft + fi;
-      double v = 0.0;
-      if (on && f < d) v = pb.x[(size_t)p * d + f];
-      else if (on && f == d) v = 1.0;
-      b[ft] = v;
-    }
-    double a_lo, a_hi;
-    {
-      const int f = 16 * row_lo + fi;
-      double v = 0.0;
-      if (on && f < d) v = pb.x[(size_t)p * d + f];
-      else if (on && f == d) v = 1.0;
-      a_lo = v * wp;
-      const int f2 = 16 * row_hi + fi;
-      v = 0.0;
-      if (on && f2 < d) v = pb.x[(size_t)p * d + f2];
-      else if (on && f2 == d) v = 1.0;
-      a_hi = v * wp;
-    }
-#pragma unroll
-    for (int jt = 0; jt < DT; ++jt) {
-      if (jt <= row_lo) acc_lo[jt] = MFMA(a_lo, b[jt], acc_lo[jt]);
-      if (two && jt <= row_hi) acc_hi[jt] = MFMA(a_hi, b[jt], acc_hi[jt]);
-    }
-  }
-  double* out = pb.partial + ((size_t)blockIdx.x * SG + sg) * NT * NB_TILE;
-#pragma unroll
-  for (int jt = 0; jt < DT; ++jt) {
-    if (jt <= row_lo) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[mv_tri(row_lo, jt) * NB_TILE + r * 64 + lane] = acc_lo[jt][r];
-    }
-    if (two && jt <= row_hi) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[mv_tri(row_hi, jt) * NB_TILE + r * 64 + lane] = acc_hi[jt][r];
-    }
-  }
-}
-
-__device__ __forceinline__ double mom_element(const double* partial, int vw,
-                                              int nt, int r, int c) {
-  // entry (r, c) with r >= c summed over the partial results in fixed order
-  const int it = r >> 4, jt = c >> 4, i = r & 15, j = c & 15;
-  const int off = mv_tri(it, jt) * NB_TILE + (i >> 2) * 64 + (i & 3) * 16 + j;
-  double s = 0.0;
-  for (int v = 0; v < vw; ++v) s += partial[(size_t)v * nt * NB_TILE + off];
-  return s;
+  const int p1 = (p0 + pts_per_wg) < pb.n ? (p0 + pts_per_wg) : pb.n;
+  sy_moments<DT>(pb.x, pb.w, d, p0, p1, sg, SG, w, lane,
+                 pb.partial + ((size_t)blockIdx.x * SG + sg) * NT * NB_TILE);
 }
 
 // out[r][c] = S[r][c] * scale, full symmetric row-major (m x m)

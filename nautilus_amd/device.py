@@ -389,7 +389,6 @@ def prior_transform(u, kind, loc, scale):
     return out
 
 
-GMM_MAX_DIM = 63
 
 
 def gmm_fit(x, n_init=10, seed=0, tol=1e-3, reg_covar=1e-6, max_iter=100,

@@ -239,7 +239,6 @@ def ellipsoids_overlap(params):
 
 
 N_INIT = 10          # bounds/union.py:186
-_GMM_POOL = None
 
 
 class _Mixture:
@@ -253,43 +252,26 @@ class _Mixture:
         self.lower_bound_ = lower_bound
 
 
-def _fit_one(args):
-    from sklearn.mixture import GaussianMixture
-    points_t, seed = args
-    with threadpool_limits(limits=1):
-        return GaussianMixture(n_components=2, n_init=1,
-                               random_state=seed).fit(points_t)
-
-
 def _best_of_inits_host(points_t, random_state):
-    """scikit-learn on host threads -- used for n_dim > 63 only.  The
-    reference runs the restarts sequentially inside one
-    ``GaussianMixture(n_init=10)`` call; here they get seeds derived from
-    ``random_state`` and run concurrently (numpy releases the GIL inside
-    BLAS).  Same estimator, same selection rule (largest lower bound)."""
-    global _GMM_POOL
-    from concurrent.futures import ThreadPoolExecutor
-    seeds = np.random.RandomState(random_state).randint(2**31 - 1,
-                                                        size=N_INIT)
-    if _GMM_POOL is None:
-        _GMM_POOL = ThreadPoolExecutor(max_workers=N_INIT)
-    fits = list(_GMM_POOL.map(_fit_one, [(points_t, int(sd)) for sd in seeds]))
-    return max(fits, key=lambda g: g.lower_bound_)
+    """scikit-learn itself -- only reached when every device restart reports
+    a degenerate fit (an empty cluster or a covariance that is not positive
+    definite): scikit-learn relocates empty clusters and may still succeed,
+    and it is the reference's own estimator for this step (union.py:185-187),
+    so it decides."""
+    from sklearn.mixture import GaussianMixture
+    with threadpool_limits(limits=1):
+        return GaussianMixture(n_components=2, n_init=N_INIT,
+                               random_state=random_state).fit(points_t)
 
 
 def _best_of_inits(points_t, random_state):
     """Best of N_INIT restarts of the two-component mixture
     (mixture/_base.py:fit_predict keeps the largest lower bound).  All
-    restarts run concurrently on the GPU (``nb_gmm_fit``)."""
+    restarts run concurrently on the GPU (``nb_gmm_fit``, n_dim <= 128)."""
     from . import device
-    if points_t.shape[1] > device.GMM_MAX_DIM:
-        return _best_of_inits_host(points_t, random_state)
     fits = [f for f in device.gmm_fit(points_t, n_init=N_INIT,
                                       seed=random_state) if not f['failed']]
     if not fits:
-        # every restart hit an empty cluster or a covariance that is not
-        # positive definite (degenerate point sets): scikit-learn relocates
-        # empty clusters and may still succeed -- let it decide
         return _best_of_inits_host(points_t, random_state)
     best = max(fits, key=lambda f: f['lower_bound'])
     return _Mixture(best['weights'], best['means'], best['covariances'],

@@ -420,7 +420,8 @@ def _sklearn_em_from_labels(x, labels, **kw):
 
 
 @pytest.mark.parametrize('d,n', [(2, 300), (7, 500), (20, 1500), (50, 2000),
-                                 (63, 700)])
+                                 (63, 700), (64, 900), (100, 3000),
+                                 (127, 1200), (128, 1000)])
 def test_gmm_em_matches_sklearn(dev, d, n):
     """nb_gmm_fit against scikit-learn 1.7 (the reference's dependency for
     Union.split, union.py:185-187): same initial assignment -> same EM
