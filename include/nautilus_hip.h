@@ -221,7 +221,7 @@ int nb_mfma_f64_peak(int32_t iters, double* tflops_host);
  * UnitCubeEllipsoidMixture.compute and Union.compute/split): n_max sweeps of
  * up to n_batch Khachiyan updates over the n points x_dev (n > n_dim,
  * n_dim <= 128, n_batch <= 32).  u_dev[n] receives the weights u of
- * basic.py:231.  The points are standardised internally (the iteration is
+ * basic.py:231.  The points are whitened internally (the iteration is
  * affine invariant) and the work is spread over up to 32 workgroups.
  * work_dev: nb_mvee_weights_work_doubles(n, n_dim, n_batch) doubles.  The
  * reference's defaults are n_max = 100, n_batch = 20.                       */
@@ -231,12 +231,23 @@ int nb_mvee_weights(const double* x_dev, int64_t n, int32_t n_dim,
                     int32_t n_max, int32_t n_batch, double* u_dev,
                     double* work_dev, void* stream);
 
+/* Whitening of a point set: xw_dev[n][n_dim] = W ((x - mean) / sd) has zero
+ * mean and unit covariance (mean_dev, sd_dev: [n_dim]; w_dev: [n_dim^2], lower
+ * triangular, row-major; per-column statistics, second moments on the matrix
+ * cores, L D L^T of the correlation matrix in LDS, triangular product on the
+ * matrix cores).  The Khachiyan iteration is invariant under affine maps;
+ * on whitened points its matrices stay well conditioned however correlated
+ * or badly scaled the input is.  work_dev: nb_whiten_work_doubles(n, n_dim).  */
+int64_t nb_whiten_work_doubles(int64_t n, int32_t n_dim);
+int nb_whiten(const double* x_dev, int64_t n, int32_t n_dim, double* xw_dev,
+              double* mean_dev, double* sd_dev, double* w_dev,
+              double* work_dev, void* stream);
+
 /* The same iteration for a batch of independent point sets of one dimension
  * (the two children of Union.split, union.py:198-202; the neural-bound
  * ellipsoids of one NautilusBound, nautilus.py:107-114), advanced side by
- * side by the same launches.  xs_dev[b] are STANDARDISED points (zero mean,
- * unit variance per column, e.g. from nb_standardize); u_dev[b] receives the
- * weights of set b.  work_dev: nb_mvee_work_doubles(n_problems, max n,
+ * side by the same launches.  xs_dev[b] are WHITENED points (nb_whiten);
+ * u_dev[b] receives the weights of set b.  work_dev: nb_mvee_work_doubles(n_problems, max n,
  * n_dim, n_batch) doubles.                                                   */
 int64_t nb_mvee_work_doubles(int32_t n_problems, int64_t n_points_max,
                              int32_t n_dim, int32_t n_batch);

@@ -107,6 +107,10 @@ _SIGNATURES = {
                                     C.c_int32, C.c_int32,
                                     C.POINTER(C.c_void_p), C.c_void_p,
                                     C.c_void_p]),
+    'nb_whiten_work_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
+    'nb_whiten': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p]),
     'nb_moments_work_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
     'nb_weighted_moments': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_double, C.c_void_p,

@@ -46,6 +46,10 @@ int nb_launch_quadform_max(const double* x, long long n, int d,
                            const double* p_dev, double* out, double* work,
                            hipStream_t stream);
 long long nb_quadform_work_doubles_impl();
+long long nb_whiten_work_doubles_impl(long long n, int d);
+int nb_launch_whiten(const double* x, long long n, int d, double* xw,
+                     double* mean, double* sd, double* w, double* work,
+                     hipStream_t stream);
 int nb_launch_transform(const double* ell_block, int dt, int n_dim,
                         const double* x, long long n, double* y,
                         hipStream_t stream);
@@ -608,9 +612,26 @@ int nb_mvee_khachiyan(int32_t n_problems, const double* const* xs,
                               u, work, as_stream(stream));
 }
 
+int64_t nb_whiten_work_doubles(int64_t n, int32_t n_dim) {
+  return nb_whiten_work_doubles_impl(n, n_dim);
+}
+
+int nb_whiten(const double* x, int64_t n, int32_t n_dim, double* xw,
+              double* mean, double* sd, double* w, double* work,
+              void* stream) {
+  if (x == nullptr || xw == nullptr || mean == nullptr || sd == nullptr ||
+      w == nullptr || work == nullptr) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_whiten(x, n, n_dim, xw, mean, sd, w, work,
+                          as_stream(stream));
+}
+
 int64_t nb_mvee_weights_work_doubles(int64_t n, int32_t n_dim,
                                      int32_t n_batch) {
-  return 2 * 16 * NB_MAX_DT + n * n_dim + 2 +
+  return 2 * 16 * NB_MAX_DT + (int64_t)n_dim * n_dim + n * n_dim + 4 +
+         nb_whiten_work_doubles_impl(n, n_dim) +
          nb_mvee_work_doubles_impl(1, n, n_dim, n_batch);
 }
 
@@ -624,17 +645,19 @@ int nb_mvee_weights(const double* x, int64_t n, int32_t n_dim, int32_t n_max,
     nb_set_error("device MVEE supports n_dim <= 128 (got %d)", n_dim);
     return NB_ERR_UNSUPPORTED;
   }
-  // standardised copy of the points (the iteration is affine invariant)
+  // whitened copy of the points (the iteration is affine invariant)
   double* mean = work;
   double* scale = work + 16 * NB_MAX_DT;
-  double* xs = scale + 16 * NB_MAX_DT;
-  double* rest = xs + ((n * n_dim + 1) & ~(int64_t)1);
-  int rc = nb_launch_standardize(x, n, n_dim, mean, scale, xs,
-                                 as_stream(stream));
+  double* wmat = scale + 16 * NB_MAX_DT;
+  double* xw = wmat + (((int64_t)n_dim * n_dim + 1) & ~(int64_t)1);
+  double* wh = xw + ((n * n_dim + 1) & ~(int64_t)1);
+  double* rest = wh + nb_whiten_work_doubles_impl(n, n_dim);
+  int rc = nb_launch_whiten(x, n, n_dim, xw, mean, scale, wmat, wh,
+                            as_stream(stream));
   if (rc != NB_OK) return rc;
-  const double* xs_c = xs;
+  const double* xw_c = xw;
   long long nn = n;
-  return nb_launch_mvee_batch(1, &xs_c, &nn, n_dim, n_max, n_batch, &u, rest,
+  return nb_launch_mvee_batch(1, &xw_c, &nn, n_dim, n_max, n_batch, &u, rest,
                               as_stream(stream));
 }
 

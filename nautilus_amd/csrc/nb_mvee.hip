@@ -676,6 +676,85 @@ nb_spd_inverse_kernel(MomBatch batch, int d, int vw, int nt) {
   }
 }
 
+// Whitening factor of standardised points: C = S / n (the d x d block of the
+// moments) = L D L^T by elimination on the packed lower triangles of [C | I]
+// in LDS (one barrier per pivot), W = D^-1/2 L^-1.  Written twice: row-major
+// (for the host's back transformation) and as the operand block of
+// nb_transform_kernel (nb_common.h "ell block", centre 0), which maps the
+// points to unit covariance.  Near-singular pivots are clamped.
+constexpr int MV_WH_EPT = 17;          // ceil(128 * 129 / 2 / 512)
+
+__device__ __forceinline__ int pk(int r, int c) { return r * (r + 1) / 2 + c; }
+
+__global__ void __launch_bounds__(MV_THREADS)
+nb_whiten_factor_kernel(MomBatch batch, int d, int vw, int nt, double* w_out,
+                        double* ell_out) {
+  extern __shared__ __attribute__((aligned(16))) double wl[];
+  const MomProb pb = batch.p[0];
+  const int tid = threadIdx.x;
+  const int nl = d * (d + 1) / 2;
+  double* A = wl;
+  double* B = wl + nl;
+  const double inv_n = 1.0 / (double)pb.n;
+  int er[MV_WH_EPT], ec[MV_WH_EPT];
+#pragma unroll
+  for (int q = 0; q < MV_WH_EPT; ++q) {
+    const int e = tid + q * MV_THREADS;
+    int r = -1, c = 0;
+    if (e < nl) {
+      r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while (r * (r + 1) / 2 > e) --r;
+      while ((r + 1) * (r + 2) / 2 <= e) ++r;
+      c = e - r * (r + 1) / 2;
+      A[e] = mom_element(pb.partial, vw, nt, r, c) * inv_n;
+      B[e] = r == c ? 1.0 : 0.0;
+    }
+    er[q] = r;
+    ec[q] = c;
+  }
+  __syncthreads();
+  for (int p = 0; p + 1 < d; ++p) {
+    double dp = A[pk(p, p)];
+    if (!(dp > 1e-15)) dp = 1e-15;
+    const double inv = 1.0 / dp;
+#pragma unroll
+    for (int q = 0; q < MV_WH_EPT; ++q) {
+      const int i = er[q], j = ec[q];
+      if (i > p) {
+        const double f = A[pk(i, p)] * inv;
+        if (j > p) A[pk(i, j)] -= f * A[pk(j, p)];
+        else B[pk(i, j)] -= f * B[pk(p, j)];
+      }
+    }
+    __syncthreads();
+  }
+  const int dt = (d + 15) / 16, dp16 = 16 * dt;
+  const int blk = nb_ell_block_size(dt);
+  for (int e = tid; e < blk; e += MV_THREADS) ell_out[e] = 0.0;
+  for (int e = tid; e < d * d; e += MV_THREADS) w_out[e] = 0.0;
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) ((long long*)ell_out)[0] = d;
+  const double inf = __builtin_huge_val();
+  for (int f = tid; f < dp16; f += MV_THREADS) {
+    ell_out[2 + f] = -inf;
+    ell_out[2 + dp16 + f] = inf;
+  }
+  double* tiles = ell_out + 2 + 3 * dp16;
+#pragma unroll
+  for (int q = 0; q < MV_WH_EPT; ++q) {
+    const int r = er[q], c = ec[q];
+    if (r < 0) continue;
+    double dr = A[pk(r, r)];
+    if (!(dr > 1e-15)) dr = 1e-15;
+    const double v = B[pk(r, c)] / sqrt(dr);
+    w_out[r * d + c] = v;
+    const int sl = mv_slot(c), ks = sl >> 2, lgk = sl & 3;
+    tiles[((ks >> 2) * dt + (r >> 4)) * NB_TILE + (ks & 3) * 64 + lgk * 16 +
+          (r & 15)] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -949,4 +1028,53 @@ int nb_launch_quadform_max(const double* x, long long n, int d,
 
 long long nb_quadform_work_doubles_impl() {
   return 2LL * MV_MAXW * 20 + (2LL * MV_MAXW * 21 + 1) / 2 + 8;
+}
+
+long long nb_whiten_work_doubles_impl(long long n, int d) {
+  const int dt = (d + 15) / 16;
+  return ((n * d + 1) & ~1LL) + mom_partial_doubles(n, (d + 1 + 15) / 16) +
+         nb_ell_block_size(dt) + 16;
+}
+
+int nb_launch_standardize(const double* x, long long n, int d, double* mean,
+                          double* scale, double* out, hipStream_t stream);
+int nb_launch_transform(const double* ell_block, int dt, int n_dim,
+                        const double* x, long long n, double* y,
+                        hipStream_t stream);
+
+// xw = W ((x - mean) / sd): zero mean, unit covariance.  mean[d], sd[d],
+// w[d*d] (lower triangular, row-major) describe the map.
+int nb_launch_whiten(const double* x, long long n, int d, double* xw,
+                     double* mean, double* sd, double* w, double* work,
+                     hipStream_t stream) {
+  if (d < 1 || d > 128 || n <= d || n > 2147483647LL / (d + 1)) {
+    nb_set_error("whitening needs n_dim < n, n_dim <= 128 (n=%lld, n_dim=%d)",
+                 n, d);
+    return NB_ERR_ARG;
+  }
+  const int dtm = (d + 1 + 15) / 16, dt = (d + 15) / 16;
+  double* xs = work;
+  double* partial = xs + ((n * d + 1) & ~1LL);
+  double* ell = partial + mom_partial_doubles(n, dtm);
+  int rc = nb_launch_standardize(x, n, d, mean, sd, xs, stream);
+  if (rc != NB_OK) return rc;
+  MomBatch b;
+  memset(&b, 0, sizeof(b));
+  b.p[0].x = xs; b.p[0].w = nullptr; b.p[0].n = (int)n;
+  b.p[0].partial = partial;
+  const int ppw = mom_pts_per_wg(n);
+  const int wg = (int)((n + ppw - 1) / ppw);
+  rc = launch_moments(dtm, b, 1, d, wg, ppw, stream);
+  if (rc != NB_OK) return rc;
+  {
+    static size_t allowed = 0;
+    const size_t bytes = (size_t)d * (d + 1) * sizeof(double);
+    rc = set_lds(nb_whiten_factor_kernel, bytes, &allowed);
+    if (rc != NB_OK) return rc;
+    hipLaunchKernelGGL(nb_whiten_factor_kernel, dim3(1), dim3(MV_THREADS), bytes,
+                       stream, b, d, wg * mom_sg(dtm), dtm * (dtm + 1) / 2, w,
+                       ell);
+  }
+  NB_HIP_CHECK(hipGetLastError());
+  return nb_launch_transform(ell, dt, d, xs, n, xw, stream);
 }

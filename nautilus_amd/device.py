@@ -8,6 +8,7 @@ import ctypes as C
 
 import numpy as np
 import torch
+from scipy.linalg import solve_triangular
 
 from . import _lib
 
@@ -301,26 +302,41 @@ def quadform_max(x, p):
     return out
 
 
+def whiten(x):
+    """(xw, mean, sd, w) with xw = w ((x - mean) / sd) of zero mean and unit
+    covariance -- ``nb_whiten``."""
+    lib = _lib.load()
+    x = as_device_points(x)
+    n, d = x.shape
+    xw = torch.empty_like(x)
+    stats = torch.empty(2 * d + d * d, dtype=torch.float64, device='cuda')
+    work = _work(lib.nb_whiten_work_doubles(n, d))
+    _lib.check(lib.nb_whiten(
+        _ptr(x), n, d, _ptr(xw), _ptr(stats), _ptr(stats[d:]),
+        _ptr(stats[2 * d:]), _ptr(work), _stream()))
+    return xw, stats
+
+
 def mvee_fit_batch(point_sets, n_max=100, n_batch=20):
     """minimum_volume_enclosing_ellipsoid (reference bounds/basic.py:175-241)
     for several point sets of one dimension at once.
 
-    Every set is standardised on the device (``nb_standardize``), the
-    Khachiyan iterations of all sets advance side by side in the same
-    launches (``nb_mvee_khachiyan``), centre and covariance follow from the
-    weights with one matrix-core pass (``nb_weighted_moments``, basic.py:
-    233-234) and the scaling from the largest quadratic form
-    (``nb_quadform_max``, basic.py:236).  Only (n_dim+1)^2 numbers per set
-    cross PCIe.  Returns a list of (c, A, A_inv) like the reference."""
+    Every set is whitened on the device (``nb_whiten``; the iteration is
+    affine invariant), the Khachiyan iterations of all sets advance side by
+    side in the same launches (``nb_mvee_khachiyan``), centre and covariance
+    follow from the weights with one matrix-core pass
+    (``nb_weighted_moments``, basic.py:233-234) and the scaling from the
+    largest quadratic form (``nb_quadform_max``, basic.py:236).  Only
+    O(n_dim^2) numbers per set cross PCIe.  Returns a list of (c, A, A_inv)
+    like the reference."""
     lib = _lib.load()
-    xs, means, sds, us = [], [], [], []
+    xs, stats, us = [], [], []
     for pts in point_sets:
-        x = as_device_points(pts)
-        mean, sd, x_std = standardize(x)
-        xs.append(x_std)
-        means.append(mean)
-        sds.append(sd)
-        us.append(torch.empty(x.shape[0], dtype=torch.float64, device='cuda'))
+        xw, st = whiten(pts)
+        xs.append(xw)
+        stats.append(st)
+        us.append(torch.empty(xw.shape[0], dtype=torch.float64,
+                              device='cuda'))
     nb = len(xs)
     d = xs[0].shape[1]
     n_arr = (C.c_int64 * nb)(*[x.shape[0] for x in xs])
@@ -331,8 +347,8 @@ def mvee_fit_batch(point_sets, n_max=100, n_batch=20):
         _stream()))
     moments = torch.stack([weighted_moments(x, u) for x, u in zip(xs, us)])
     moments = moments.cpu().numpy()
-    stats = torch.stack(means + sds).cpu().numpy()
-    # host: (n_dim+1)^2 matrices only
+    stats = torch.stack(stats).cpu().numpy()
+    # host: O(n_dim^2) numbers per set only
     p_all, c_all, cov_all = [], [], []
     for s in moments:
         su = s[d, d]
@@ -350,13 +366,16 @@ def mvee_fit_batch(point_sets, n_max=100, n_batch=20):
     gmax = gmax.cpu().numpy()
     out = []
     for b in range(nb):
-        mean, sd = stats[b], stats[nb + b]
+        mean, sd = stats[b, :d], stats[b, d:2 * d]
+        w = stats[b, 2 * d:].reshape(d, d)
+        # x = mean + back xw with back = diag(sd) w^-1 (lower triangular)
+        back = sd[:, None] * solve_triangular(w, np.eye(d), lower=True)
+        fwd = w / sd[None, :]                           # back^-1
         scale = gmax[b] - 1.0                           # basic.py:236
-        a_std = np.linalg.inv(cov_all[b])
-        c = mean + sd * c_all[b]
-        a = a_std / np.outer(sd, sd) / scale
-        a_inv = cov_all[b] * np.outer(sd, sd) * scale
-        out.append((c, a, a_inv))
+        c = mean + back @ c_all[b]
+        a_inv = back @ cov_all[b] @ back.T * scale
+        a = fwd.T @ np.linalg.inv(cov_all[b]) @ fwd / scale
+        out.append((c, 0.5 * (a + a.T), 0.5 * (a_inv + a_inv.T)))
     return out
 
 
