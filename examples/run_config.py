@@ -3,7 +3,7 @@ C1-C5) on one GPU:  python examples/run_config.py C4 [--n-eff 10000]
 
 Prints one JSON line per run: wall time, log Z (and the analytic value where
 one exists), effective sample size, likelihood calls, bounds.  The likelihoods
-are user-side code (torch on the device batch), not part of the product.
+are the product's device likelihoods (nautilus_amd/likelihoods.py).
 """
 
 import argparse
@@ -17,31 +17,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from nautilus_amd import (GaussianLikelihood, GaussianMixtureLikelihood,  # noqa
+from nautilus_amd import (FunnelLikelihood, GaussianLikelihood,  # noqa
+                          GaussianMixtureLikelihood, RosenbrockLikelihood,
                           Sampler, unit_prior)
-
-
-def rosenbrock(u):
-    x = 10.0 * u - 5.0
-    return -torch.sum(100.0 * (x[:, 1:] - x[:, :-1]**2)**2 +
-                      (1.0 - x[:, :-1])**2, dim=1)
-
-
-rosenbrock.device = True
-
-
-def funnel(u):
-    # x0 ~ N(0.5, 0.1^2), x_i ~ N(0.5, (exp(20 (x0 - 0.5)) / 100)^2)
-    d = u.shape[1]
-    s = torch.exp(20.0 * (u[:, 0] - 0.5)) / 100.0
-    z0 = (u[:, 0] - 0.5) / 0.1
-    zi = (u[:, 1:] - 0.5) / s[:, None]
-    return (-0.5 * z0**2 - np.log(0.1) - 0.5 * np.log(2 * np.pi) -
-            0.5 * torch.sum(zi**2, dim=1) - (d - 1) * torch.log(s) -
-            0.5 * (d - 1) * np.log(2 * np.pi))
-
-
-funnel.device = True
 
 
 def config(name):
@@ -55,14 +33,14 @@ def config(name):
         return dict(like=GaussianLikelihood(np.full(d, 0.5), cov), n_dim=d,
                     n_live=2000, n_networks=4, analytic=0.0)
     if name == 'C3':
-        return dict(like=rosenbrock, n_dim=30, n_live=3000, n_networks=4,
+        return dict(like=RosenbrockLikelihood(30), n_dim=30, n_live=3000, n_networks=4,
                     analytic=None)
     if name == 'C4':
         means = 0.25 + 0.5 * np.random.default_rng(3).random((4, 50))
         return dict(like=GaussianMixtureLikelihood(means, 0.02), n_dim=50,
                     n_live=5000, n_networks=4, analytic=0.0)
     if name == 'C5':
-        return dict(like=funnel, n_dim=100, n_live=10000, n_networks=8,
+        return dict(like=FunnelLikelihood(100), n_dim=100, n_live=10000, n_networks=8,
                     analytic=None)
     raise SystemExit('unknown config ' + name)
 

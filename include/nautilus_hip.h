@@ -297,6 +297,21 @@ int nb_prior_transform(const double* u_dev, int64_t n, int32_t n_dim,
                        const uint8_t* kind, const double* loc,
                        const double* scale, double* out_dev, void* stream);
 
+/* Device likelihoods of the benchmark problems (the user-side callable of
+ * sampler.py:863-873 for the BASELINE configurations C3 and C5; Gaussians go
+ * through nb_neural_score): out_dev[i] = log L of row i of u_dev (unit-cube
+ * points, n x n_dim).
+ *   Rosenbrock: x = lo + (hi - lo) u,
+ *               log L = -sum_i [a (x_{i+1} - x_i^2)^2 + (1 - x_i)^2]
+ *   Neal funnel (tests/test_sampler.py:311-314 in n_dim dimensions):
+ *               x_0 ~ N(mu, sigma0^2), x_i ~ N(mu, (exp(k (x_0 - mu)) / c)^2) */
+int nb_loglike_rosenbrock(const double* u_dev, int64_t n, int32_t n_dim,
+                          double lo, double hi, double a, double* out_dev,
+                          void* stream);
+int nb_loglike_funnel(const double* u_dev, int64_t n, int32_t n_dim, double mu,
+                      double sigma0, double k, double c, double* out_dev,
+                      void* stream);
+
 /* The mixture fit of Union.split (bounds/union.py:185-187): scikit-learn's
  * GaussianMixture(n_components=2, n_init=n_init, covariance_type='full')
  * restated on the device -- k-means++ / Lloyd initialisation, EM until the

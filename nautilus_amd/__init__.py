@@ -17,6 +17,7 @@ _LAZY = {
     'NeuralNetworkEmulator': 'emulator',
     'GaussianLikelihood': 'likelihoods',
     'GaussianMixtureLikelihood': 'likelihoods', 'unit_prior': 'likelihoods',
+    'RosenbrockLikelihood': 'likelihoods', 'FunnelLikelihood': 'likelihoods',
 }
 
 

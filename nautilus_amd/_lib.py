@@ -126,6 +126,12 @@ _SIGNATURES = {
     'nb_prior_transform': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
                                      C.c_void_p, c_double_p, c_double_p,
                                      C.c_void_p, C.c_void_p]),
+    'nb_loglike_rosenbrock': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
+                                        C.c_double, C.c_double, C.c_double,
+                                        C.c_void_p, C.c_void_p]),
+    'nb_loglike_funnel': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
+                                    C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_void_p, C.c_void_p]),
     'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
     'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
     'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

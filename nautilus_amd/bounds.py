@@ -567,18 +567,19 @@ class NeuralBound(_DeviceBoundBase):
 
     @classmethod
     def compute(cls, points, log_l, log_l_min, enlarge_per_dim=1.1,
-                n_networks=4, neural_network_kwargs={}, pool=None, rng=None):
+                n_networks=4, neural_network_kwargs={}, pool=None, rng=None,
+                comm=None):
         """``points`` may be a numpy array or a cuda tensor (the sampler keeps
         all points on the device); ``log_l`` is a numpy array."""
         return cls.compute_many([(points, log_l)], log_l_min,
                                 enlarge_per_dim=enlarge_per_dim,
                                 n_networks=n_networks,
                                 neural_network_kwargs=neural_network_kwargs,
-                                rng=rng)[0]
+                                rng=rng, comm=comm)[0]
 
     @classmethod
     def compute_many(cls, data, log_l_min, enlarge_per_dim=1.1, n_networks=4,
-                     neural_network_kwargs={}, rng=None):
+                     neural_network_kwargs={}, rng=None, comm=None):
         """bounds/neural.py:58-97 for several (points, log_l) sets -- the
         neural bounds of one NautilusBound (nautilus.py:107-114).  The
         reference trains their emulators one after the other; here all
@@ -618,7 +619,7 @@ class NeuralBound(_DeviceBoundBase):
             emus = NeuralNetworkEmulator.train_many(
                 [(x_t, score) for _, x_t, score, _ in train],
                 n_networks=n_networks,
-                neural_network_kwargs=neural_network_kwargs)
+                neural_network_kwargs=neural_network_kwargs, comm=comm)
             for (self, x_t, score, hi), emu in zip(train, emus):
                 self.emulator = emu
                 pred = emu.predict_device(x_t).cpu().numpy()
@@ -713,7 +714,10 @@ class NautilusBound(_RejectionSampler):
     def compute(cls, points, log_l, log_l_min, log_v_target,
                 enlarge_per_dim=1.1, n_points_min=None, split_threshold=100,
                 periodic=None, n_networks=4, neural_network_kwargs={},
-                pool=None, rng=None):
+                pool=None, rng=None, comm=None):
+        """nautilus.py:39-144.  ``comm`` (a ``parallel.ShardedComm``) deals
+        the emulator networks out over the GPUs of a sharded run, the way the
+        reference maps them over ``pool`` (neural.py:93-96)."""
         self = cls()
         t0 = time()
         log_l = np.asarray(log_l)
@@ -741,7 +745,8 @@ class NautilusBound(_RejectionSampler):
         self.neural_bounds = NeuralBound.compute_many(
             data, log_l_min, enlarge_per_dim=enlarge_per_dim,
             n_networks=n_networks,
-            neural_network_kwargs=neural_network_kwargs, rng=self.rng)
+            neural_network_kwargs=neural_network_kwargs, rng=self.rng,
+            comm=comm)
 
         t2 = time()
         # sampling envelope (:116-133)

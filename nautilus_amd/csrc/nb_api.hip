@@ -46,6 +46,10 @@ int nb_launch_quadform_max(const double* x, long long n, int d,
                            const double* p_dev, double* out, double* work,
                            hipStream_t stream);
 long long nb_quadform_work_doubles_impl();
+int nb_launch_rosenbrock(const double* u, long long n, int d, double lo,
+                         double hi, double a, double* out, hipStream_t stream);
+int nb_launch_funnel(const double* u, long long n, int d, double mu, double s0,
+                     double k, double c, double* out, hipStream_t stream);
 long long nb_whiten_work_doubles_impl(long long n, int d);
 int nb_launch_whiten(const double* x, long long n, int d, double* xw,
                      double* mean, double* sd, double* w, double* work,
@@ -729,6 +733,27 @@ int nb_prior_transform(const double* u, int64_t n, int32_t n_dim,
       return NB_ERR_UNSUPPORTED;
     }
   return nb_launch_prior(u, n, n_dim, kind, loc, scale, out, as_stream(stream));
+}
+
+int nb_loglike_rosenbrock(const double* u, int64_t n, int32_t n_dim, double lo,
+                          double hi, double a, double* out, void* stream) {
+  if (n_dim < 2 || (n > 0 && (u == nullptr || out == nullptr))) {
+    nb_set_error("bad Rosenbrock likelihood arguments");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_rosenbrock(u, n, n_dim, lo, hi, a, out, as_stream(stream));
+}
+
+int nb_loglike_funnel(const double* u, int64_t n, int32_t n_dim, double mu,
+                      double sigma0, double k, double c, double* out,
+                      void* stream) {
+  if (n_dim < 2 || !(sigma0 > 0.0) || !(c > 0.0) ||
+      (n > 0 && (u == nullptr || out == nullptr))) {
+    nb_set_error("bad funnel likelihood arguments");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_funnel(u, n, n_dim, mu, sigma0, k, c, out,
+                          as_stream(stream));
 }
 
 int64_t nb_gmm_out_doubles(int32_t n_dim) {

@@ -24,6 +24,7 @@
 #include "nb_common.h"
 #include "../../include/nautilus_hip.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -622,8 +623,8 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 // ---------------------------------------------------------------------------
 constexpr int XCD_COUNT = 8;
 constexpr int XCD_SLOTS = 17;            // workgroups per network
-constexpr int SYNC_WORDS = 4;            // counter, error, xcc mask, pad
-constexpr int SYNC_LIMIT = 1 << 22;
+constexpr int SYNC_WORDS = 4;            // counter, error, (unused), ticket
+constexpr int SYNC_LIMIT = 1 << 23;
 
 // (split into arrive / wait so that read-only prefetches can be issued in
 // between: after the workgroup has signalled, before it starts polling)
@@ -680,36 +681,35 @@ __global__ void __launch_bounds__(256)
 nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
   // own disjoint XCDs; map.net[x] = network of XCD x or -1
+  // The workgroup asks the hardware which XCD it runs on and takes a ticket
+  // there: the first XCD_SLOTS arrivals on an XCD this trainer owns are the
+  // network's workgroups, everybody else leaves.  (The dispatcher deals the
+  // workgroups of a grid out round-robin over the XCDs, 17 each for this
+  // grid, but not necessarily starting at XCD 0 when several queues are
+  // active -- two concurrent trainers that both assumed blockIdx % 8 could
+  // end up with 34 resident workgroups on the 32 CUs of one XCD and wait for
+  // each other forever.)
+  __shared__ int sh_slot;
   const int n_nets = map.n_nets;
-  const int net = map.net[(int)blockIdx.x % XCD_COUNT];
-  if (net < 0) return;
-  const int slot = (int)blockIdx.x / XCD_COUNT;
-  if (net >= n_nets) return;
-  const NetState st = a.nets[net];
+  unsigned xcc_id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+  const int net = map.net[xcc_id & (XCD_COUNT - 1)];
+  if (net < 0 || net >= n_nets) return;
   int* counter = sync + SYNC_WORDS * net;
   int* err = counter + 1;
-  int* mask = counter + 2;
+  int* ticket = counter + 3;
+  if (threadIdx.x == 0) sh_slot = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int slot = sh_slot;
+  if (slot >= XCD_SLOTS) return;
+  const NetState st = a.nets[net];
   int phase = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long n = a.n;
   const int steps = (int)((n + a.batch - 1) / a.batch);
   const int n_gt = nb_net_tiles(a.kt1);
-  if (threadIdx.x == 0) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    atomicOr(mask, 1 << (xcc & 15));
-  }
   xcd_barrier(counter, err, phase, XCD_SLOTS);
-  {
-    const int m = __hip_atomic_load(mask, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT);
-    if (__popc(m) != 1) {                 // not one XCD: no shared L2
-      if (threadIdx.x == 0)
-        __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-  }
   long long t_adam = t_adam0;
   FbRows<DT> rows;
   bool have_rows = false;        // rows = the slice of the step about to run
@@ -858,6 +858,10 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
       g_xcd_in_use |= t->xcd_owned;
     }
   }
+  if (getenv("NB_TRAIN_DEBUG") != nullptr)
+    fprintf(stderr, "[trainer] nets=%d n=%lld two_launch=%d owned=%02x in_use=%02x\n",
+            n_networks, (long long)n_rows, (int)t->two_launch, t->xcd_owned,
+            g_xcd_in_use);
   if (e != hipSuccess) {
     nb_set_error("trainer allocation failed: %s", hipGetErrorString(e));
     nb_trainer_destroy(t);

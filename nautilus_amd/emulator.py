@@ -162,16 +162,24 @@ class NeuralNetworkEmulator:
     """Drop-in for ``nautilus.neural.NeuralNetworkEmulator``."""
 
     @classmethod
-    def train(cls, x, y, n_networks=4, neural_network_kwargs={}, pool=None):
+    def train(cls, x, y, n_networks=4, neural_network_kwargs={}, pool=None,
+              comm=None):
         """neural.py:50-98.  ``x`` / ``y`` may be numpy arrays or cuda
         tensors; ``pool`` is accepted for API compatibility (the networks
-        train concurrently on the GPU, one workgroup each)."""
-        return cls.train_many([(x, y)], n_networks, neural_network_kwargs)[0]
+        train concurrently on the GPU, one XCD each); ``comm`` deals them out
+        over the GPUs of a sharded run."""
+        return cls.train_many([(x, y)], n_networks, neural_network_kwargs,
+                              comm=comm)[0]
 
     @classmethod
-    def train_many(cls, data, n_networks=4, neural_network_kwargs={}):
+    def train_many(cls, data, n_networks=4, neural_network_kwargs={},
+                   comm=None):
         """``train`` for several (x, y) sets at once; the ensembles train
-        concurrently on separate streams."""
+        concurrently on separate streams.  With ``comm`` (a
+        ``parallel.ShardedComm``) network g of the flattened (ensemble,
+        seed) list trains on rank g mod world and the weights are exchanged
+        afterwards (reference neural.py:93-96: networks mapped over the
+        pool)."""
         hp = _hparams_from_kwargs(dict(neural_network_kwargs))
         emus, jobs = [], []
         for x, y in data:
@@ -187,7 +195,9 @@ class NeuralNetworkEmulator:
             emus.append(emu)
             jobs.append(dict(xs=xs, y=yt, seeds=list(range(n_networks)),
                              hparams=hp))
-        for emu, (nets, stats) in zip(emus, train_ensembles(jobs)):
+        results = (train_ensembles(jobs) if comm is None or comm.world == 1
+                   else train_ensembles_sharded(jobs, comm))
+        for emu, (nets, stats) in zip(emus, results):
             emu.neural_networks, emu.trainer_stats = nets, stats
         return emus
 
@@ -333,3 +343,75 @@ def train_networks(xs, y, seeds, hparams=None, permutations=None,
     return train_ensembles([dict(xs=xs, y=y, seeds=seeds, hparams=hparams,
                                  permutations=permutations, init=init,
                                  max_epochs=max_epochs)])[0]
+
+
+def _pack_network(net, n_dim):
+    """[n_iter, final loss, coefs..., intercepts...] as one float64 row."""
+    parts = [np.array([net.n_iter_, net.loss_curve_[-1]
+                       if len(net.loss_curve_) else 0.0])]
+    parts += [np.ravel(c) for c in net.coefs_]
+    parts += [np.ravel(b) for b in net.intercepts_]
+    return np.concatenate(parts)
+
+
+def _unpack_network(row, n_dim):
+    units = [n_dim, *HIDDEN, 1]
+    pos = 2
+    coefs, intercepts = [], []
+    for a, b in zip(units[:-1], units[1:]):
+        coefs.append(row[pos:pos + a * b].reshape(a, b).copy())
+        pos += a * b
+    for b in units[1:]:
+        intercepts.append(row[pos:pos + b].copy())
+        pos += b
+    return Network(coefs, intercepts, int(row[0]), [float(row[1])])
+
+
+def train_ensembles_sharded(jobs, comm):
+    """``train_ensembles`` with the networks dealt out over the ranks of
+    ``comm``: network g (ensembles in order, seeds in order) belongs to rank
+    g mod world.  Every rank trains its share as smaller ensembles, then one
+    all-reduce of the zero-padded weight rows brings all networks to all
+    ranks.  Training is deterministic given (data, seed), so the result is
+    bit for bit that of ``train_ensembles``; only the last entry of each
+    remote network's loss curve travels."""
+    flat = [(j, s) for j, job in enumerate(jobs) for s in job['seeds']]
+    mine = [g for g in range(len(flat)) if g % comm.world == comm.rank]
+    local_jobs, local_of = [], {}
+    for g in mine:
+        j, seed = flat[g]
+        key = j
+        if key not in local_of:
+            local_of[key] = len(local_jobs)
+            job = dict(jobs[j])
+            job['seeds'] = []
+            for opt in ('permutations', 'init'):
+                if job.get(opt) is not None:
+                    job[opt] = []
+            local_jobs.append(job)
+        lj = local_jobs[local_of[key]]
+        lj['seeds'].append(seed)
+        pos = jobs[j]['seeds'].index(seed)
+        for opt in ('permutations', 'init'):
+            if jobs[j].get(opt) is not None:
+                lj[opt].append(jobs[j][opt][pos])
+    trained = train_ensembles(local_jobs) if local_jobs else []
+    n_dim = jobs[0]['xs'].shape[1]
+    units = [n_dim, *HIDDEN, 1]
+    width = 2 + sum(a * b + b for a, b in zip(units[:-1], units[1:]))
+    rows = np.zeros((len(flat), width))
+    for g in mine:
+        j, seed = flat[g]
+        nets, _ = trained[local_of[j]]
+        net = nets[local_jobs[local_of[j]]['seeds'].index(seed)]
+        rows[g] = _pack_network(net, n_dim)
+    rows = comm.sum_rows(torch.from_numpy(rows).cuda()).cpu().numpy()
+    out, g = [], 0
+    for job in jobs:
+        nets = []
+        for _ in job['seeds']:
+            nets.append(_unpack_network(rows[g], n_dim))
+            g += 1
+        out.append((nets, dict(n_iter=[n.n_iter_ for n in nets],
+                               n_rows=job['xs'].shape[0])))
+    return out

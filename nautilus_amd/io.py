@@ -128,8 +128,14 @@ def write_bound(bound, group):
             write_bound(neural, group.create_group(
                 'neural_bound_{}'.format(i)))
         write_bound(bound.outer_bound, group.create_group('outer_bound'))
-        group.create_dataset('points', data=bound.points,
+        group.create_dataset('points', data=_file_points(bound),
                              maxshape=(None, bound.n_dim))
+        if bound.shift is not None:
+            # the device queue itself (sampler frame): a resumed run of THIS
+            # implementation continues bit for bit, which a shift / unshift
+            # round trip through 'points' cannot guarantee
+            group.create_dataset('amd_points', data=bound.points,
+                                 maxshape=(None, bound.n_dim))
         group.attrs['n_sample'] = bound.n_sample
         group.attrs['n_reject'] = bound.n_reject
         _write_stream(bound, group)
@@ -141,15 +147,40 @@ def write_bound(bound, group):
         raise TypeError('cannot write {}'.format(type(bound).__name__))
 
 
+def _file_points(bound):
+    """Queued points of a bound in the frame the reference stores them in:
+    a NautilusBound with periodic parameters keeps ``self.points`` in the
+    SHIFTED frame and undoes the shift when it hands points out
+    (bounds/nautilus.py:239-243), while the device queue holds sampler-frame
+    rows (bounds.py ``_fill``).  Forward shift on the way to the file."""
+    pts = bound.points
+    shift = getattr(bound, 'shift', None)
+    if shift is not None and len(pts) > 0:
+        pts = shift.transform(pts)
+    return pts
+
+
+def _queue_points(bound, pts):
+    """File frame -> sampler frame (inverse of ``_file_points``)."""
+    shift = getattr(bound, 'shift', None)
+    if shift is not None and len(pts) > 0:
+        pts = shift.transform(pts, inverse=True)
+    return pts
+
+
 def update_bound(bound, group):
     """bounds/union.py:374-385, bounds/nautilus.py:328-342."""
     group.attrs['n_sample'] = bound.n_sample
     group.attrs['n_reject'] = bound.n_reject
     if isinstance(bound, nb.NautilusBound):
         update_bound(bound.outer_bound, group['outer_bound'])
-    pts = bound.points
+    pts = _file_points(bound)
     group['points'].resize(pts.shape)
     group['points'][...] = pts
+    if 'amd_points' in group:
+        raw = bound.points
+        group['amd_points'].resize(raw.shape)
+        group['amd_points'][...] = raw
     _write_stream(bound, group)
 
 
@@ -219,7 +250,11 @@ def read_bound(cls, group, rng=None):
         bound.outer_bound._queue().clear()
         bound.n_sample = int(group.attrs['n_sample'])
         bound.n_reject = int(group.attrs['n_reject'])
-        _set_queue(bound, np.array(group['points']))
+        if 'amd_points' in group and 'amd_philox_seed' in group.attrs:
+            _set_queue(bound, np.array(group['amd_points'], dtype=float))
+        else:                            # a file written by the reference
+            _set_queue(bound, _queue_points(
+                bound, np.array(group['points'], dtype=float)))
     elif cls is nb.PhaseShift:
         bound.periodic = np.array(group.attrs['periodic'])
         bound.centers = np.array(group.attrs['centers'], dtype=float)

@@ -89,3 +89,63 @@ class GaussianMixtureLikelihood:
         from scipy.special import logsumexp
         return logsumexp([p.numpy(x) for p in self.parts], axis=0) - \
             np.log(len(self.parts))
+
+
+class RosenbrockLikelihood:
+    """Rosenbrock function on x = low + (high - low) u (BASELINE config 3):
+    log L = -sum_i [a (x_{i+1} - x_i^2)^2 + (1 - x_i)^2] --
+    ``nb_loglike_rosenbrock``."""
+
+    device = True
+
+    def __init__(self, n_dim, low=-5.0, high=5.0, a=100.0):
+        self.n_dim = int(n_dim)
+        self.low, self.high, self.a = float(low), float(high), float(a)
+
+    def __call__(self, x):
+        from . import _lib
+        lib = _lib.load()
+        xs = device.as_device_points(x, self.n_dim)
+        out = torch.empty(xs.shape[0], dtype=torch.float64, device='cuda')
+        _lib.check(lib.nb_loglike_rosenbrock(
+            device._ptr(xs), xs.shape[0], self.n_dim, self.low, self.high,
+            self.a, device._ptr(out), device._stream()))
+        return out if isinstance(x, torch.Tensor) else out.cpu().numpy()
+
+    def numpy(self, x):
+        """Pure-numpy evaluation (CPU baseline / oracle runs / tests)."""
+        x = self.low + (self.high - self.low) * np.atleast_2d(x)
+        return -np.sum(self.a * (x[:, 1:] - x[:, :-1]**2)**2 +
+                       (1.0 - x[:, :-1])**2, axis=1)
+
+
+class FunnelLikelihood:
+    """Neal's funnel in n_dim dimensions on the unit cube (BASELINE config 5;
+    the reference's tests/test_sampler.py:311-314 has the 2-D case):
+    x_0 ~ N(mu, sigma0^2), x_i ~ N(mu, (exp(k (x_0 - mu)) / c)^2) for i > 0 --
+    ``nb_loglike_funnel``."""
+
+    device = True
+
+    def __init__(self, n_dim, mu=0.5, sigma0=0.1, k=20.0, c=100.0):
+        self.n_dim = int(n_dim)
+        self.mu, self.sigma0 = float(mu), float(sigma0)
+        self.k, self.c = float(k), float(c)
+
+    def __call__(self, x):
+        from . import _lib
+        lib = _lib.load()
+        xs = device.as_device_points(x, self.n_dim)
+        out = torch.empty(xs.shape[0], dtype=torch.float64, device='cuda')
+        _lib.check(lib.nb_loglike_funnel(
+            device._ptr(xs), xs.shape[0], self.n_dim, self.mu, self.sigma0,
+            self.k, self.c, device._ptr(out), device._stream()))
+        return out if isinstance(x, torch.Tensor) else out.cpu().numpy()
+
+    def numpy(self, x):
+        from scipy.stats import norm
+        x = np.atleast_2d(x)
+        s = np.exp(self.k * (x[:, 0] - self.mu)) / self.c
+        return (norm.logpdf(x[:, 0], loc=self.mu, scale=self.sigma0) +
+                np.sum(norm.logpdf(x[:, 1:], loc=self.mu,
+                                   scale=s[:, None]), axis=1))

@@ -7,16 +7,26 @@ counters" (nautilus/bounds/nautilus.py:223-237).
 The MI355X version of it:
 
 * every rank holds the (tiny) bound parameters and the full sampler state;
-* a batch of ``n_batch`` shell points is split into ``n_batch / world`` per
-  rank; each rank draws its share from its own Philox stream (key mixed with
-  the rank) and evaluates the likelihood for it;
+* every batch of ``n_batch`` shell points -- in the exploration phase, in the
+  pre-fill of a new bound (sampler.py:1032) and in the sampling phase -- is
+  split into ``n_batch / world`` per rank; each rank draws its share from its
+  own Philox stream (key mixed with the rank) and evaluates the likelihood
+  for it;
 * ONE ``all_gather`` per batch moves the accepted points (+ their log L) to
   every rank -- equal counts, so no padding -- and one ``all_reduce`` adds the
   integer counters (``n_bound`` and the four MC-volume counters) that the
-  evidence depends on (sampler.py:1133, nautilus.py:232-237).
+  evidence depends on (sampler.py:1133, nautilus.py:232-237).  A batch that
+  pairs fresh points with transfer candidates (sampler.py:803-819) gathers
+  the points first, runs the (replicated, host-RNG) pairing on the gathered
+  batch and gathers the likelihoods afterwards;
+* the networks of an emulator ensemble are dealt out over the ranks
+  (reference neural.py:93-96 maps them over its pool); one ``all_reduce`` of
+  the zero-padded weight blobs brings every network to every rank, bit for
+  bit what a single rank would have trained.
 
-There is no collective inside the kernels; bound construction is replicated
-(identical seeds give identical bounds on every rank).
+There is no collective inside the kernels; the geometric part of the bound
+construction (MVEE, mixture fit) is replicated: identical seeds give
+identical bounds on every rank.
 """
 
 import torch
@@ -83,6 +93,26 @@ class ShardedComm:
         if not torch.equal(lo, hi):
             raise RuntimeError('replicated %s diverged between ranks: %s vs %s'
                                % (what, lo.tolist(), hi.tolist()))
+
+    def sum_rows(self, rows):
+        """Element-wise sum of equally shaped float tensors over all ranks
+        (used with disjoint non-zero rows: x + 0 = x exactly, so the result is
+        a bit-exact gather of what the owners wrote)."""
+        if rows.is_cuda and dist.get_backend(self.group) == 'gloo':
+            host = rows.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            return host.to(rows.device)
+        out = rows.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def any_flag(self, flag):
+        """True on every rank if ``flag`` is true on any (collective stop /
+        continue decisions: wall-clock limits differ between ranks)."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int64,
+                         device=self._dev('cuda'))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.cpu()[0]))
 
     def barrier(self):
         dist.barrier(group=self.group)

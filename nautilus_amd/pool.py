@@ -1,53 +1,79 @@
 """Worker pools for host-side likelihoods.
 
-``NautilusPool`` keeps the interface of ``nautilus.pool.NautilusPool``
-(reference nautilus/pool.py:36-107): ``map(func, iterable)`` and ``size``
-over a ``multiprocessing.Pool``, a dask ``Client``, an MPI executor or
-anything with ``.map``.  On the MI355X path the proposal / bound work never
-goes through a pool (it is one kernel launch spread over the whole GPU); a
-pool is only used to evaluate *host* likelihood functions, exactly at the
-reference's call site C1 (sampler.py:863-873).
+On the MI355X path proposals and bound tests never go through a pool (one
+launch covers the whole GPU); a pool only serves *host* likelihood callables,
+at the reference's call site C1 (nautilus/sampler.py:863-873).
+``NautilusPool`` offers what the sampler needs from any pool flavour --
+``map(func, iterable)`` returning a list and ``size`` -- like
+``nautilus.pool.NautilusPool`` (reference nautilus/pool.py:36-107).
 """
 
-from multiprocessing import Pool
+import multiprocessing
+import numbers
 
-_LIKELIHOOD = None
+# attribute that holds the worker count, by pool flavour: multiprocessing.Pool,
+# concurrent.futures executors, mpi4py / schwimmbad pools, ...
+_SIZE_ATTRIBUTES = ('_processes', '_max_workers', 'size', 'nt')
+
+_worker_likelihood = None
 
 
-def initialize_worker(likelihood):
-    """Cache the likelihood in the worker process (pool.py:6-16)."""
-    global _LIKELIHOOD
-    _LIKELIHOOD = likelihood
+def _install_likelihood(likelihood):
+    global _worker_likelihood
+    _worker_likelihood = likelihood
 
 
 def likelihood_worker(*args):
-    """Evaluate the cached likelihood (pool.py:19-33)."""
-    return _LIKELIHOOD(*args)
+    """Runs in a worker of an integer-sized pool: the likelihood was shipped
+    once when the worker started, only the points travel per call."""
+    return _worker_likelihood(*args)
+
+
+def _start_method():
+    """Workers are forked (closures and interactively defined likelihoods
+    work, as with the reference's default pool) unless this process has
+    already initialised the HIP runtime: a forked child would inherit an
+    unusable GPU context, so a fork server is used then and the likelihood
+    has to be picklable."""
+    try:
+        import torch
+        if torch.cuda.is_initialized():
+            return 'forkserver'
+    except ImportError:
+        pass
+    return 'fork'
 
 
 class NautilusPool:
-    """Uniform ``map`` / ``size`` over different pool flavours."""
+    """``map`` / ``size`` over an integer (a new ``multiprocessing`` pool), a
+    ``multiprocessing.Pool``, an executor, a dask client or anything else
+    with ``map``."""
 
     def __init__(self, pool, likelihood=None):
-        if isinstance(pool, int):
-            self.pool = Pool(pool, initializer=initialize_worker,
-                             initargs=(likelihood, ))
+        if isinstance(pool, numbers.Integral) and not isinstance(pool, bool):
+            context = multiprocessing.get_context(_start_method())
+            self.pool = context.Pool(int(pool), initializer=_install_likelihood,
+                                     initargs=(likelihood, ))
         else:
             self.pool = pool
 
     def _is_dask(self):
-        return 'distributed.client.Client' in str(type(self.pool))
+        # a dask.distributed client returns futures from map() and knows its
+        # workers through nthreads()
+        return hasattr(self.pool, 'gather') and hasattr(self.pool, 'nthreads')
 
     def map(self, func, iterable):
+        result = self.pool.map(func, iterable)
         if self._is_dask():
-            return list(self.pool.gather(self.pool.map(func, iterable)))
-        return list(self.pool.map(func, iterable))
+            result = self.pool.gather(result)
+        return list(result)
 
     @property
     def size(self):
         if self._is_dask():
             return len(self.pool.nthreads())
-        for attr in ('_processes', '_max_workers', 'size', 'nt'):
-            if hasattr(self.pool, attr):
-                return getattr(self.pool, attr)
+        for name in _SIZE_ATTRIBUTES:
+            value = getattr(self.pool, name, None)
+            if value is not None:
+                return value
         raise ValueError('Cannot determine size of pool.')

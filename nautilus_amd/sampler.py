@@ -91,8 +91,9 @@ class Sampler:
             io.h5py()          # ImportError now rather than at the first write
 
         self._device_likelihood = bool(getattr(likelihood, 'device', False))
-        self._prior_is_identity = getattr(prior, '__name__', '') == \
-            'unit_prior'
+        from .likelihoods import unit_prior
+        self._prior_is_identity = (prior is unit_prior or
+                                   getattr(prior, 'identity', False) is True)
         if self._device_likelihood and not getattr(prior, 'device', False):
             raise ValueError(
                 'a device likelihood needs a prior transform that works on '
@@ -177,7 +178,6 @@ class Sampler:
         self.shell_t = np.zeros(0, dtype=int)
         self.log_l_t = np.zeros(0)
         self.comm = comm         # parallel.ShardedComm or None
-        self._sharded = False    # per-rank Philox keys active
         self._later = {}         # cache: shell index -> DeviceBoundList
         self.timing = dict(add_bound=0.0, sample_shell=0.0, likelihood=0.0,
                            bookkeeping=0.0)
@@ -332,8 +332,16 @@ class Sampler:
             return bool(self.explored and np.all(self.shell_n >= n_shell) and
                         self.n_eff >= n_eff)
 
+        def out_of_time():
+            late = time() - t0 >= timeout
+            # wall clocks differ between the ranks of a sharded run; the
+            # decision to enter another (collective) batch must not
+            if self.comm is not None and timeout < np.inf:
+                late = self.comm.any_flag(late)
+            return late
+
         done = finished()
-        while self.n_like < n_like_max and time() - t0 < timeout and not done:
+        while self.n_like < n_like_max and not done and not out_of_time():
             if not self.explored:
                 if ((self.n_update_iter >= self.n_update or
                      self.n_like_iter >= self.n_like_new_bound) and
@@ -341,33 +349,38 @@ class Sampler:
                     self.add_bound(verbose=verbose)
                     self.n_update_iter = 0
                     self.n_like_iter = 0
-                    if self.filepath is not None:
+                    if self._writes_checkpoints():
                         self.write(self.filepath, overwrite=True)
                 self.n_update_iter += self.add_samples(-1, verbose=verbose)
                 self.n_like_iter += self.n_batch
-                if self.filepath is not None:
+                if self._writes_checkpoints():
                     # the complete file after the first batch (:449-453)
                     if self.n_like == self.n_batch:
                         self.write(self.filepath, overwrite=True)
                     self.write_shell_update(self.filepath, -1)
                 if self.f_live <= f_live:
                     self._finish_exploration(discard_exploration)
-                    if self.filepath is not None:
+                    if self._writes_checkpoints():
                         self.write(self.filepath, overwrite=True)
             elif np.any(self.shell_n < n_shell):
                 shell = int(np.flatnonzero(self.shell_n < n_shell)[0])
                 self.add_samples(shell, verbose=verbose)
-                if self.filepath is not None:
+                if self._writes_checkpoints():
                     self.write_shell_update(self.filepath, shell)
             elif self.n_eff < n_eff:
                 shell = self._next_shell()
                 self.add_samples(shell, verbose=verbose)
-                if self.filepath is not None:
+                if self._writes_checkpoints():
                     self.write_shell_update(self.filepath, shell)
             done = finished()
         if verbose:
             self.print_status('Finished' if done else 'Stopped')
         return done
+
+    def _writes_checkpoints(self):
+        """Every rank of a sharded run holds the same state; rank 0 writes."""
+        return self.filepath is not None and (self.comm is None or
+                                              self.comm.rank == 0)
 
     def _next_shell(self):
         """Shell with the largest expected gain (sampler.py:489-491)."""
@@ -468,22 +481,7 @@ class Sampler:
                 n_bound += n_req
 
             if transfer and x.shape[0] > 0:
-                # pair fresh points with stored candidates of the same
-                # earlier shell (sampler.py:803-819)
-                shell_p = self.shell_association(
-                    x, n_max=len(self.bounds) - 1)
-                swap = np.zeros(x.shape[0], dtype=bool)
-                for s in range(len(self.bounds) - 1):
-                    cand = np.flatnonzero(shell_t == s)
-                    fresh = np.flatnonzero(shell_p == s)
-                    m = min(len(cand), len(fresh))
-                    if m > 0:
-                        idx_t = np.append(idx_t, self.rng.choice(
-                            cand, size=m, replace=False))
-                        shell_t[idx_t] = -1
-                        swap[self.rng.choice(fresh, size=m,
-                                             replace=False)] = True
-                x = x[torch.from_numpy(~swap).cuda()]
+                x, idx_t = self._pair_with_candidates(x, shell_t, idx_t)
             if x.shape[0] > 0:
                 chunks.append(x)
                 have += x.shape[0]
@@ -492,6 +490,24 @@ class Sampler:
         if shell_t is None:
             return pts, n_bound
         return pts, n_bound, idx_t
+
+    def _pair_with_candidates(self, x, shell_t, idx_t):
+        """Pair fresh points of the newest shell with stored candidates of
+        the same earlier shell (sampler.py:803-819): the candidates move into
+        the new shell, the paired fresh points are dropped.  Host RNG; in a
+        sharded run every rank does this on the same gathered points."""
+        shell_p = self.shell_association(x, n_max=len(self.bounds) - 1)
+        swap = np.zeros(x.shape[0], dtype=bool)
+        for s in range(len(self.bounds) - 1):
+            cand = np.flatnonzero(shell_t == s)
+            fresh = np.flatnonzero(shell_p == s)
+            m = min(len(cand), len(fresh))
+            if m > 0:
+                idx_t = np.append(idx_t, self.rng.choice(
+                    cand, size=m, replace=False))
+                shell_t[idx_t] = -1
+                swap[self.rng.choice(fresh, size=m, replace=False)] = True
+        return x[torch.from_numpy(~swap).cuda()], idx_t
 
     def evaluate_likelihood(self, points):
         """sampler.py:832-908.  ``points`` is a cuda tensor (n, n_dim);
@@ -588,7 +604,10 @@ class Sampler:
         log_l = None
         blobs = None
         if shell == -1 and len(self.shell_t) > 0:
-            pts, n_bound, idx_t = self.sample_shell(-1, self.shell_t)
+            if self.comm is not None:
+                pts, n_bound, idx_t = self._sharded_transfer_batch()
+            else:
+                pts, n_bound, idx_t = self.sample_shell(-1, self.shell_t)
             assert pts.shape[0] + len(idx_t) == n_bound
             if len(idx_t) > 0:
                 sel = torch.from_numpy(idx_t).cuda()
@@ -600,14 +619,17 @@ class Sampler:
                 if self.blobs is not None:
                     self.blobs[-1] = np.concatenate(
                         (self.blobs[-1], self.blobs_t[idx_t]))
-        elif self.comm is not None and self.explored:
+        elif self.comm is not None:
             pts, log_l, log_l_dev, n_bound = self._sharded_batch(shell)
         else:
             pts, n_bound = self.sample_shell(shell)
         t1 = time()
         self.shell_n_sample[shell] += n_bound
         if log_l is None:
-            log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
+            if self.comm is not None and not self._device_likelihood:
+                log_l, log_l_dev = self._sharded_likelihood(pts)
+            else:
+                log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
         t2 = time()
         self._pts[shell].append(pts)
         self._ll_dev[shell].append(log_l_dev)
@@ -625,25 +647,52 @@ class Sampler:
         self.timing['bookkeeping'] += t3 - t2
         return int(np.sum(log_l >= self.shell_log_l_min[shell]))
 
-    def _sharded_batch(self, shell):
-        """One batch of the sampling phase spread over all ranks
-        (parallel.py): local draw + likelihood, one all-gather of the
-        accepted points, one all-reduce of the integer counters."""
-        from . import parallel
-        comm = self.comm
-        if not self._sharded:
-            # from here on every rank draws from its own Philox stream
-            for b in self.bounds:
-                b._stream.seed = parallel.rank_key(b._stream.seed, comm.rank)
-                if hasattr(b, '_queue'):
-                    b._queue().clear()
-            self._sharded = True
-        bound = self.bounds[shell]
-        counters = ['n_sample', 'n_reject']
+    # -- multi-GPU (parallel.py): every batch of every phase is sharded ----
+    @staticmethod
+    def _counter_owners(bound):
         owners = [bound] + ([bound.outer_bound]
                             if hasattr(bound, 'outer_bound') else [])
-        owners = [o for o in owners if hasattr(o, 'n_sample')]
-        before = [getattr(o, c) for o in owners for c in counters]
+        return [o for o in owners if hasattr(o, 'n_sample')]
+
+    def _counters(self, bound):
+        return [getattr(o, c) for o in self._counter_owners(bound)
+                for c in ('n_sample', 'n_reject')]
+
+    def _rank_keyed(self, bound):
+        """From its first sharded draw on, rank r takes the proposals of
+        ``bound`` from its own Philox stream."""
+        if not getattr(bound, '_is_rank_keyed', False):
+            from . import parallel
+            bound._stream.seed = parallel.rank_key(bound._stream.seed,
+                                                   self.comm.rank)
+            if hasattr(bound, '_queue'):
+                bound._queue().clear()
+            bound._is_rank_keyed = True
+        return bound
+
+    def _sum_counters(self, bound, before, extra=()):
+        """The MC-volume counters of ``bound`` advance by the sum of what all
+        ranks drew since ``before`` (nautilus.py:232-237); ``extra`` ints are
+        summed along.  Returns the summed extras."""
+        after = self._counters(bound)
+        delta = [a - b for a, b in zip(after, before)]
+        n_extra = len(extra)
+        totals = self.comm.sum_ints(list(extra) + delta, 'cuda')
+        k = 0
+        for o in self._counter_owners(bound):
+            for c in ('n_sample', 'n_reject'):
+                setattr(o, c, before[k] + totals[n_extra + k])
+                k += 1
+        return totals[:n_extra]
+
+    def _sharded_batch(self, shell):
+        """One batch spread over all ranks: local draw + likelihood, ONE
+        all-gather of the accepted points with their log L, one all-reduce
+        of the integer counters."""
+        from . import parallel
+        comm = self.comm
+        bound = self._rank_keyed(self.bounds[shell])
+        before = self._counters(bound)
         n_local = parallel.split_batch(self.n_batch, comm.world)
         pts, n_bound = self.sample_shell(shell, n_target=n_local)
         n_like0 = self.n_like
@@ -652,17 +701,57 @@ class Sampler:
             raise NotImplementedError(
                 'blobs are not exchanged between ranks of a sharded run')
         self.n_like = n_like0
-        after = [getattr(o, c) for o in owners for c in counters]
-        delta = [a - b for a, b in zip(after, before)]
-        pts, ll_dev, totals = parallel.shard_shell_batch(
-            comm, pts, ll_dev, [n_bound] + delta)
+        packed = torch.cat([pts, ll_dev[:, None]], dim=1)
+        gathered = comm.gather_rows(packed)
+        n_bound, = self._sum_counters(bound, before, [n_bound])
+        pts = gathered[:, :-1].contiguous()
+        ll_dev = gathered[:, -1].contiguous()
         self.n_like += pts.shape[0]
-        k = 0
-        for o in owners:
-            for c in counters:
-                setattr(o, c, before[k] + totals[1 + k])
-                k += 1
-        return pts, ll_dev.cpu().numpy(), ll_dev, totals[0]
+        return pts, ll_dev.cpu().numpy(), ll_dev, n_bound
+
+    def _sharded_transfer_batch(self):
+        """A batch of the newest shell while transfer candidates are waiting
+        (sampler.py:790-823): the ranks draw their shares, the points are
+        gathered, and the pairing with the candidates -- host RNG, identical
+        on every rank -- runs on the gathered batch."""
+        comm = self.comm
+        bound = self._rank_keyed(self.bounds[-1])
+        before = self._counters(bound)
+        have, n_bound = 0, 0
+        chunks = []
+        idx_t = np.zeros(0, dtype=int)
+        while have < self.n_batch:
+            need = self.n_batch - have
+            x = bound.sample_device(-(-need // comm.world))
+            x = comm.gather_rows(x)[:need]   # newest bound: all in its shell
+            n_bound += need
+            if len(self.shell_t) > 0:
+                x, idx_t = self._pair_with_candidates(x, self.shell_t, idx_t)
+            if x.shape[0] > 0:
+                chunks.append(x)
+                have += x.shape[0]
+        self._sum_counters(bound, before)
+        pts = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+        return pts, n_bound, idx_t
+
+    def _sharded_likelihood(self, pts):
+        """Host likelihood of a batch every rank holds: rank r evaluates rows
+        r, r + world, ... and one all-gather returns all values."""
+        comm = self.comm
+        n = pts.shape[0]
+        per = -(-n // comm.world)
+        mine = pts[comm.rank::comm.world]
+        n_like0 = self.n_like
+        ll, _, blobs = self.evaluate_likelihood(mine)
+        if blobs is not None:
+            raise NotImplementedError(
+                'blobs are not exchanged between ranks of a sharded run')
+        self.n_like = n_like0 + n
+        padded = torch.zeros(per, dtype=torch.float64, device='cuda')
+        padded[:len(ll)] = torch.from_numpy(ll).cuda()
+        table = comm.gather_rows(padded[:, None]).reshape(comm.world, per)
+        ll_dev = table.t().reshape(-1)[:n].contiguous()
+        return ll_dev.cpu().numpy(), ll_dev
 
     # ------------------------------------------------------------------
     # bounds
@@ -701,8 +790,16 @@ class Sampler:
                         periodic=self.periodic,
                         n_networks=self.n_networks,
                         neural_network_kwargs=self.neural_network_kwargs,
-                        pool=self.pool_s, rng=self.rng)
-                    bound.sample(1000, return_points=False)
+                        pool=self.pool_s, rng=self.rng, comm=self.comm)
+                    if self.comm is None:
+                        bound.sample(1000, return_points=False)
+                    else:
+                        # the pre-fill behind the first volume estimate
+                        # (sampler.py:1032), a share per rank
+                        before = self._counters(self._rank_keyed(bound))
+                        bound.sample(-(-1000 // self.comm.world),
+                                     return_points=False)
+                        self._sum_counters(bound, before)
                 for key, val in bound.timing.items():
                     self.timing[key] = self.timing.get(key, 0.0) + val
                 ok = bool(bound.log_v < self.bounds[-1].log_v)

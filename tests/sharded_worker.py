@@ -1,0 +1,67 @@
+"""Worker of the sharded-run tests: one rank of a whole ``Sampler.run()`` with
+every batch of every phase (exploration, pre-fill of new bounds, sampling) and
+the emulator ensembles spread over the ranks.  Launched by
+``torch.distributed.run``; rank 0 prints one JSON line."""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def host_like(x):
+    # normalised 4-D Gaussian: analytic log Z = 0
+    return (-0.5 * np.sum(((x - 0.5) / 0.1)**2, axis=-1) -
+            x.shape[-1] * np.log(0.1 * np.sqrt(2 * np.pi)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--host-likelihood', action='store_true')
+    ap.add_argument('--n-networks', type=int, default=2)
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    os.environ.setdefault('NB_TRAIN_TWO_LAUNCH', '1')   # ranks share one GPU
+    dist.init_process_group('gloo')
+    from nautilus_amd import GaussianLikelihood, Sampler, unit_prior
+    from nautilus_amd.parallel import ShardedComm
+    comm = ShardedComm()
+    d = 4
+    if args.host_likelihood:
+        prior, like = (lambda u: u), host_like
+    else:
+        prior, like = unit_prior, GaussianLikelihood(np.full(d, 0.5),
+                                                     np.eye(d) * 0.01)
+    s = Sampler(prior, like, n_dim=d, n_live=400, n_networks=args.n_networks,
+                vectorized=True, seed=args.seed, n_batch=400,
+                comm=comm)
+    ok = s.run(n_eff=3000, discard_exploration=True, timeout=500)
+    # every rank must hold the same state
+    state = np.concatenate([s.shell_n_sample, s.shell_n, [s.n_like],
+                            np.concatenate(s.log_l)])
+    digest = hashlib.sha1(np.ascontiguousarray(state).tobytes()).hexdigest()
+    comm.assert_identical([float(int(digest[:12], 16)), s.log_z, s.n_eff],
+                          'cuda', 'sampler state')
+    if comm.rank == 0:
+        nets = [n for b in s.bounds[1:] for nbd in b.neural_bounds
+                if nbd.emulator is not None
+                for n in nbd.emulator.neural_networks]
+        print(json.dumps(dict(
+            ok=bool(ok), world=comm.world, log_z=float(s.log_z),
+            n_eff=float(s.n_eff), n_like=int(s.n_like),
+            n_bounds=len(s.bounds),
+            shell_n_sample=[int(v) for v in s.shell_n_sample],
+            shell_n=[int(v) for v in s.shell_n],
+            n_networks=len(nets))), flush=True)
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -733,3 +733,49 @@ def test_emulator_full_training_quality(dev):
     # early epochs of network 0 follow sklearn's own loss curve
     assert np.allclose(emu.neural_networks[0].loss_curve_[:5],
                        g['loss_curve_0'][:5], rtol=1e-6)
+
+
+def test_benchmark_likelihoods_match_numpy(dev):
+    """nb_loglike_rosenbrock / nb_loglike_funnel (BASELINE configs C3 / C5;
+    the funnel is the D-dimensional form of the reference's
+    tests/test_sampler.py:311-314) against numpy / scipy on 10^5 points, and
+    the Gaussian / mixture likelihoods of C1, C2, C4 against scipy."""
+    from scipy.stats import multivariate_normal, norm
+    from nautilus_amd import (FunnelLikelihood, GaussianLikelihood,
+                              GaussianMixtureLikelihood, RosenbrockLikelihood)
+    rng = np.random.default_rng(0)
+    for d in (2, 3, 30, 100, 128):
+        u = rng.random((100000 if d <= 30 else 20000, d))
+        ros = RosenbrockLikelihood(d)
+        x = 10 * u - 5
+        want = -np.sum(100 * (x[:, 1:] - x[:, :-1]**2)**2 +
+                       (1 - x[:, :-1])**2, axis=1)
+        got = ros(torch.from_numpy(u).cuda()).cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-12, atol=0)   # fma contraction
+        assert np.allclose(ros.numpy(u), want, rtol=1e-13)
+        assert np.array_equal(ros(u), got)          # numpy in -> numpy out
+        fun = FunnelLikelihood(d)
+        s = np.exp(20 * (u[:, 0] - 0.5)) / 100
+        want = norm.logpdf(u[:, 0], 0.5, 0.1) + np.sum(
+            norm.logpdf(u[:, 1:], 0.5, s[:, None]), axis=1)
+        got = fun(torch.from_numpy(u).cuda()).cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+        assert np.allclose(fun.numpy(u), want, rtol=1e-12, atol=1e-9)
+    # empty batch
+    assert RosenbrockLikelihood(4)(torch.empty((0, 4), dtype=torch.float64,
+                                               device='cuda')).shape == (0,)
+    d = 20
+    cov = 0.05**2 * (0.5 * np.ones((d, d)) + 0.5 * np.eye(d))
+    u = rng.random((50000, d)) * 0.2 + 0.4
+    g = GaussianLikelihood(np.full(d, 0.5), cov)
+    want = multivariate_normal(np.full(d, 0.5), cov).logpdf(u)
+    assert np.allclose(g(torch.from_numpy(u).cuda()).cpu().numpy(), want,
+                       rtol=1e-11, atol=1e-9)
+    means = 0.25 + 0.5 * np.random.default_rng(3).random((4, 50))
+    mix = GaussianMixtureLikelihood(means, 0.02)
+    u = means[rng.integers(0, 4, 20000)] + 0.02 * rng.normal(size=(20000, 50))
+    from scipy.special import logsumexp
+    want = logsumexp([multivariate_normal(m, 0.02**2 * np.eye(50)).logpdf(u)
+                      for m in means], axis=0) - np.log(4)
+    assert np.allclose(mix(torch.from_numpy(u).cuda()).cpu().numpy(), want,
+                       rtol=1e-11, atol=1e-8)

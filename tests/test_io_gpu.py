@@ -71,6 +71,38 @@ def test_bounds_round_trip(name, sync):
         assert b.log_v == r.log_v
 
 
+def test_periodic_bound_is_stored_in_the_reference_frame():
+    """bounds/nautilus.py:239-243: the reference keeps the queued points of a
+    NautilusBound in the SHIFTED frame and undoes the shift when it hands
+    them out; the file must hold that frame, whatever the device queue
+    holds, and a file written by the reference (no amd_* entries) must come
+    back in the sampler frame."""
+    import nautilus_amd.bounds as nb
+    rng = np.random.default_rng(0)
+    pts = np.random.default_rng(3).random((1500, 2))
+    pts[:, 0] = (0.95 + 0.04 * np.random.default_rng(4).normal(size=1500)) % 1
+    log_l = -((pts[:, 0] - 0.95 + 0.5) % 1 - 0.5)**2 - (pts[:, 1] - 0.5)**2
+    b = nb.NautilusBound.compute(pts, log_l, np.median(log_l), np.log(0.5),
+                                 n_networks=0, periodic=np.arange(1), rng=rng)
+    assert b.shift is not None
+    b.sample(10)
+    queue = b.points
+    assert len(queue) > 0
+    group = fake_h5py.Group()
+    b.write(group)
+    stored = np.array(group['points'])
+    assert np.array_equal(stored, b.shift.transform(queue))
+    # the stored rows are inside the (shifted-frame) envelope, as in the
+    # reference, where contains() of the outer bound sees shifted points
+    assert np.all(b.outer_bound.contains(stored))
+    # a reference file: no implementation-specific entries
+    del group.items_['amd_points']
+    group.attrs.pop('amd_philox_seed', None)
+    r = nb.NautilusBound.read(group, rng=np.random.default_rng(1))
+    assert np.allclose(r.points, queue, rtol=0, atol=1e-15)
+    assert np.all(r.contains(r.points))
+
+
 def _flat(x):
     return -np.linalg.norm(x - 0.5) * 0.001
 

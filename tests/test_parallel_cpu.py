@@ -41,6 +41,19 @@ def _worker(rank, world, port, out_dir):
         comm.assert_identical([float(rank)], 'cpu')
     with pytest.raises(ValueError):
         parallel.split_batch(7, world)
+    # zero-padded rows summed over the ranks = bit-exact gather (the weight
+    # exchange of the sharded ensemble training)
+    blob = torch.zeros((4, 5), dtype=torch.float64)
+    mine = [g for g in range(4) if g % world == rank]
+    for g in mine:
+        blob[g] = torch.from_numpy(np.random.default_rng(g).normal(size=5))
+    total = comm.sum_rows(blob)
+    for g in range(4):
+        assert np.array_equal(total[g].numpy(),
+                              np.random.default_rng(g).normal(size=5))
+    # collective stop decision: true everywhere if true anywhere
+    assert comm.any_flag(rank == 1) is True
+    assert comm.any_flag(False) is False
     comm.barrier()
     np.save(os.path.join(out_dir, 'rows_%d.npy' % rank), all_rows.numpy())
     dist.destroy_process_group()
@@ -62,3 +75,19 @@ def test_rank_keys_are_distinct():
     assert len(keys) == 8
     assert parallel.rank_key(987654321, 0) == 987654321
     assert all(0 <= k < 2**63 for k in keys)
+
+
+def test_network_weight_rows_round_trip():
+    """The rows exchanged by ``train_ensembles_sharded`` hold a network
+    completely (host logic, no GPU)."""
+    from nautilus_amd import emulator
+    rs = np.random.RandomState(3)
+    coefs, intercepts = emulator._glorot(7, rs)
+    net = emulator.Network(coefs, intercepts, 41, [0.5, 0.25, 0.125])
+    row = emulator._pack_network(net, 7)
+    assert row.shape == (2 + sum(c.size for c in coefs) +
+                         sum(b.size for b in intercepts),)
+    back = emulator._unpack_network(row, 7)
+    assert back.n_iter_ == 41 and back.loss_curve_ == [0.125]
+    for a, b in zip(coefs + intercepts, back.coefs_ + back.intercepts_):
+        assert np.array_equal(a, b)

@@ -247,6 +247,49 @@ def test_two_rank_sharded_run_on_one_gpu():
     assert res['value'] > 0
 
 
+def _run_sharded(world, *extra):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(29300 + (os.getpid() + 7 * world) % 300),
+           os.path.join(ROOT, 'tests', 'sharded_worker.py'), *extra]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize('extra', [(), ('--host-likelihood',)])
+def test_whole_run_sharded_over_two_ranks(extra):
+    """SURVEY section 8e / reference nautilus.py:223-237, neural.py:93-96: a
+    whole Sampler.run() with EVERY batch (exploration incl. the transfer
+    pairing, the pre-fill of new bounds, sampling) and the emulator networks
+    spread over two ranks (two processes on cuda:0, gloo; the worker asserts
+    that both ranks end in the identical state).  Against the same run on
+    one rank: same problem, same seed, different proposal streams -- the
+    evidence agrees within the Monte-Carlo error, the number of bounds and
+    the per-shell in-bound fractions statistically."""
+    one = _run_sharded(1, *extra)
+    two = _run_sharded(2, *extra)
+    assert one['ok'] and two['ok'] and two['world'] == 2
+    for res in (one, two):
+        assert abs(res['log_z']) < 0.05          # analytic log Z = 0
+        assert res['n_eff'] >= 3000
+        assert res['n_networks'] == 2 * (res['n_bounds'] - 1)
+    assert abs(one['log_z'] - two['log_z']) < 0.06
+    assert abs(one['n_bounds'] - two['n_bounds']) <= 2
+    # shell_n_sample / shell_n = 1 / (fraction of the bound in its shell):
+    # a property of the bounds, not of the number of ranks
+    k = min(one['n_bounds'], two['n_bounds']) - 1
+    f1 = np.array(one['shell_n'][:k]) / np.array(one['shell_n_sample'][:k])
+    f2 = np.array(two['shell_n'][:k]) / np.array(two['shell_n_sample'][:k])
+    assert np.all(np.abs(f1 - f2) < 0.15)
+
+
 def test_multimodal_mixture_evidence_and_mode_weights():
     """BASELINE config 4 in small: equal-weight isotropic mixture.  Exercises
     the multi-ellipsoid Union (K > 1 members, overlap-corrected draw) and
