@@ -15,10 +15,20 @@ growth of the effective sample size over the K timed steps divided by the
 time (max over ranks).  With N GPUs every step fills N x n_batch points
 (weak scaling): each rank draws its share, one RCCL all-gather per step.
 
+``value`` is the rate of the hot loop (sampling-phase steps);
+``value_full_run`` is SURVEY.md section 8d's end-to-end figure, n_eff divided
+by the whole wall time including the exploration phase that builds the bounds
+(emulator training, MVEE, mixture fits) -- with N GPUs the exploration is
+sharded too (every batch and the emulator networks are dealt out over the
+ranks).
+
 Extra objects on the JSON line: ``roofline`` (dominant kernel of the timed
-region, HIP-event timed), ``roofline_contains`` (the north star's streaming
-Ellipsoid.contains kernel), ``cpu_baseline`` (the CPU oracle continuing the
-same sampler state on one host core for a bounded time).
+region, HIP-event timed; ``traffic`` is measured only with ``--pmc-traffic``,
+which re-runs this command under ``rocprofv3 --pmc`` in child processes),
+``roofline_contains`` (the north star's streaming Ellipsoid.contains kernel),
+``cpu_baseline`` (the CPU oracle continuing the same sampler state through
+the reference's multiprocess-pool path on all host cores, and on one core,
+for a bounded time).
 """
 
 import argparse
@@ -51,7 +61,16 @@ def parse():
                         'shell receives its first batch (untimed setup)')
     p.add_argument('--n-networks', type=int, default=4)
     p.add_argument('--seed', type=int, default=0)
-    p.add_argument('--cpu-seconds', type=float, default=20.0)
+    p.add_argument('--cpu-seconds', type=float, default=14.0,
+                   help='wall time of the pooled CPU baseline leg (the '
+                        'single-core leg gets half of it)')
+    p.add_argument('--cpu-cores', type=int, default=0,
+                   help='workers of the pooled CPU baseline (0 = all host '
+                        'cores)')
+    p.add_argument('--pmc-traffic', action='store_true',
+                   help='measure roofline.traffic: re-run this command under '
+                        'rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in '
+                        'separate child passes; adds two full runs)')
     p.add_argument('--explore-timeout', type=float, default=1500.0)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--host-likelihood', action='store_true',
@@ -67,12 +86,59 @@ def parse():
     p.add_argument('--force-comm', action='store_true',
                    help='functional test: run the collective code path even '
                         'with a single rank')
-    p.add_argument('--broadcast-state', action='store_true',
-                   help='build the bounds on rank 0 only and broadcast the '
-                        'sampler (default: every rank repeats the '
-                        'deterministic exploration; the broadcast is also the '
-                        'automatic fallback if the replicas disagree)')
     return p.parse_args()
+
+
+class NumpyGaussian:
+    """Isotropic Gaussian log-density in plain numpy (picklable: the pooled
+    CPU baseline ships it to its workers)."""
+
+    def __init__(self, mean, sigma):
+        self.mean, self.sigma = np.asarray(mean, float), float(sigma)
+
+    def __call__(self, x):
+        x = np.atleast_2d(x)
+        d = x.shape[1]
+        return (-0.5 * np.sum(((x - self.mean) / self.sigma)**2, axis=1) -
+                d * np.log(self.sigma * np.sqrt(2 * np.pi)))
+
+
+_THREAD_VARS = ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')
+
+
+class _OraclePool:
+    """``map`` / ``size`` over a multiprocessing pool (what the reference's
+    NautilusPool offers, pool.py:65-107).  Fork server: this process has
+    initialised the HIP runtime."""
+
+    def __init__(self, n_workers):
+        import multiprocessing
+        self.size = n_workers
+        # one BLAS / OpenMP thread per worker, as the reference's CI and docs
+        # prescribe for pools (the fork server inherits the environment)
+        saved = {k: os.environ.get(k) for k in _THREAD_VARS}
+        os.environ.update({k: '1' for k in _THREAD_VARS})
+        try:
+            self._pool = multiprocessing.get_context('forkserver').Pool(
+                n_workers)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        self._pool.map(_warm, range(4 * n_workers))      # start the workers
+
+    def map(self, func, iterable):
+        return self._pool.map(func, iterable)
+
+    def close(self):
+        self._pool.terminate()
+
+
+def _warm(i):
+    import oracle.bounds_oracle, oracle.mlp_oracle     # noqa: F401
+    return i
 
 
 def oracle_sampler_from(sampler, like_numpy):
@@ -132,12 +198,12 @@ def oracle_sampler_from(sampler, like_numpy):
     return o
 
 
-def cpu_baseline(sampler, like_numpy, seconds):
-    """ESS/s of the CPU oracle continuing the same state, one core,
-    n_batch = 100 (the reference's default batch)."""
+def _oracle_leg(sampler, like_numpy, seconds, pool, n_batch):
     from threadpoolctl import threadpool_limits
     with threadpool_limits(limits=1):
         o = oracle_sampler_from(sampler, like_numpy)
+        o.pool = pool
+        o.n_batch = n_batch
         for s in range(len(o.log_l)):
             o.update_shell_info(s)
         n0, like0 = o.n_eff, o.n_like
@@ -152,14 +218,111 @@ def cpu_baseline(sampler, like_numpy, seconds):
             steps += 1
         dt = time.time() - t0
         prop1 = sum(b.outer_bound.n_sample for b in o.bounds[1:])
-    return dict(value=(o.n_eff - n0) / dt, unit='effective samples/s',
-                cores=1, kind='port',
-                sample='%d add_samples steps of n_batch=100 on the same '
-                       'explored %d-bound state, %.1f s, oracle/ numpy '
-                       'restatement of the reference' %
-                       (steps, len(o.bounds), dt),
+    return dict(value=(o.n_eff - n0) / dt, steps=steps, seconds=dt,
                 points_per_s=(o.n_like - like0) / dt,
-                proposals_per_s=(prop1 - prop0) / dt)
+                proposals_per_s=(prop1 - prop0) / dt, n_bounds=len(o.bounds))
+
+
+def cpu_baseline(sampler, like_numpy, seconds, cores):
+    """ESS/s of the CPU oracle continuing the same explored state through
+    the reference's multiprocess-pool path (north star: "the reference's own
+    multiprocess-pool CPU path timed on the node's host cores"): bounds
+    replicate themselves over the pool in ``sample`` (bounds/nautilus.py:
+    223-237), the vectorized likelihood gets one chunk per worker
+    (sampler.py:860-873), n_batch = the reference's default for that pool
+    (the smallest multiple of its size >= 100, sampler.py:300-303).  The
+    one-core figure (pool=None, n_batch=100) rides along."""
+    cores = cores or os.cpu_count() or 1
+    single = _oracle_leg(sampler, like_numpy, 0.5 * seconds, None, 100)
+    out = dict(unit='effective samples/s', kind='port',
+               host_cores_available=os.cpu_count(), single_core=dict(
+                   value=single['value'], cores=1,
+                   points_per_s=single['points_per_s'],
+                   proposals_per_s=single['proposals_per_s'],
+                   sample='%d add_samples steps of n_batch=100, pool=None, '
+                          '%.1f s' % (single['steps'], single['seconds'])))
+    if cores == 1:
+        out.update(value=single['value'], cores=1,
+                   sample=out['single_core']['sample'])
+        return out
+    t0 = time.time()
+    pool = _OraclePool(cores)
+    start_s = time.time() - t0
+    try:
+        n_batch = (100 // cores + (100 % cores != 0)) * cores
+        leg = _oracle_leg(sampler, like_numpy, seconds, pool, n_batch)
+    finally:
+        pool.close()
+    out.update(
+        value=leg['value'], cores=cores, points_per_s=leg['points_per_s'],
+        proposals_per_s=leg['proposals_per_s'], pool_start_s=start_s,
+        sample='%d add_samples steps of n_batch=%d on the same explored '
+               '%d-bound state with pool=%d (multiprocessing, fork server), '
+               '%.1f s; oracle/ numpy restatement of the reference' %
+               (leg['steps'], n_batch, leg['n_bounds'], cores,
+                leg['seconds']))
+    return out
+
+
+def pmc_traffic(argv, kernel_substr):
+    """HBM bytes per launch of the kernels whose name contains
+    ``kernel_substr`` over the timed region of this very command: two child
+    runs under ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE need separate
+    passes on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"; FETCH_SIZE
+    counts 64 B per 128-B request of wide loads -> x 2).  Returns a dict or
+    None if the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None
+    totals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix='nb_pmc_', dir='/tmp')
+        # counters in their own passes with the kernel trace only (the guide's
+        # recipe); the timed region's launches are the LAST `roofline.launches`
+        # dispatches of the kernel in the child run
+        cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace',
+               '--output-format', 'csv', '-d', tmp, '-o', 'pmc', '--',
+               sys.executable, os.path.abspath(__file__)] + [
+                   a for a in argv if a != '--pmc-traffic'] + [
+                   '--no-cpu-baseline']
+        env = dict(os.environ, TMPDIR='/tmp')
+        try:
+            child = subprocess.run(cmd, cwd='/tmp', env=env, check=True,
+                                   timeout=1800, capture_output=True,
+                                   text=True)
+            line = [ln for ln in child.stdout.splitlines()
+                    if ln.startswith('{"metric"')][-1]
+            n_timed = int(json.loads(line)['roofline']['launches'])
+        except Exception:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None
+        rows = []
+        for path in glob.glob(os.path.join(tmp, '**', '*counter_collection'
+                                                      '.csv'),
+                              recursive=True):
+            with open(path) as fh:
+                rows += [r for r in csv.DictReader(fh)
+                         if kernel_substr in r.get('Kernel_Name', '') and
+                         r.get('Counter_Name') == counter]
+        shutil.rmtree(tmp, ignore_errors=True)
+        rows.sort(key=lambda r: int(r['Dispatch_Id']))
+        vals = [float(r['Counter_Value']) for r in rows[-n_timed:]]
+        if not vals:
+            return None
+        # FETCH_SIZE / WRITE_SIZE are reported in kilobytes; FETCH_SIZE
+        # tallies the 128-B requests of wide loads at 64 B on gfx950 (x 2)
+        totals[counter] = (sum(vals) * 1024.0 *
+                           (2.0 if counter == 'FETCH_SIZE' else 1.0),
+                           len(vals))
+    fetch, n_f = totals['FETCH_SIZE']
+    write, n_w = totals['WRITE_SIZE']
+    return dict(bytes_per_launch=fetch / n_f + write / n_w,
+                read_bytes_per_launch=fetch / n_f,
+                write_bytes_per_launch=write / n_w, launches=n_f)
 
 
 def roctx_region(resume):
@@ -229,33 +392,14 @@ def main():
             raise SystemExit('exploration did not finish within %.0f s' %
                              args.explore_timeout)
 
-    def broadcast_from_rank0(s):
-        box = [s if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        if rank != 0:
-            s = box[0]
-            s.comm = comm
-        return s
-
-    if comm is None:
-        explore()
-    elif args.broadcast_state:
-        if rank == 0:
-            explore()
-        sampler = broadcast_from_rank0(sampler)
-    else:
-        # bound construction is "replicas only": identical seeds and
-        # deterministic kernels give identical bounds on every rank
-        explore()
-        try:
-            comm.assert_identical([sampler.log_z or 0.0, sampler.n_like,
-                                   len(sampler.bounds)], 'cuda',
-                                  'exploration state')
-        except RuntimeError as err:
-            if rank == 0:
-                print('replicas differ (%s); broadcasting rank 0' % err,
-                      file=sys.stderr)
-            sampler = broadcast_from_rank0(sampler)
+    # with N ranks the exploration is sharded like everything else: every
+    # batch and the emulator networks are dealt out over the ranks, the
+    # (deterministic) geometric construction is replicated
+    explore()
+    if comm is not None:
+        comm.assert_identical([sampler.log_z or 0.0, sampler.n_like,
+                               len(sampler.bounds)], 'cuda',
+                              'exploration state')
     setup_s = time.time() - t_setup
     if comm is not None:
         sampler.n_batch = args.n_batch_setup * world
@@ -312,20 +456,23 @@ def main():
     ev = kernels.get('nb_eval_kernel', dict(ms=0.0, launches=0))
     achieved_tf = flops / (ev['ms'] * 1e-3) / 1e12 if ev['ms'] > 0 else 0.0
     # HBM bytes per launch: PMC counters cannot be collected from inside this
-    # process; profiles/tools/bench_traffic.sh measures them in separate
-    # rocprofv3 --pmc passes of this very command (FETCH_SIZE x 2 on gfx950,
-    # WRITE_SIZE) and commits the result.  Only quoted for that workload.
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                            'profiles', 'r01', 'bench_eval_traffic.json')
-    default_workload = (d == 50 and args.n_live == 2000 and e == 4 and
-                        args.n_batch == 65536 and world == 1 and
-                        not args.host_likelihood)
-    if default_workload and os.path.exists(pmc_file):
-        with open(pmc_file) as fh:
-            traffic = float(json.load(fh)['hbm_bytes_per_launch'])
-        traffic_src = ('profiles/r01/bench_eval_traffic.json (separate '
-                       'rocprofv3 --pmc passes of this command)')
+    # process.  --pmc-traffic re-runs this command under rocprofv3 --pmc
+    # (separate FETCH_SIZE / WRITE_SIZE passes, only the timed region is
+    # profiled) and reports the measured value; otherwise null, with the
+    # latest committed measurement under profiles/ named for reference.
+    traffic, traffic_src = None, ('not measured in this run (use '
+                                  '--pmc-traffic); committed measurements: '
+                                  'profiles/r02/')
+    if args.pmc_traffic and rank == 0 and world == 1:
+        got = pmc_traffic(sys.argv[1:], 'nb_eval_kernel')
+        if got is not None:
+            traffic = got['bytes_per_launch']
+            traffic_src = ('rocprofv3 --pmc child passes of this command: '
+                           '%.0f B read (FETCH_SIZE x 2) + %.0f B written per '
+                           'launch, %d launches' % (
+                               got['read_bytes_per_launch'],
+                               got['write_bytes_per_launch'],
+                               got['launches']))
     roofline = dict(
         kernel='nb_eval_kernel', bound='mfma', achieved=achieved_tf,
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
@@ -346,6 +493,14 @@ def main():
         metric='effective posterior samples/sec + |dlogZ| vs analytic, '
                '50-dim Gaussian',
         value=(n_eff1 - n_eff0) / dt, unit='effective samples/s',
+        value_definition='growth of the effective sample size over the K '
+                         'timed sampling-phase steps / their wall time (the '
+                         'hot loop); the end-to-end figure incl. the '
+                         'exploration phase is value_full_run',
+        value_full_run=n_eff1 / (setup_s + fill_s + dt),
+        value_full_run_definition='n_eff / (exploration + first batch of '
+                                  'every shell + warm-up and timed steps) '
+                                  '(SURVEY.md section 8d)',
         n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
         scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
@@ -374,9 +529,10 @@ def main():
         nb = sampler.bounds[-1].neural_bounds[0].outer_bound
         ell = Ellipsoid.from_params(nb.c, nb.B, nb.B_inv, nb.A)
         n_pts = 1 << 24
+        # a mixed mask: half of the probe points are drawn inside the
+        # ellipsoid, half uniformly in the cube (all outside at D = 50)
         x = torch.rand((n_pts, d), dtype=torch.float64, device='cuda')
-        x[::2] = torch.from_numpy(nb.c).cuda() + 3.0 * (
-            x[::2] - 0.5) * float(np.sqrt(np.mean(np.diag(nb.B)**2)))
+        x[::2] = ell.device_bound().propose(7, 0, n_pts // 2)
         bound_dev = ell.device_bound()
         bound_dev.contains_stream(x)
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -397,9 +553,9 @@ def main():
         del x, mask
         out['mfma_f64_probe_tflops'] = device.mfma_f64_peak(20000)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sampler, like.numpy,
-                                               args.cpu_seconds)
-            out['cpu_baseline']['host_cores_available'] = os.cpu_count()
+            out['cpu_baseline'] = cpu_baseline(
+                sampler, NumpyGaussian(np.full(d, 0.5), 0.05),
+                args.cpu_seconds, args.cpu_cores)
         print(json.dumps(out))
     if comm is not None:
         comm.barrier()

@@ -4,8 +4,12 @@
 
 TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  Only the features the
 BASELINE configs use are restated: identity-style callable prior or none,
-``vectorized`` likelihood (or per-point), no blobs, no checkpointing,
-``pool=None``.
+``vectorized`` likelihood (or per-point), no blobs, no checkpointing.  An
+optional ``pool`` attribute (an object with ``map`` / ``size``) switches on
+the reference's multiprocess path: bounds replicate themselves over the pool
+in ``sample`` (bounds/nautilus.py:223-237) and a vectorized likelihood gets
+one chunk per worker (sampler.py:860-873) -- used by ``bench.py``'s
+``cpu_baseline`` leg.
 """
 
 from time import time
@@ -232,7 +236,9 @@ class OSampler:
         idx_t = np.zeros(0, dtype=int)
         chunks = []
         while n_have < self.n_batch:
-            x = self.bounds[index].sample(self.n_batch - n_have)
+            # sampler.py:791-792: the bound replicates itself over pool_s
+            x = self.bounds[index].sample(self.n_batch - n_have,
+                                          pool=getattr(self, 'pool', None))
             n_bound += self.n_batch - n_have
             keep = np.ones(len(x), dtype=bool)
             for later in self.bounds[index:][1:]:
@@ -263,7 +269,14 @@ class OSampler:
 
     def evaluate_likelihood(self, x):
         """sampler.py:856-908 without pools / dict priors / blobs."""
-        if self.vectorized:
+        pool = getattr(self, 'pool', None)
+        if self.vectorized and pool is not None:
+            # sampler.py:860-873: one chunk per worker of pool_l
+            args = x if self.prior is None else self.prior(x)
+            log_l = np.concatenate([np.atleast_1d(r) for r in pool.map(
+                self.likelihood, np.array_split(args, pool.size))]).astype(
+                    float)
+        elif self.vectorized:
             args = x if self.prior is None else self.prior(x)
             log_l = np.asarray(self.likelihood(args), float)
         else:
