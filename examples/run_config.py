@@ -17,32 +17,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from nautilus_amd import (FunnelLikelihood, GaussianLikelihood,  # noqa
-                          GaussianMixtureLikelihood, RosenbrockLikelihood,
-                          Sampler, unit_prior)
-
-
-def config(name):
-    if name == 'C1':
-        like = GaussianLikelihood([0.4, 0.5, 0.6], 0.01 * np.eye(3))
-        return dict(like=like, n_dim=3, n_live=1000, n_networks=4,
-                    analytic=-6.4e-5)
-    if name == 'C2':
-        d, s = 20, 0.05
-        cov = s**2 * (0.5 * np.ones((d, d)) + 0.5 * np.eye(d))
-        return dict(like=GaussianLikelihood(np.full(d, 0.5), cov), n_dim=d,
-                    n_live=2000, n_networks=4, analytic=0.0)
-    if name == 'C3':
-        return dict(like=RosenbrockLikelihood(30), n_dim=30, n_live=3000, n_networks=4,
-                    analytic=None)
-    if name == 'C4':
-        means = 0.25 + 0.5 * np.random.default_rng(3).random((4, 50))
-        return dict(like=GaussianMixtureLikelihood(means, 0.02), n_dim=50,
-                    n_live=5000, n_networks=4, analytic=0.0)
-    if name == 'C5':
-        return dict(like=FunnelLikelihood(100), n_dim=100, n_live=10000, n_networks=8,
-                    analytic=None)
-    raise SystemExit('unknown config ' + name)
+from nautilus_amd import Sampler, unit_prior  # noqa: E402
+from nautilus_amd.configs import baseline_config  # noqa: E402
 
 
 def main():
@@ -53,9 +29,10 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--timeout', type=float, default=np.inf)
     args = ap.parse_args()
-    c = config(args.name)
+    c = baseline_config(args.name)
     t0 = time.time()
-    s = Sampler(unit_prior, c['like'], n_dim=c['n_dim'], n_live=c['n_live'],
+    s = Sampler(unit_prior, c['likelihood'], n_dim=c['n_dim'],
+                n_live=c['n_live'],
                 n_networks=c['n_networks'], n_batch=args.n_batch,
                 vectorized=True, seed=args.seed)
     ok = s.run(n_eff=args.n_eff, discard_exploration=True,
@@ -67,7 +44,7 @@ def main():
     mean = np.average(pts, weights=w, axis=0)
     print(json.dumps(dict(
         config=args.name, finished=bool(ok), wall_s=round(wall, 2),
-        log_z=float(s.log_z), analytic_log_z=c['analytic'],
+        log_z=float(s.log_z), analytic_log_z=c['analytic_log_z'],
         n_eff=float(s.n_eff), n_like=int(s.n_like), n_bounds=len(s.bounds),
         n_neural_last=len(s.bounds[-1].neural_bounds)
         if len(s.bounds) > 1 else 0,

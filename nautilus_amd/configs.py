@@ -1,0 +1,57 @@
+"""The five BASELINE.json workloads as ready
+made (likelihood, sampler settings) pairs: synthetic problems on the unit
+cube with an identity prior and device likelihoods, shared by
+``examples/run_config.py``, ``bench.py`` and the end-to-end tests."""
+
+import numpy as np
+
+from .likelihoods import (FunnelLikelihood, GaussianLikelihood,
+                          GaussianMixtureLikelihood, RosenbrockLikelihood)
+
+NAMES = ('C1', 'C2', 'C3', 'C4', 'C5')
+
+
+def baseline_config(name):
+    """dict(likelihood, n_dim, n_live, n_networks, analytic_log_z or None,
+    description)."""
+    if name == 'C1':
+        # README example of the reference: 3-D Gaussian
+        return dict(
+            likelihood=GaussianLikelihood([0.4, 0.5, 0.6], 0.01 * np.eye(3)),
+            n_dim=3, n_live=1000, n_networks=4, analytic_log_z=-6.4e-5,
+            description='3-dim multivariate Gaussian (README example), '
+                        'n_live=1000')
+    if name == 'C2':
+        d, s = 20, 0.05
+        cov = s**2 * (0.5 * np.ones((d, d)) + 0.5 * np.eye(d))
+        return dict(
+            likelihood=GaussianLikelihood(np.full(d, 0.5), cov), n_dim=d,
+            n_live=2000, n_networks=4, analytic_log_z=0.0,
+            description='20-dim correlated Gaussian, n_live=2000')
+    if name == 'C3':
+        return dict(
+            likelihood=RosenbrockLikelihood(30), n_dim=30, n_live=3000,
+            n_networks=4, analytic_log_z=None,
+            description='30-dim Rosenbrock on [-5, 5]^30, n_live=3000')
+    if name == 'C4':
+        means = 0.25 + 0.5 * np.random.default_rng(3).random((4, 50))
+        return dict(
+            likelihood=GaussianMixtureLikelihood(means, 0.02), n_dim=50,
+            n_live=5000, n_networks=4, analytic_log_z=0.0,
+            description='50-dim 4-mode Gaussian mixture, n_live=5000')
+    if name == 'C5':
+        return dict(
+            likelihood=FunnelLikelihood(100), n_dim=100, n_live=10000,
+            n_networks=8, analytic_log_z=None,
+            description='100-dim Neal funnel, n_live=10000, n_networks=8')
+    raise ValueError('unknown BASELINE configuration %r' % (name,))
+
+
+def headline_config(n_dim=50):
+    """The BASELINE.json ``metric`` case: single-mode 50-D Gaussian,
+    mu = 0.5, sigma = 0.05, analytic log Z = 0."""
+    return dict(
+        likelihood=GaussianLikelihood(np.full(n_dim, 0.5),
+                                      np.eye(n_dim) * 0.05**2),
+        n_dim=n_dim, n_live=2000, n_networks=4, analytic_log_z=0.0,
+        description='%d-dim Gaussian mu=0.5 sigma=0.05' % n_dim)

@@ -133,6 +133,17 @@ def union_cases():
                8)
 
 
+def union_d50_case():
+    """union_K4_D50: four blobs in 50 dimensions, the
+    last five uniform, cube-ellipsoid mixture members, unit-cube clip."""
+    rng = np.random.default_rng(12)
+    cen = 0.3 + 0.4 * rng.random((4, 50))
+    pts = np.vstack([c + 0.01 * rng.normal(size=(300, 50)) for c in cen])
+    pts[:, 45:] = rng.random((1200, 5))
+    union_case('union_K4_D50', pts, bounds.UnitCubeEllipsoidMixture, 3, True,
+               50)
+
+
 def emulator_case(d, n, e, seed):
     rng = np.random.default_rng(seed)
     x = rng.normal(size=(n, d))
@@ -326,7 +337,80 @@ def e2e_cases():
     save('shellstats', **arrays)
 
 
+def gauss20(x):
+    """BASELINE config 2: mu = 0.5, Sigma = sigma^2
+    (0.5 11^T + 0.5 I), sigma = 0.05; analytic log Z = 0."""
+    d, s = 20, 0.05
+    cov = s**2 * (0.5 * np.ones((d, d)) + 0.5 * np.eye(d))
+    if not hasattr(gauss20, 'prec'):
+        gauss20.prec = np.linalg.inv(cov)
+        gauss20.norm = -0.5 * (d * np.log(2 * np.pi) +
+                               np.linalg.slogdet(cov)[1])
+    y = np.atleast_2d(x) - 0.5
+    return gauss20.norm - 0.5 * np.einsum('ij,jk,ik->i', y, gauss20.prec, y)
+
+
+def gauss3_c1(x):
+    """BASELINE config 1 (README example): mu = (0.4, 0.5, 0.6), sigma = 0.1,
+    normalised; analytic log Z = -6.4e-5."""
+    return (gauss3(x) - 3 * np.log(0.1 * np.sqrt(2 * np.pi)))
+
+
+def _summary(s, seed, discard, mu):
+    pts, log_w, log_l = s.posterior()
+    w = np.exp(log_w)
+    mean = np.average(pts, weights=w, axis=0)
+    return dict(seed=seed, discard_exploration=discard,
+                log_z=float(s.log_z), n_eff=float(s.n_eff),
+                n_like=int(s.n_like), n_bounds=len(s.bounds),
+                eta=float(s.eta), mean=mean.tolist(),
+                var=np.average((pts - mu)**2, weights=w, axis=0).tolist())
+
+
+def e2e_config_run(config, seed, discard):
+    """One full reference run of BASELINE config C1 / C2."""
+    if config == 'C1':
+        s = nautilus.Sampler(lambda x: x, gauss3_c1, n_dim=3, n_live=1000,
+                             vectorized=True, seed=seed)
+        mu = np.array([0.4, 0.5, 0.6])
+    else:
+        s = nautilus.Sampler(lambda x: x, gauss20, n_dim=20, n_live=2000,
+                             vectorized=True, seed=seed)
+        mu = np.full(20, 0.5)
+    s.run(discard_exploration=discard)
+    return _summary(s, seed, discard, mu)
+
+
+def e2e_config_sweep(config, seeds, discards, n_proc):
+    """Seed sweep of a BASELINE config with the reference (the tolerance band
+    of log Z, n_like and the number of bounds for the device path)."""
+    import multiprocessing
+    jobs = [(config, seed, discard) for discard in discards for seed in seeds]
+    with multiprocessing.Pool(n_proc) as pool:
+        rows = pool.starmap(e2e_config_run, jobs)
+    analytic = -6.4e-5 if config == 'C1' else 0.0
+    problem = ('3-D Gaussian mu=(0.4,0.5,0.6) sigma=0.1 (normalised), '
+               'n_live=1000' if config == 'C1' else
+               '20-D correlated Gaussian mu=0.5 Sigma=0.05^2 (0.5 11^T + '
+               '0.5 I), n_live=2000')
+    with open(os.path.join(HERE, 'e2e_%s.json' % config), 'w') as f:
+        json.dump(dict(problem=problem + ', identity prior, n_networks=4, '
+                       'n_eff=10000 (reference defaults)',
+                       analytic_log_z=analytic, runs=rows), f, indent=1)
+    print(config, [round(r['log_z'], 4) for r in rows])
+
+
 if __name__ == '__main__':
+    if '--round2-small' in sys.argv:
+        union_d50_case()
+        emulator_case(50, 1500, 4, 23)
+        sys.exit(0)
+    if '--e2e-C1' in sys.argv:
+        e2e_config_sweep('C1', range(10), [False, True], 7)
+        sys.exit(0)
+    if '--e2e-C2' in sys.argv:
+        e2e_config_sweep('C2', range(6), [True], 6)
+        sys.exit(0)
     if '--periodic-only' in sys.argv:
         periodic_cases()
         sys.exit(0)

@@ -127,7 +127,8 @@ def _union_from_golden(g, mixture):
 
 
 @pytest.mark.parametrize('name,mixture', [('union_K2_D3', False),
-                                          ('union_K4_D8', True)])
+                                          ('union_K4_D8', True),
+                                          ('union_K4_D50', True)])
 def test_union_golden(dev, name, mixture):
     g = load_golden(name)
     u = _union_from_golden(g, mixture)
@@ -140,7 +141,8 @@ def test_union_golden(dev, name, mixture):
 
 
 @pytest.mark.parametrize('name,mixture', [('union_K2_D3', False),
-                                          ('union_K4_D8', True)])
+                                          ('union_K4_D8', True),
+                                          ('union_K4_D50', True)])
 def test_union_proposals_match_oracle(dev, name, mixture):
     """Device Union.sample == oracle Philox tier, proposal by proposal."""
     from oracle import philox
@@ -205,7 +207,7 @@ def test_neural_bound_golden(dev, neural_d4):
     assert 0 < g['contains'].sum() < len(g['contains'])
 
 
-@pytest.mark.parametrize('d,e', [(5, 1), (20, 2)])
+@pytest.mark.parametrize('d,e', [(5, 1), (20, 2), (50, 4)])
 def test_emulator_predict_golden(dev, d, e):
     """NeuralNetworkEmulator.predict (neural.py:100-116) on the matrix cores
     against sklearn's own predictions."""
@@ -715,6 +717,35 @@ def test_emulator_training_ragged_batches(dev):
         ref = mo.fit_network(x, y, 1, max_iter=3)
         assert np.allclose(nets[0].loss_curve_, ref.loss_curve, rtol=1e-9)
         assert np.allclose(nets[0].coefs_[0], ref.coefs[0], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize('name,e', [('emulator_D5_E1', 1),
+                                    ('emulator_D20_E2', 2),
+                                    ('emulator_D50_E4', 4)])
+def test_emulator_full_fit_equals_sklearn(dev, name, e):
+    """A WHOLE fit -- same Glorot draw, same minibatch order for every epoch
+    (numpy RandomState shuffles as in scikit-learn), the stopping rule of
+    _fit_stochastic -- against scikit-learn's own MLPRegressor.fit (fixtures
+    written by make_golden.py through the reference's
+    NeuralNetworkEmulator.train): the stop epoch is EQUAL, the loss curve
+    agrees over its whole length, weights and predictions to rounding."""
+    from nautilus_amd.emulator import NeuralNetworkEmulator
+    g = load_golden(name)
+    emu = NeuralNetworkEmulator.train(g['x'], g['y'], n_networks=e)
+    assert np.allclose(emu.mean, g['mean'], rtol=1e-14, atol=1e-15)
+    assert np.allclose(emu.scale, g['scale'], rtol=1e-13)
+    for i, net in enumerate(emu.neural_networks):
+        ref = g['loss_curve_%d' % i]
+        assert net.n_iter_ == int(g['n_iter_%d' % i]) == len(ref)
+        assert np.allclose(net.loss_curve_, ref, rtol=1e-9, atol=0)
+        for k in range(4):
+            assert np.allclose(net.coefs_[k], g['coef_%d_%d' % (i, k)],
+                               rtol=0, atol=1e-10)
+            assert np.allclose(net.intercepts_[k],
+                               g['intercept_%d_%d' % (i, k)], rtol=0,
+                               atol=1e-10)
+    assert np.allclose(emu.predict(g['test']), g['predict'], rtol=0,
+                       atol=1e-11)
 
 
 def test_emulator_full_training_quality(dev):

@@ -69,7 +69,8 @@ def test_mixture_matches_reference():
 
 @pytest.mark.parametrize('name,cls,n_split,unit', [
     ('union_K2_D3', bo.OEllipsoid, 1, False),
-    ('union_K4_D8', bo.OMixture, 3, True)])
+    ('union_K4_D8', bo.OMixture, 3, True),
+    ('union_K4_D50', bo.OMixture, 3, True)])
 def test_union_matches_reference(name, cls, n_split, unit):
     g = load_golden(name)
     union = bo.OUnion.build(g['points'], enlarge_per_dim=1.1, unit=unit,
@@ -107,7 +108,8 @@ def test_union_errors():
         bo.OEllipsoid.build(np.random.random(size=(30, 3)), 0.9)
 
 
-@pytest.mark.parametrize('name', ['emulator_D5_E1', 'emulator_D20_E2'])
+@pytest.mark.parametrize('name', ['emulator_D5_E1', 'emulator_D20_E2',
+                                  'emulator_D50_E4'])
 def test_emulator_matches_sklearn(name):
     """The restated MLPRegressor.fit reproduces scikit-learn's weights, loss
     curve and stopping epoch (same BLAS calls -> expected bit-identical; the
