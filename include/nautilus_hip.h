@@ -152,14 +152,19 @@ int nb_accept(const nb_bound* bound, uint64_t seed, uint64_t offset,
               void* stream);
 
 /* Stable stream compaction (the reference's boolean indexing
- * `points[in_bound]`): rows with (flags & mask) != 0 are copied to out_dev in
- * input order.  counts_dev[0] = rows with bit0 set, counts_dev[1] = rows
- * copied.  src_idx_dev (optional) receives the source row of every output
- * row.  scratch_dev must hold nb_compact_scratch_bytes(n) bytes.            */
+ * `points[in_bound]`, `points[in_shell]`): rows with ((flags ^ flip) & mask)
+ * != 0 are copied to out_dev in input order (flip = 1, mask = 1 keeps the
+ * rows whose flag is 0: the points NOT inside a later bound,
+ * sampler.py:796-799).  counts_dev[0] = rows with bit0 of flags ^ flip set,
+ * counts_dev[1] = rows copied.  src_idx_dev (optional) receives the source
+ * row of every output row -- src_idx_dev[k-1] + 1 rows were examined for
+ * the first k survivors, the "trials until the k-th success" of
+ * Sampler.sample_shell.  scratch_dev must hold nb_compact_scratch_bytes(n)
+ * bytes.                                                                    */
 int64_t nb_compact_scratch_bytes(int64_t n);
 int nb_compact_rows(const double* x_dev, const uint8_t* flags_dev,
-                    uint8_t mask, int64_t n, int32_t n_dim, double* out_dev,
-                    int64_t* src_idx_dev, int64_t* counts_dev,
+                    uint8_t mask, uint8_t flip, int64_t n, int32_t n_dim,
+                    double* out_dev, int64_t* src_idx_dev, int64_t* counts_dev,
                     void* scratch_dev, void* stream);
 
 /* Per-shell evidence statistics (sampler.py:927-943): out_dev[0] =
@@ -168,6 +173,34 @@ int nb_compact_rows(const double* x_dev, const uint8_t* flags_dev,
 int nb_shell_stats(const double* log_l_dev, int64_t n, double threshold,
                    double* out_dev, void* scratch_dev, void* stream);
 int64_t nb_shell_stats_scratch_bytes(int64_t n);
+
+/* The live set of the exploration phase on the device (Sampler.f_live /
+ * log_v_live / the threshold of add_bound, sampler.py:1147-1190, 1004-1010:
+ * the reference sorts every stored log L on every iteration).  A pool in HBM
+ * holds every log L at or above the current threshold (thr_dev[0], start at
+ * -inf):
+ *   nb_live_append   appends the values >= threshold of a new batch
+ *                    (pool_n_dev[0] entries so far; overflow_dev[0] is set if
+ *                    the capacity does not suffice -- rebuild with a larger
+ *                    pool);
+ *   nb_live_select   the exact k-th largest value of the pool (radix
+ *                    selection, one workgroup) becomes the new threshold, the
+ *                    values >= it are copied to pool_out (pool_out_n_dev[0]
+ *                    entries); stats_dev[0..2] = threshold, #values above,
+ *                    #values equal (ties at the threshold);
+ *   nb_live_stats    for one shell's log L: out_dev[0] = #(l > threshold),
+ *                    out_dev[1] = logsumexp(l | l > threshold), out_dev[2] =
+ *                    #(l == threshold) -- the shell's share of the live
+ *                    weight (shuffle reductions).                            */
+int nb_live_append(const double* log_l_dev, int64_t n, const double* thr_dev,
+                   double* pool_dev, int32_t* pool_n_dev, int32_t capacity,
+                   int32_t* overflow_dev, void* stream);
+int nb_live_select(const double* pool_dev, const int32_t* pool_n_dev,
+                   int32_t capacity, int32_t k, double* pool_out_dev,
+                   int32_t* pool_out_n_dev, double* thr_dev, double* stats_dev,
+                   void* stream);
+int nb_live_stats(const double* log_l_dev, int64_t n, const double* thr_dev,
+                  double* out_dev, void* stream);
 
 /* Emulator training, NeuralNetworkEmulator.train -> MLPRegressor.fit
  * (neural.py:50-98; sklearn/_multilayer_perceptron.py:620-760): Adam,
@@ -339,6 +372,28 @@ int nb_gmm_fit(const double* x_dev, int64_t n, int32_t n_dim, int32_t n_init,
 int nb_phase_shift(double* x_dev, int64_t n, int32_t n_dim, int32_t n_periodic,
                    const int32_t* periodic, const double* centers,
                    int32_t inverse, void* stream);
+
+/* Multi-GPU exchange over RCCL / xGMI for a binding that does not bring its
+ * own collectives (the product's Python layer uses torch.distributed, whose
+ * "nccl" backend is the same RCCL): the reference's parallel pattern on this
+ * path -- replicate the bound, draw independent streams, concatenate the
+ * accepted points, add the counters (bounds/nautilus.py:223-237) -- is one
+ * all-gather of equal per-rank blocks of doubles and one all-reduce of
+ * int64 counters per batch.  Rank 0 creates the 128-byte id and hands it to
+ * the other processes out of band (one process per GPU); nb_comm_rank_key
+ * gives rank r its own Philox key.  RCCL is loaded at run time.            */
+#define NB_COMM_ID_BYTES 128
+typedef struct nb_comm nb_comm;
+int nb_comm_unique_id(uint8_t* id_out /* [NB_COMM_ID_BYTES] */);
+int nb_comm_init(int32_t rank, int32_t n_ranks, const uint8_t* id,
+                 nb_comm** out);
+int nb_comm_destroy(nb_comm* comm);
+uint64_t nb_comm_rank_key(uint64_t seed, int32_t rank);
+int nb_comm_allgather_f64(nb_comm* comm, const double* send_dev, int64_t count,
+                          double* recv_dev /* [n_ranks * count] */,
+                          void* stream);
+int nb_comm_allreduce_i64(nb_comm* comm, int64_t* buf_dev /* in place, sum */,
+                          int64_t count, void* stream);
 
 /* The roofline kernel: single-ellipsoid contains (basic.py:344-360) with the
  * points streamed once from HBM.  Same result as nb_contains.               */

@@ -67,7 +67,7 @@ _SIGNATURES = {
                             C.c_int64, C.c_void_p, C.c_void_p]),
     'nb_compact_scratch_bytes': (C.c_int64, [C.c_int64]),
     'nb_compact_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint8,
-                                  C.c_int64, C.c_int32, C.c_void_p,
+                                  C.c_uint8, C.c_int64, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     'nb_shell_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_double,
@@ -132,6 +132,23 @@ _SIGNATURES = {
     'nb_loglike_funnel': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
                                     C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_void_p, C.c_void_p]),
+    'nb_live_append': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_void_p, C.c_void_p]),
+    'nb_live_select': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    'nb_live_stats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+    'nb_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'nb_comm_init': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p,
+                               C.POINTER(C.c_void_p)]),
+    'nb_comm_destroy': (C.c_int, [C.c_void_p]),
+    'nb_comm_rank_key': (C.c_uint64, [C.c_uint64, C.c_int32]),
+    'nb_comm_allgather_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p]),
+    'nb_comm_allreduce_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p]),
     'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
     'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
     'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

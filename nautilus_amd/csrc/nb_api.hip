@@ -23,7 +23,8 @@ int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
                    hipStream_t stream);
 long long nb_compact_chunks(long long n);
 int nb_launch_compact(const double* x, const unsigned char* flags,
-                      unsigned char mask, long long n, int n_dim, double* out,
+                      unsigned char mask, unsigned char flip, long long n,
+                      int n_dim, double* out,
                       long long* src_idx, long long* counts,
                       long long* chunk_counts, hipStream_t stream);
 int nb_lse_blocks(long long n);
@@ -46,6 +47,14 @@ int nb_launch_quadform_max(const double* x, long long n, int d,
                            const double* p_dev, double* out, double* work,
                            hipStream_t stream);
 long long nb_quadform_work_doubles_impl();
+int nb_launch_live_append(const double* ll, long long n, const double* thr,
+                          double* pool, int* pool_n, int cap, int* overflow,
+                          hipStream_t stream);
+int nb_launch_live_select(const double* pool, const int* pool_n, int cap,
+                          int k, double* out, int* out_n, double* thr,
+                          double* stats, hipStream_t stream);
+int nb_launch_live_stats(const double* ll, long long n, const double* thr,
+                         double* out, hipStream_t stream);
 int nb_launch_rosenbrock(const double* u, long long n, int d, double lo,
                          double hi, double a, double* out, hipStream_t stream);
 int nb_launch_funnel(const double* u, long long n, int d, double mu, double s0,
@@ -566,9 +575,10 @@ int64_t nb_compact_scratch_bytes(int64_t n) {
 }
 
 int nb_compact_rows(const double* x, const uint8_t* flags, uint8_t mask,
-                    int64_t n, int32_t n_dim, double* out, int64_t* src_idx,
-                    int64_t* counts, void* scratch, void* stream) {
-  return nb_launch_compact(x, flags, mask, n, n_dim, out,
+                    uint8_t flip, int64_t n, int32_t n_dim, double* out,
+                    int64_t* src_idx, int64_t* counts, void* scratch,
+                    void* stream) {
+  return nb_launch_compact(x, flags, mask, flip, n, n_dim, out,
                            (long long*)src_idx, (long long*)counts,
                            (long long*)scratch, as_stream(stream));
 }
@@ -754,6 +764,40 @@ int nb_loglike_funnel(const double* u, int64_t n, int32_t n_dim, double mu,
   }
   return nb_launch_funnel(u, n, n_dim, mu, sigma0, k, c, out,
                           as_stream(stream));
+}
+
+int nb_live_append(const double* log_l, int64_t n, const double* thr,
+                   double* pool, int32_t* pool_n, int32_t capacity,
+                   int32_t* overflow, void* stream) {
+  if (capacity < 1 || thr == nullptr || pool == nullptr || pool_n == nullptr ||
+      overflow == nullptr || (n > 0 && log_l == nullptr)) {
+    nb_set_error("bad live-pool arguments");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_live_append(log_l, n, thr, pool, pool_n, capacity, overflow,
+                               as_stream(stream));
+}
+
+int nb_live_select(const double* pool, const int32_t* pool_n, int32_t capacity,
+                   int32_t k, double* pool_out, int32_t* pool_out_n,
+                   double* thr, double* stats, void* stream) {
+  if (capacity < 1 || k < 1 || pool == nullptr || pool_n == nullptr ||
+      pool_out == nullptr || pool_out_n == nullptr || thr == nullptr ||
+      stats == nullptr) {
+    nb_set_error("bad live-pool arguments");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_live_select(pool, pool_n, capacity, k, pool_out, pool_out_n,
+                               thr, stats, as_stream(stream));
+}
+
+int nb_live_stats(const double* log_l, int64_t n, const double* thr,
+                  double* out, void* stream) {
+  if (thr == nullptr || out == nullptr || (n > 0 && log_l == nullptr)) {
+    nb_set_error("null argument");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_live_stats(log_l, n, thr, out, as_stream(stream));
 }
 
 int64_t nb_gmm_out_doubles(int32_t n_dim) {

@@ -130,11 +130,7 @@ __device__ __forceinline__ void mlp_block(const double* w, int ks_n,
     const double* wk = w + ((ks - KS_LO) >> 2) * HT * NB_TILE + (ks & 3) * 64;
 #pragma unroll
     for (int h = 0; h < NF; ++h) {
-#ifdef NB_EXPERIMENT_NOLOAD
-      a[h] = 1e-3 * (double)(lane + ks + 7 * h);       // dev experiment only
-#else
       a[h] = wk[(H0 + h) * NB_TILE + lane];
-#endif
     }
     if constexpr (REM) a[NF] = wk[roff];
   };
@@ -535,9 +531,6 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             inside_e[t] = !box_bad[t] && r2[t] < 1.0;
             need[t] = want[t] && inside_e[t] && !neural_ok[t];
             if (m_score) need[t] = valid[t];
-#ifdef NB_DBG_NO_MLP
-            need[t] = false;                       // dev experiment only
-#endif
             cnt_ell += __popcll(__ballot(want[t] && lg == 0));
             cnt_mlp += (unsigned long long)E *
                        __popcll(__ballot(need[t] && lg == 0));
@@ -852,18 +845,22 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   // Gathered variant (emulator inputs compacted through LDS): pays off when
   // only a small minority of a workgroup's points reaches an emulator.  In
   // the benchmark's shell exclusion the dense variant with its overlapped
-  // weight streaming is 3 % faster end to end, so it is the default;
-  // NB_EVAL_GATHER=1 selects the gathered kernel for the sparse modes.
+  // weight streaming is 3 % faster end to end, so it is the default (the
+  // gathered instantiation is only built with -DNB_EVAL_GATHER, `make debug`).
   const size_t need = ((size_t)gather_tiles * NB_TILE + 128 * TS + 128) * 8 + 64;
   const bool sparse = (a.mode == MODE_ANY || a.mode == MODE_ASSOC);
   // two tiles per wavefront up to n_dim = 64; beyond that the per-lane state
   // (y, standardised input, hidden activations of two tiles) no longer fits
   // the register file
   constexpr int TPW = (DT <= 4) ? 2 : 1;
+#ifdef NB_EVAL_GATHER
   if constexpr (DT <= 4) {
-    if (sparse && getenv("NB_EVAL_GATHER") != nullptr && need <= 160 * 1024)
+    if (sparse && need <= 160 * 1024)
       return launch_eval_impl<DT, 0, TPW, 4, true>(a, gather_tiles, stream);
   }
+#else
+  (void)need;
+#endif
   // (8 wavefronts x 1 tile was measured as well: +7 % at D = 20, -2 % at
   // D = 50, where the 256-register budget per wavefront forces ~100 spills)
   if (sparse) return launch_eval_impl<DT, 1, TPW, 4, true>(a, lds_tiles, stream);

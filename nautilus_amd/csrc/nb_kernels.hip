@@ -214,13 +214,14 @@ constexpr int CHUNK = 2048;   // flags per workgroup (256 threads x 8)
 
 __global__ void __launch_bounds__(256)
 nb_count_kernel(const unsigned char* __restrict__ flags, unsigned char mask,
-                long long n, long long* __restrict__ chunk_counts) {
+                unsigned char flip, long long n,
+                long long* __restrict__ chunk_counts) {
   __shared__ int s0[4], s1[4];
   const long long base = (long long)blockIdx.x * CHUNK;
   int c0 = 0, c1 = 0;
   for (int k = 0; k < CHUNK / 256; ++k) {
     const long long i = base + k * 256 + threadIdx.x;
-    const unsigned char f = (i < n) ? flags[i] : 0;
+    const unsigned char f = (i < n) ? (flags[i] ^ flip) : 0;
     c0 += __popcll(__ballot((f & 1) != 0));
     c1 += __popcll(__ballot((f & mask) != 0));
   }
@@ -267,7 +268,7 @@ nb_scan_kernel(long long* __restrict__ chunk_counts, long long n_chunks,
 __global__ void __launch_bounds__(256)
 nb_scatter_kernel(const double* __restrict__ x,
                   const unsigned char* __restrict__ flags, unsigned char mask,
-                  long long n, int n_dim,
+                  unsigned char flip, long long n, int n_dim,
                   const long long* __restrict__ chunk_counts,
                   double* __restrict__ out, long long* __restrict__ src_idx) {
   __shared__ int wcount[4];
@@ -276,7 +277,7 @@ nb_scatter_kernel(const double* __restrict__ x,
   long long dst = chunk_counts[2 * blockIdx.x + 1];
   for (int k = 0; k < CHUNK / 256; ++k) {
     const long long i = base + k * 256 + threadIdx.x;
-    const bool keep = (i < n) && ((flags[i] & mask) != 0);
+    const bool keep = (i < n) && (((flags[i] ^ flip) & mask) != 0);
     const unsigned long long b = __ballot(keep);
     if (lane == 0) wcount[wave] = __popcll(b);
     __syncthreads();
@@ -432,7 +433,8 @@ int nb_launch_draw(const double* blob_dev, int n_dim, unsigned long long seed,
 long long nb_compact_chunks(long long n) { return (n + CHUNK - 1) / CHUNK; }
 
 int nb_launch_compact(const double* x, const unsigned char* flags,
-                      unsigned char mask, long long n, int n_dim, double* out,
+                      unsigned char mask, unsigned char flip, long long n,
+                      int n_dim, double* out,
                       long long* src_idx, long long* counts,
                       long long* chunk_counts, hipStream_t stream) {
   const long long n_chunks = nb_compact_chunks(n);
@@ -441,12 +443,13 @@ int nb_launch_compact(const double* x, const unsigned char* flags,
     return NB_OK;
   }
   hipLaunchKernelGGL(nb_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0,
-                     stream, flags, mask, n, chunk_counts);
+                     stream, flags, mask, flip, n, chunk_counts);
   hipLaunchKernelGGL(nb_scan_kernel, dim3(1), dim3(256), 0, stream,
                      chunk_counts, n_chunks, counts);
   if (out != nullptr)
     hipLaunchKernelGGL(nb_scatter_kernel, dim3((unsigned)n_chunks), dim3(256),
-                       0, stream, x, flags, mask, n, n_dim, chunk_counts, out,
+                       0, stream, x, flags, mask, flip, n, n_dim, chunk_counts,
+                       out,
                        src_idx);
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;

@@ -238,12 +238,14 @@ class DeviceBoundList:
             self._lib.nb_boundlist_destroy(h)
             self._h = None
 
-    def contains_any(self, x):
+    def contains_any(self, x, as_flags=False):
+        """mask[i] = any bound of the list contains x[i] (uint8 flags for the
+        compaction kernels with ``as_flags``)."""
         x = as_device_points(x, self.n_dim)
         mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
         _lib.check(self._lib.nb_contains_any(self._h, _ptr(x), x.shape[0],
                                              _ptr(mask), _stream()))
-        return mask.bool()
+        return mask if as_flags else mask.bool()
 
     def first_containing(self, x):
         x = as_device_points(x, self.n_dim)
@@ -478,8 +480,9 @@ def _buffer(role, shape, dtype, reuse):
     return buf[:n_bytes].view(dtype).view(shape)
 
 
-def compact_rows(x, flags, mask=1, want_index=False, reuse=False):
-    """Stable compaction of the rows of ``x`` with (flags & mask) != 0.
+def compact_rows(x, flags, mask=1, want_index=False, reuse=False, flip=0):
+    """Stable compaction of the rows of ``x`` with ((flags ^ flip) & mask)
+    != 0.
 
     Returns (rows, counts, src_idx): ``rows`` has x.shape[0] allocated rows of
     which the first counts[1] are valid; counts is an int64 device tensor
@@ -494,7 +497,7 @@ def compact_rows(x, flags, mask=1, want_index=False, reuse=False):
     src = (torch.empty(n, dtype=torch.int64, device='cuda')
            if want_index else None)
     _lib.check(lib.nb_compact_rows(
-        _ptr(x), _ptr(flags), mask, n, d, _ptr(out),
+        _ptr(x), _ptr(flags), mask, flip, n, d, _ptr(out),
         _ptr(src) if src is not None else None, _ptr(counts), _ptr(scratch),
         _stream()))
     return out, counts, src
@@ -511,6 +514,83 @@ def shell_stats(log_l, threshold=-np.inf):
     _lib.check(lib.nb_shell_stats(_ptr(log_l), n, float(threshold), _ptr(out),
                                   _ptr(scratch), _stream()))
     return out
+
+
+class LivePool:
+    """The n_live largest log-likelihoods of the exploration phase, kept on
+    the device (``nb_live_append`` / ``nb_live_select`` / ``nb_live_stats``;
+    reference nautilus/sampler.py:1147-1190 sorts every stored log L on
+    every iteration)."""
+
+    def __init__(self, k, tensors=()):
+        """Pool of the ``k`` largest values of ``tensors`` (all stored log L
+        at construction time; sized for them once, then for k + a few
+        batches)."""
+        self._lib = _lib.load()
+        self.k = int(k)
+        self._host = np.array([-np.inf, 0.0, 0.0, 0.0])
+        self._alloc(sum(int(t.shape[0]) for t in tensors) + 16)
+        for t in tensors:
+            self.add(t)
+        if self.dirty:
+            self.select()
+        keep = self.bufs[self.cur][:int(self.counts[self.cur])].clone()
+        thr = self.thr.clone()
+        self._alloc(4 * self.k + (1 << 17))
+        self.bufs[0][:keep.shape[0]] = keep
+        self.counts[0] = keep.shape[0]
+        self.thr.copy_(thr)
+
+    def _alloc(self, capacity):
+        self.cap = int(capacity)
+        self.bufs = [torch.empty(self.cap, dtype=torch.float64, device='cuda')
+                     for _ in range(2)]
+        self.counts = torch.zeros(3, dtype=torch.int32, device='cuda')
+        self.thr = torch.full((1,), -np.inf, dtype=torch.float64,
+                              device='cuda')
+        self.stats = torch.zeros(4, dtype=torch.float64, device='cuda')
+        self.cur = 0
+        self.dirty = False
+
+    def add(self, log_l):
+        """Append the values of a batch that reach the current threshold."""
+        if log_l.shape[0] == 0:
+            return
+        log_l = log_l.contiguous()
+        _lib.check(self._lib.nb_live_append(
+            _ptr(log_l), log_l.shape[0], _ptr(self.thr), _ptr(self.bufs[
+                self.cur]), _ptr(self.counts[self.cur:]), self.cap,
+            _ptr(self.counts[2:]), _stream()))
+        self.dirty = True
+
+    def select(self):
+        """(threshold, #above, #equal) of the k-th largest value; the pool
+        shrinks to the values that reach it."""
+        if self.dirty:
+            nxt = 1 - self.cur
+            _lib.check(self._lib.nb_live_select(
+                _ptr(self.bufs[self.cur]), _ptr(self.counts[self.cur:]),
+                self.cap, self.k, _ptr(self.bufs[nxt]),
+                _ptr(self.counts[nxt:]), _ptr(self.thr), _ptr(self.stats),
+                _stream()))
+            self.cur = nxt
+            self.dirty = False
+            self._host = torch.cat([self.stats[:3],
+                                    self.counts[2:].double()]).cpu().numpy()
+            if self._host[3] != 0:
+                raise OverflowError('live pool capacity exceeded')
+        return float(self._host[0]), int(self._host[1]), int(self._host[2])
+
+    def shell_stats(self, shells):
+        """Rows (#above, logsumexp above, #equal) for the log-L tensors of
+        ``shells`` against the current threshold -- one device reduction per
+        shell, ONE copy to the host."""
+        out = torch.zeros((max(1, len(shells)), 4), dtype=torch.float64,
+                          device='cuda')
+        for row, ll in zip(out, shells):
+            _lib.check(self._lib.nb_live_stats(
+                _ptr(ll), ll.shape[0], _ptr(self.thr), _ptr(row), _stream()))
+        return out[:len(shells), :3].cpu().numpy()
 
 
 def philox_uniform(seed, offset, block, tag, n):

@@ -173,6 +173,8 @@ class Sampler:
         self.shell_log_v = np.zeros(0, dtype=float)
         self.shell_n_sample_exp = np.zeros(0, dtype=int)
         self.shell_end_exp = np.zeros(0, dtype=int)
+        self._shell_max = np.zeros(0)   # per shell: largest stored log L
+        self._live = None               # device.LivePool (exploration)
         self._pts_t = torch.empty((0, self.n_dim), dtype=torch.float64,
                                   device='cuda')
         self.shell_t = np.zeros(0, dtype=int)
@@ -193,6 +195,7 @@ class Sampler:
     def __getstate__(self):
         state = dict(self.__dict__)
         state['_later'] = {}
+        state['_live'] = None
         state['comm'] = None
         state['_pts_t'] = self._pts_t.cpu().numpy()
         return state
@@ -268,18 +271,52 @@ class Sampler:
                       DeprecationWarning, stacklevel=2)
         return self.eta
 
-    def _weights_and_log_l(self):
-        per_point = np.repeat(
-            self.shell_log_v - np.log(np.maximum(self.shell_n, 1)),
-            self.shell_n)
-        return per_point, np.concatenate(self.log_l)
+    # -- the live set (exploration phase), on the device -------------------
+    def _live_pool(self):
+        """All log L at or above the n_live-th largest, maintained on the
+        device (device.LivePool).  Built from the points stored in the shells
+        -- transfer candidates waiting between shells do not count, as in the
+        reference, which concatenates ``self.log_l`` -- whenever a bound was
+        added (points leave their shells) or the sampler was unpickled /
+        resumed; in between every batch appends to it."""
+        pool = self.__dict__.get('_live')
+        if pool is None or pool.k != self.n_live:
+            pool = device.LivePool(self.n_live,
+                                   [ll.view() for ll in self._ll_dev])
+            self._live = pool
+            self._shell_max = np.array([
+                float(device.shell_stats(ll.view())[2]) if ll.n > 0
+                else -np.inf for ll in self._ll_dev])
+        return pool
 
-    def _live_slice(self, log_l):
-        """Indices of the n_live largest log_l values, ascending."""
-        if len(log_l) <= self.n_live:
-            return np.argsort(log_l)
-        part = np.argpartition(log_l, len(log_l) - self.n_live)
-        return part[len(log_l) - self.n_live:]
+    def _live_sums(self):
+        """(log sum of the weights of the n_live points of largest log L,
+        log sum of their volumes): sampler.py:1162-1169 and 1186-1190 with the
+        selection and the per-shell sums on the device.  Ties at the
+        threshold (likelihood plateaus) share the remaining places equally --
+        the reference takes an arbitrary subset of them."""
+        pool = self._live_pool()
+        try:
+            thr, n_gt, n_eq = pool.select()
+        except OverflowError:               # many batches without a selection
+            self._live = None
+            pool = self._live_pool()
+            thr, n_gt, n_eq = pool.select()
+        shells = [s for s in range(len(self._ll_dev))
+                  if self._ll_dev[s].n > 0 and self._shell_max[s] >= thr]
+        rows = pool.shell_stats([self._ll_dev[s].view() for s in shells])
+        frac = min(1.0, max(0.0, (self.n_live - n_gt) / n_eq)) if n_eq > 0 \
+            else 0.0
+        log_w, log_v = [-np.inf], [-np.inf]
+        for s, (c_gt, lse_gt, c_eq) in zip(shells, rows):
+            a = self.shell_log_v[s] - np.log(self.shell_n[s])
+            if c_gt > 0:
+                log_w.append(a + lse_gt)
+            if c_eq > 0 and frac > 0:
+                log_w.append(a + thr + np.log(frac * c_eq))
+            if c_gt + frac * c_eq > 0:
+                log_v.append(a + np.log(c_gt + frac * c_eq))
+        return logsumexp(log_w), logsumexp(log_v)
 
     @property
     def f_live(self):
@@ -288,18 +325,17 @@ class Sampler:
             return None
         if np.sum(self.shell_n) == 0:
             return 1.0
-        log_v, log_l = self._weights_and_log_l()
-        log_w = log_v + log_l
-        return np.exp(logsumexp(log_w[self._live_slice(log_l)]) -
-                      logsumexp(log_w))
+        # the weights of ALL points sum to the evidence (sampler.py:691-694)
+        return float(np.exp(self._live_sums()[0] - self.log_z))
 
     @property
     def log_v_live(self):
         """sampler.py:1171-1190."""
         if len(self.bounds) == 0:
             return 1.0
-        log_v, log_l = self._weights_and_log_l()
-        return logsumexp(log_v[self._live_slice(log_l)])
+        if np.sum(self.shell_n) == 0:
+            return -np.inf
+        return float(self._live_sums()[1])
 
     @property
     def discard_exploration(self):
@@ -398,7 +434,8 @@ class Sampler:
             if self.blobs is not None:
                 self.blobs.pop(s)
             for key in ('shell_n', 'shell_n_sample', 'shell_n_eff',
-                        'shell_log_l_min', 'shell_log_l', 'shell_log_v'):
+                        'shell_log_l_min', 'shell_log_l', 'shell_log_v',
+                        '_shell_max'):
                 setattr(self, key, np.delete(getattr(self, key), s))
         self._later = {}
         self.shell_n_sample_exp = np.copy(self.shell_n_sample)
@@ -460,23 +497,28 @@ class Sampler:
                 n_req = int(min(4 * device_block(), need / frac * 1.15 + 256))
             x = bound.sample_device(n_req)
             if later is not None:
-                keep = ~later.contains_any(x)             # sampler.py:796-798
-                csum = torch.cumsum(keep.to(torch.int64), 0)
-                total = int(csum[-1])
+                # sampler.py:796-799 on the device: flag the points inside a
+                # later bound, compact the others in order; the source row of
+                # the need-th survivor tells how many draws were examined
+                inside = later.contains_any(x, as_flags=True)
+                rows, counts, src = device.compact_rows(
+                    x, inside, mask=1, want_index=True, flip=1)
+                probe = torch.cat([counts, src[max(0, min(
+                    need, n_req) - 1):max(1, min(need, n_req))]]).cpu()
+                total = int(probe[1])
                 if total >= need:
                     # stop at the need-th success; the rest goes back
-                    pos = int(torch.searchsorted(csum, need))
-                    used = pos + 1
+                    used = int(probe[2]) + 1
                     if hasattr(bound, '_queue'):
                         bound._queue().unpop(n_req - used)
                     # (points of a bound without FIFO are i.i.d. draws; the
                     # unexamined tail is independent of the stopping rule
                     # and is simply dropped)
-                    x, keep = x[:used], keep[:used]
+                    x = rows[:need]
                 else:
                     used = n_req
+                    x = rows[:total]
                 n_bound += used
-                x = x[keep]
             else:
                 n_bound += n_req
 
@@ -581,9 +623,13 @@ class Sampler:
             start = 0
         ll = self._ll_dev[index].view()[start:]
         n = ll.shape[0]
+        if len(self._shell_max) != len(self._ll_dev):     # resumed / unpickled
+            self._shell_max = np.full(len(self._ll_dev), np.inf)
         self.shell_n[index] = n
         if n > 0:
             st = device.shell_stats(ll).cpu().numpy()
+            if start == 0:
+                self._shell_max[index] = st[2]
             self.shell_log_v[index] = (self.bounds[index].log_v +
                                        np.log(n / n_sample))
             self.shell_log_l[index] = st[0] - np.log(n)
@@ -592,6 +638,8 @@ class Sampler:
             else:
                 self.shell_n_eff[index] = n
         else:
+            if start == 0:
+                self._shell_max[index] = -np.inf
             self.shell_log_v[index] = -np.inf
             self.shell_log_l[index] = np.nan
             self.shell_n_eff[index] = 0
@@ -612,8 +660,10 @@ class Sampler:
             if len(idx_t) > 0:
                 sel = torch.from_numpy(idx_t).cuda()
                 self._pts[-1].append(self._pts_t[sel])
-                self._ll_dev[-1].append(
-                    torch.from_numpy(self.log_l_t[idx_t]).cuda())
+                moved = torch.from_numpy(self.log_l_t[idx_t]).cuda()
+                self._ll_dev[-1].append(moved)
+                if self.__dict__.get('_live') is not None:
+                    self._live.add(moved)
                 self.log_l[-1] = np.concatenate(
                     (self.log_l[-1], self.log_l_t[idx_t]))
                 if self.blobs is not None:
@@ -633,6 +683,8 @@ class Sampler:
         t2 = time()
         self._pts[shell].append(pts)
         self._ll_dev[shell].append(log_l_dev)
+        if not self.explored and self.__dict__.get('_live') is not None:
+            self._live.add(log_l_dev)
         self.log_l[shell] = np.append(self.log_l[shell], log_l)
         if blobs is not None:                      # sampler.py:1137-1141
             if self.blobs is None:
@@ -813,6 +865,7 @@ class Sampler:
         self.shell_n = np.append(self.shell_n, 0)
         self.shell_n_sample = np.append(self.shell_n_sample, 0)
         self.shell_n_eff = np.append(self.shell_n_eff, 0)
+        self._shell_max = np.append(self._shell_max, -np.inf)
         self.shell_log_l = np.append(self.shell_log_l, np.nan)
         self.shell_log_v = np.append(self.shell_log_v, np.nan)
         self.shell_log_l_min = np.append(self.shell_log_l_min, log_l_min)
@@ -859,6 +912,9 @@ class Sampler:
                 self.log_l_t = np.zeros(0)
                 if self.blobs is not None:
                     self.blobs_t = self.blobs[0][:0]
+        # points left their shells for the transfer set: the live pool is
+        # rebuilt from the shells on its next use
+        self._live = None
         self.timing['add_bound'] += time() - t0
         return True
 

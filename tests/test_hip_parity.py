@@ -810,3 +810,38 @@ def test_benchmark_likelihoods_match_numpy(dev):
                       for m in means], axis=0) - np.log(4)
     assert np.allclose(mix(torch.from_numpy(u).cuda()).cpu().numpy(), want,
                        rtol=1e-11, atol=1e-8)
+
+
+def test_comm_c_abi_single_rank(dev):
+    """nb_comm_* (RCCL through the C ABI): a one-rank communicator -- the
+    all-gather is a copy, the all-reduce the identity; rank keys as in
+    parallel.rank_key.  (More ranks need one GPU per rank: the driver's
+    multi-GPU run; the collective pattern itself is covered by the gloo
+    tests.)"""
+    import ctypes as C
+    from nautilus_amd import _lib, parallel
+    lib = _lib.load()
+    uid = (C.c_uint8 * 128)()
+    if lib.nb_comm_unique_id(uid) != 0:
+        pytest.skip('RCCL not available: ' +
+                    lib.nb_last_error().decode())
+    comm = C.c_void_p()
+    _lib.check(lib.nb_comm_init(0, 1, uid, C.byref(comm)))
+    try:
+        x = torch.arange(1000, dtype=torch.float64, device='cuda') * 0.5
+        y = torch.zeros_like(x)
+        _lib.check(lib.nb_comm_allgather_f64(
+            comm, C.c_void_p(x.data_ptr()), 1000, C.c_void_p(y.data_ptr()),
+            None))
+        c = torch.tensor([3, -7, 2**40], dtype=torch.int64, device='cuda')
+        _lib.check(lib.nb_comm_allreduce_i64(comm, C.c_void_p(c.data_ptr()),
+                                             3, None))
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+        assert c.cpu().tolist() == [3, -7, 2**40]
+    finally:
+        lib.nb_comm_destroy(comm)
+    for seed in (0, 123456789, 2**62 + 5):
+        for r in range(8):
+            assert lib.nb_comm_rank_key(seed, r) == parallel.rank_key(seed, r)
+    assert lib.nb_comm_init(2, 2, uid, C.byref(comm)) != 0     # bad rank
