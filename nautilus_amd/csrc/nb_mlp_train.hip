@@ -252,11 +252,26 @@ __device__ __forceinline__ void fb_gather(const TrainArgs& a, int net, int tile,
   in.yv = (wave == 0 && lg == 0 && valid) ? a.y[in.row] : 0.0;
 }
 
+#ifdef NB_TRAIN_TIMING
+__device__ long long g_train_ticks[64];
+#define FB_STAMP(i)                                                           \
+  do {                                                                        \
+    if (net == 0 && tile == 0 && threadIdx.x == 0) {                          \
+      const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
+      g_train_ticks[i] += t_now - fb_prev;                                    \
+      fb_prev = t_now;                                                        \
+    }                                                                         \
+  } while (0)
+#else
+#define FB_STAMP(i)
+#endif
+
 template <int DT, bool CHECK_DONE>
 __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
                                         int net, int tile, int ep,
                                         long long start, int nb,
-                                        const FbRows<DT>& rows) {
+                                        const FbRows<DT>& rows,
+                                        bool zero_input) {
   constexpr int KS1MAX = 4 * DT + 1;
   constexpr int LD0MAX = 16 * (DT + 1);
   // activations / deltas of the tile in [unit][row] layout
@@ -294,40 +309,47 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   const int pt = tile * 16 + li;
   const bool valid = pt < nb;
 
-  // ---- every weight operand this wavefront will need, loaded up front: the
-  // loads do not depend on the other wavefronts, so their latency overlaps
-  // with the input gather instead of being paid after every barrier --------
+  // ---- weight operands: every wavefront loads the A operands of ITS output
+  // tiles straight into registers, one layer ahead of their use.  A wavefront
+  // can only keep ~64 vector-memory instructions in flight: issuing all ~110
+  // loads of the step up front (as an earlier version did) stalls it until
+  // half of them have returned -- 4.5 us of the step.  Now layer 1 (+ layer 2
+  // for n_dim <= 64) goes out first, the rest after the layer-1 products
+  // (the barriers between the layers are compiler barriers for memory
+  // operations, so the loads stay where they are written; they only wait
+  // for LDS, so operands stay in flight across them). ----------------------
+#ifdef NB_TRAIN_TIMING
+  long long fb_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
   double w1r[2][KS1MAX], w2r[26], w3r[13], w4r[6], b4r[1], b3r[5], b2r[2][13];
-  // (issued in the order of use: loads return in order and the barriers
-  // between the layers only wait for LDS, so a layer waits for its own
-  // operands while the later ones are still in flight)
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
     const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
     load_fwd<KS1MAX>(W1, NB_HT1, ht, ks1, lane, w1r[rep]);
   }
-  load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
-  load_fwd<13>(W3, NB_HT3, wave & 1, 13, lane, w3r);
-  load_fwd<6>(W4, 1, 0, 6, lane, w4r);
-  load_bwd<1>(W4, 1, wave & 1, lane, b4r);
-  load_bwd<5>(W3, NB_HT3, wave, lane, b3r);
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
-    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
-  }
+  if constexpr (DT <= 4) load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
 
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
   // (all of it: rows >= ld0 are multiplied by zero weights and must not
   // hold NaN bit patterns)
-  for (int i = threadIdx.x; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
+  // (the padding only has to be cleared once per launch: every step rewrites
+  // exactly the rows below ld0)
+  if (zero_input) {
+    for (int i = threadIdx.x; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
+  }
   lds_barrier();
+  FB_STAMP(10);
 #pragma unroll
   for (int j = 0; j < DT + 1; ++j) {
     const int ks = 4 * j + wave;
     if (ks < KS1MAX && 4 * ks < ld0) sA0[(4 * ks + lg) * LS + li] = rows.x[j];
   }
   lds_barrier();
+  FB_STAMP(11);
+  if constexpr (DT > 4) load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
+  // the stash for the G phase is written as soon as a block is complete
+  // (coalesced, fire and forget: the stores overlap the next layer)
+  flush_stash(sA0, A0, ld0, ld0, tile);
 
   // ---- layer 1: output tiles wave, wave + 4 ------------------------------
   {
@@ -349,6 +371,18 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     }
   }
   lds_barrier();
+  FB_STAMP(12);
+  // the remaining operands, in the order of use (in flight during layer 2)
+  load_fwd<13>(W3, NB_HT3, wave & 1, 13, lane, w3r);
+  load_fwd<6>(W4, 1, 0, 6, lane, w4r);
+  load_bwd<1>(W4, 1, wave & 1, lane, b4r);
+  load_bwd<5>(W3, NB_HT3, wave, lane, b3r);
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
+    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
+  }
+  flush_stash(sA1, A1, LD1, LD1, tile);
 
   // ---- layer 2: output tile = wave ----------------------------------------
   {
@@ -364,6 +398,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     }
   }
   lds_barrier();
+  FB_STAMP(13);
+  flush_stash(sA2, A2, LD2, LD2, tile);
 
   // ---- layer 3: two output tiles ------------------------------------------
   if (wave < NB_HT3) {
@@ -379,6 +415,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     }
   }
   lds_barrier();
+  FB_STAMP(14);
+  flush_stash(sA3, A3, LD3, LD3, tile);
 
   // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
   if (wave == 0) {
@@ -398,6 +436,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     if (lane == 0) st.scal[8 + tile] = lp;
   }
   lds_barrier();
+  FB_STAMP(15);
+  flush_stash(sD4, D4, LD4, LD4, tile);
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
   if (wave < NB_HT3) {
@@ -413,6 +453,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     }
   }
   lds_barrier();
+  FB_STAMP(16);
+  flush_stash(sD3, D3, LD3, LD3, tile);
 
   // ---- delta 2 --------------------------------------------------------------
   {
@@ -428,6 +470,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     }
   }
   lds_barrier();
+  FB_STAMP(17);
+  flush_stash(sD2, D2, LD2, LD2, tile);
 
   // ---- delta 1 --------------------------------------------------------------
   {
@@ -449,14 +493,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     }
   }
 
-  // ---- stash for the G kernel, written once and coalesced ------------------
-  flush_stash(sA0, A0, ld0, ld0, tile);
-  flush_stash(sA1, A1, LD1, LD1, tile);
-  flush_stash(sA2, A2, LD2, LD2, tile);
-  flush_stash(sA3, A3, LD3, LD3, tile);
-  flush_stash(sD4, D4, LD4, LD4, tile);
-  flush_stash(sD3, D3, LD3, LD3, tile);
-  flush_stash(sD2, D2, LD2, LD2, tile);
+  FB_STAMP(18);
 }
 
 template <int DT>
@@ -466,7 +503,7 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   FbRows<DT> rows;
   fb_gather<DT>(a, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb, rows);
   fb_body<DT, true>(a, st, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb,
-                    rows);
+                    rows, true);
 }
 
 // ---- G: dW of one 16x16 weight tile over the minibatch + Adam, one wavefront
@@ -573,6 +610,7 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
   }
 }
 
+
 __global__ void __launch_bounds__(64)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
   const NetState st = a.nets[blockIdx.y];
@@ -676,6 +714,19 @@ __global__ void nb_xcc_probe_kernel(int* out) {
   }
 }
 
+#ifdef NB_TRAIN_TIMING
+#define TR_STAMP(i)                                                           \
+  do {                                                                        \
+    if (net == 0 && slot == 0 && threadIdx.x == 0) {                          \
+      const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
+      g_train_ticks[i] += t_now - t_prev;                                     \
+      t_prev = t_now;                                                         \
+    }                                                                         \
+  } while (0)
+#else
+#define TR_STAMP(i)
+#endif
+
 template <int DT>
 __global__ void __launch_bounds__(256)
 nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
@@ -713,6 +764,10 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   long long t_adam = t_adam0;
   FbRows<DT> rows;
   bool have_rows = false;        // rows = the slice of the step about to run
+  bool zero_input = true;        // the padding of the input block, once
+#ifdef NB_TRAIN_TIMING
+  long long t_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
   for (int ep = 0; ep < a.n_epochs; ++ep) {
     // uniform over the network's workgroups: the flag only changes in
     // epoch_body, which is followed by a barrier
@@ -722,19 +777,27 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
       t_adam += 1;
       if (done) continue;
+      TR_STAMP(0);
       if (slot * 16 < nb) {
         if (!have_rows) fb_gather<DT>(a, net, slot, ep, start, nb, rows);
-        fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows);
+        fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows, zero_input);
+        zero_input = false;
       }
+      TR_STAMP(1);
       // (the step size -- two pow() -- is computed while waiting)
       xcd_arrive(counter);
       const double lr_t = adam_lr(a, t_adam);
       xcd_wait(counter, err, phase, XCD_SLOTS);
-      // weight tiles 0 .. n_gt - 1, task n_gt = the loss fold
+      TR_STAMP(2);
+      // weight tiles 0 .. n_gt - 1, task n_gt = the loss fold.  (Measured and
+      // rejected: groups of four tiles sharing one operand block staged in
+      // LDS -- 37 % fewer bytes per CU, but the extra barrier and the
+      // LDS round trip cost 4 us per step.)
       for (int gt = slot * 4 + wave; gt <= n_gt; gt += XCD_SLOTS * 4) {
         if (gt < n_gt) g_body<false>(a, st, gt, lane, nb, lr_t);
         else if (lane == 0) loss_fold(st, nb);
       }
+      TR_STAMP(3);
       xcd_arrive(counter);
       {
         // rows of the next step (next epoch's permutation after the last one)
@@ -746,6 +809,7 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
         if (have_rows) fb_gather<DT>(a, net, slot, ep2, start2, nb2, rows);
       }
       xcd_wait(counter, err, phase, XCD_SLOTS);
+      TR_STAMP(4);
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
         return;
@@ -1048,6 +1112,15 @@ int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs,
   icpts[3][0] = get_w(w4, 1, NB_H3, 0);
   return NB_OK;
 }
+
+#ifdef NB_TRAIN_TIMING
+int nb_dbg_train_times(long long* out) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_train_ticks), 64 * sizeof(long long));
+  long long zero[64] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_train_ticks), zero, sizeof zero);
+  return 0;
+}
+#endif
 
 int nb_trainer_destroy(nb_trainer* t) {
   if (t == nullptr) return NB_OK;

@@ -935,9 +935,13 @@ class Sampler:
         pts = torch.cat([p.view()[s:] for p, s in zip(self._pts, start)]
                         ).cpu().numpy()
         log_l = np.concatenate([ll[s:] for ll, s in zip(self.log_l, start)])
-        log_w = np.repeat(self.shell_log_v -
-                          np.log(np.maximum(self.shell_n, 1)),
-                          self.shell_n) + log_l
+        # log w_i = shell_log_v - log shell_n + log L_i (sampler.py:602-608),
+        # per shell on the device; their normalisation is the evidence, which
+        # the per-shell device reductions already hold (sampler.py:691-694)
+        offset = self.shell_log_v - np.log(np.maximum(self.shell_n, 1))
+        log_w = torch.cat([ll.view()[s:] + float(o) for ll, s, o in
+                           zip(self._ll_dev, start, offset)]).cpu().numpy()
+        log_norm = self.log_z if np.sum(self.shell_n) > 0 else 0.0
         blobs = None
         if return_blobs:
             blobs = np.concatenate([b[s:] for b, s in zip(self.blobs, start)])
@@ -963,9 +967,11 @@ class Sampler:
         if not return_as_dict and callable(self.prior) and self.pass_dict:
             raise ValueError('Cannot return points as numpy array. The prior '
                              'function only returns dictionaries.')
+        if equal_weight:
+            log_norm = logsumexp(log_w)
         if return_blobs:
-            return pts, log_w - logsumexp(log_w), log_l, blobs
-        return pts, log_w - logsumexp(log_w), log_l
+            return pts, log_w - log_norm, log_l, blobs
+        return pts, log_w - log_norm, log_l
 
     def write(self, filepath, overwrite=False):
         """Write the sampler to an HDF5 file in the reference's layout
