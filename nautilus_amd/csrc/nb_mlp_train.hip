@@ -568,6 +568,19 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
     kt = g; ht = 0; As = A3; lda = LD3; Bs = D4; ldb = LD4;
     woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
   }
+#ifdef NB_TRAIN_TIMING
+  long long g_prev = (long long)__builtin_amdgcn_s_memtime();
+#define G_STAMP(i)                                                            \
+  do {                                                                        \
+    if (!STANDALONE && gt == 0 && lane == 0) {                                \
+      const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
+      g_train_ticks[i] += t_now - g_prev;                                     \
+      g_prev = t_now;                                                         \
+    }                                                                         \
+  } while (0)
+#else
+#define G_STAMP(i)
+#endif
   // dW tile = act^T delta over the rows of the minibatch (fixed order).  All
   // operand loads are issued before the first MFMA (one memory latency per
   // tile instead of one per k-step).
@@ -589,12 +602,14 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
     const long long idx = woff + (lg + 4 * r) * 16 + li;
     w_old[r] = st.W[idx]; m_old[r] = st.M[idx]; v_old[r] = st.V[idx];
   }
+  G_STAMP(30);
   nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
   for (int s = 0; s < MAXS; s += 2) {
     acc0 = MFMA(av[s], bv[s], acc0);
     acc1 = MFMA(av[s + 1], bv[s + 1], acc1);
   }
+  G_STAMP(31);
 
   // Adam (sklearn _stochastic_optimizers.py:255-287), in place
   const double inv_nb = 1.0 / (double)nb;
