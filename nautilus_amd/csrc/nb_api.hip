@@ -425,7 +425,7 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
     if (nd.mlp != nullptr) {
       for (int f = 0; f < n_dim; ++f) {
         mean[f] = nd.mlp->mean[f];
-        scale[f] = nd.mlp->scale[f];
+        scale[f] = 1.0 / nd.mlp->scale[f];   // the kernel multiplies
       }
       for (int e = 0; e < E; ++e)
         fill_net(scale + dp + (size_t)e * net_stride, n_dim, kt1,

@@ -575,10 +575,10 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
 #pragma unroll
             for (int ks = 0; ks < 4 * DT; ++ks) {
               const int f = 4 * ks + lg;
-              const double mv = mean[f], sv = scale[f];
+              const double mv = mean[f], sv = scale[f];     // sv = 1 / scale
 #pragma unroll
               for (int t = 0; t < TPW; ++t)
-                tin[t][ks] = (f < n_dim) ? (y[t][ks] - mv) / sv
+                tin[t][ks] = (f < n_dim) ? (y[t][ks] - mv) * sv
                                          : ((f == n_dim) ? 1.0 : 0.0);
             }
 #pragma unroll
