@@ -464,7 +464,7 @@ def main():
                                   '--pmc-traffic); committed measurements: '
                                   'profiles/r02/')
     if args.pmc_traffic and rank == 0 and world == 1:
-        got = pmc_traffic(sys.argv[1:], 'nb_eval_kernel')
+        got = pmc_traffic(sys.argv[1:], 'nb_eval_')
         if got is not None:
             traffic = got['bytes_per_launch']
             traffic_src = ('rocprofv3 --pmc child passes of this command: '
@@ -474,7 +474,11 @@ def main():
                                got['write_bytes_per_launch'],
                                got['launches']))
     roofline = dict(
-        kernel='nb_eval_kernel', bound='mfma', achieved=achieved_tf,
+        kernel='nb_eval_fast_kernel + nb_eval_kernel', kernel_note=(
+            'bound evaluation of the timed steps: proposal acceptance runs '
+            'in nb_eval_fast_kernel, shell exclusion in nb_eval_kernel; '
+            'launches and time are those of both'),
+        bound='mfma', achieved=achieved_tf,
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
         frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=traffic,
         traffic_unit='bytes/launch', traffic_source=traffic_src,

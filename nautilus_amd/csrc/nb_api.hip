@@ -13,6 +13,11 @@
 #include <vector>
 
 // launchers implemented in the kernel translation units
+bool nb_eval_fast_eligible(int n_dim, int K, int M, int E, bool sample);
+int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample,
+                        const double* x, long long n, unsigned char* out_u8,
+                        double* out_f64, unsigned long long seed,
+                        unsigned long long offset, hipStream_t stream);
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
                    int* out_i32, double* out_f64, unsigned long long seed,
@@ -550,6 +555,11 @@ int nb_neural_score(const nb_bound* b, const double* x, int64_t n, double* out,
     nb_set_error("bound has no neural bound");
     return NB_ERR_ARG;
   }
+#ifndef NB_NO_FAST_EVAL
+  if (nb_eval_fast_eligible(b->n_dim, b->K, b->M, b->E, false))
+    return nb_launch_eval_fast(b->blob_dev, b->n_dim, false, x, n, nullptr,
+                               out, 0, 0, as_stream(stream));
+#endif
   return nb_launch_eval(b->dt, b->self_list_dev, 1, 4, x, n, nullptr, nullptr,
                         out, 0, 0, as_stream(stream));
 }
@@ -566,6 +576,12 @@ int nb_propose(const nb_bound* b, uint64_t seed, uint64_t offset, int64_t n,
 
 int nb_accept(const nb_bound* b, uint64_t seed, uint64_t offset,
               const double* x, int64_t n, uint8_t* flags, void* stream) {
+#ifndef NB_NO_FAST_EVAL
+  // one neural bound, at most one outer member: the pipelined kernel
+  if (nb_eval_fast_eligible(b->n_dim, b->K, b->M, b->E, true))
+    return nb_launch_eval_fast(b->blob_dev, b->n_dim, true, x, n, flags,
+                               nullptr, seed, offset, as_stream(stream));
+#endif
   return nb_launch_eval(b->dt, b->self_list_dev, 1, 2, x, n, flags, nullptr,
                         nullptr, seed, offset, as_stream(stream));
 }

@@ -871,6 +871,7 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
 
 static unsigned long long* g_eval_counters = nullptr;
 void nb_eval_set_counters(unsigned long long* dev) { g_eval_counters = dev; }
+unsigned long long* nb_eval_counters() { return g_eval_counters; }
 
 // host entry used by nb_api.cpp
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,

@@ -257,6 +257,74 @@ def test_neural_bound_large_dims(dev, d, e):
                           any_o[~edge])
 
 
+@pytest.mark.parametrize('d,e,k_outer', [
+    (1, 1, 1), (3, 2, 1), (15, 1, 1), (16, 2, 1), (17, 1, 0), (31, 2, 1),
+    (32, 1, 1), (33, 3, 1), (47, 1, 1), (48, 2, 0), (49, 1, 1), (50, 4, 1),
+    (62, 2, 1), (63, 1, 1), (64, 2, 1)])
+def test_pipelined_accept_and_score(dev, d, e, k_outer):
+    """nb_accept / nb_neural_score of a bound with ONE neural bound and at
+    most one outer member run through the pipelined kernel (nb_eval_fast.hip)
+    for n_dim <= 63 -- every (DT, KT1) instantiation, n_dim = 16 DT included,
+    where layer 1 needs one more k-tile; n_dim = 64 stays on nb_eval.hip.
+    Launch sizes: below one pass, ragged tails, and more 128-point passes than
+    workgroups (the points of the next pass are prefetched during the last
+    stage).  Oracle: union.py:313-319 + neural.py:115-126 on the same Philox
+    stream."""
+    from oracle import bounds_oracle as bo
+    from oracle import mlp_oracle as mo
+    from oracle import philox
+    rng = np.random.default_rng(77 * d + e)
+    nets = [mo.glorot_init(d, i)[:2] for i in range(e)]
+    mean, scale = rng.normal(size=d) * 0.1, rng.uniform(0.5, 1.5, d)
+    emu = mo.Emulator.from_weights(mean, scale, nets)
+    b_mat = np.tril(rng.normal(size=(d, d)) * 0.02) + np.eye(d) * 0.4
+    centre = np.full(d, 0.5)
+    centre[0] = 0.8                         # part of the ellipsoid leaves the cube
+    ell = bo.OEllipsoid.from_params(centre, b_mat)
+    nb = bo.ONeural()
+    nb.outer_bound, nb.n_dim, nb.emulator = ell, d, emu
+    outer = None
+    if k_outer:
+        outer = bo.OUnion.from_members(
+            [bo.OEllipsoid.from_params(centre, 1.05 * b_mat)], unit=True)
+    probe = centre + (rng.normal(size=(4000, d)) @ b_mat.T) * (
+        0.7 / np.sqrt(d))
+    nb.score_predict_min = float(np.median(emu.predict(ell.transform(probe))))
+    if k_outer:
+        b = upload(bo.ONautilus.from_parts(outer, [nb]))
+    else:       # unit cube as the only outer bound
+        from helpers import neural_from_oracle
+        b = dev.DeviceBound(d, [], None, True, [neural_from_oracle(nb)])
+    seed, offset = 11 + d, 10**11 + 3
+    for n in (1, 127, 128, 129, 5000, 40000):
+        if k_outer:
+            x, _, _ = philox.union_propose(outer, seed, offset, n)
+            assert np.allclose(b.propose(seed, offset, n).cpu().numpy(), x,
+                               rtol=0, atol=1e-12)
+        else:
+            x = centre + (rng.normal(size=(n, d)) @ b_mat.T) * (
+                0.9 / np.sqrt(d))
+        xd = torch.as_tensor(x, device='cuda')
+        y = ell.transform(x)
+        r2_o, score_o = np.sum(y**2, axis=1), emu.predict(y)
+        r2, score = b.neural_score(xd)
+        assert np.allclose(r2.cpu().numpy(), r2_o, rtol=1e-12, atol=1e-13)
+        assert np.allclose(score.cpu().numpy(), score_o, rtol=0, atol=1e-10)
+        flags = b.accept(seed, offset, xd).cpu().numpy()
+        g = np.uint64(offset) + np.arange(n, dtype=np.uint64)
+        _, u_acc = philox.uniform_pair(seed, g, 0, philox.TAG_CTRL)
+        in_cube = np.all((x >= 0) & (x < 1), axis=1)
+        keep = in_cube & (u_acc > 0 if k_outer else True)
+        inside = (r2_o < 1) & (score_o > nb.score_predict_min - 1e-9)
+        edge = (near_boundary(score_o, nb.score_predict_min - 1e-9, 1e-9) |
+                near_boundary(r2_o, 1.0, 1e-12))
+        assert np.array_equal(flags & 1, keep.astype(np.uint8))
+        want = (keep & inside).astype(np.uint8)
+        assert np.array_equal((flags >> 1)[~edge], want[~edge])
+        if n >= 5000:
+            assert 0.002 < want.mean() < 0.998
+
+
 @pytest.fixture(scope='module')
 def nautilus_d4():
     from helpers import nautilus_from_golden
