@@ -35,7 +35,7 @@
 #define NBF_P2 4
 #endif
 #ifndef NBF_TB
-#define NBF_TB 2                  // DMA instructions per tick
+#define NBF_TB 1                  // DMA instructions per tick
 #endif
 #ifndef NBF_PD3
 #define NBF_PD3 2

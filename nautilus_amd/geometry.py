@@ -25,7 +25,29 @@ import xxhash
 from scipy.linalg.lapack import dpotrf, dpotri
 from scipy.optimize import minimize
 from scipy.special import gammaln, logsumexp
+from contextlib import contextmanager
+
 from threadpoolctl import threadpool_limits
+
+_BLAS_LIMITED = 0
+
+
+@contextmanager
+def single_threaded_blas():
+    """Host BLAS pinned to one thread, as the reference does around the bound
+    construction (sampler.py:1022): it works on tiny matrices.  Re-entrant:
+    only the outermost region pays for threadpoolctl's library scan (~1 ms,
+    which added up to 2 % of an exploration when every MVEE batch did it)."""
+    global _BLAS_LIMITED
+    if _BLAS_LIMITED:
+        yield
+        return
+    _BLAS_LIMITED += 1
+    try:
+        with threadpool_limits(limits=1):
+            yield
+    finally:
+        _BLAS_LIMITED -= 1
 
 
 def inv_spd(m):
@@ -122,7 +144,7 @@ def run_tasks(tasks):
             out[i] = stop.value
     while pending:
         idx = list(pending)
-        with threadpool_limits(limits=1):
+        with single_threaded_blas():
             res = mvee_batch([pending[i] for i in idx])
         pending = {}
         for i, r in zip(idx, res):
@@ -259,7 +281,7 @@ def _best_of_inits_host(points_t, random_state):
     and it is the reference's own estimator for this step (union.py:185-187),
     so it decides."""
     from sklearn.mixture import GaussianMixture
-    with threadpool_limits(limits=1):
+    with single_threaded_blas():
         return GaussianMixture(n_components=2, n_init=N_INIT,
                                random_state=random_state).fit(points_t)
 

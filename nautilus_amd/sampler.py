@@ -31,9 +31,8 @@ from time import time
 import numpy as np
 import torch
 from scipy.special import logsumexp
-from threadpoolctl import threadpool_limits
 
-from . import device
+from . import device, geometry
 from .bounds import NautilusBound, UnitCube
 from .pool import NautilusPool, likelihood_worker
 
@@ -833,7 +832,7 @@ class Sampler:
                     torch.from_numpy(order).cuda()]
                 # host BLAS pinned to one thread as in the reference
                 # (sampler.py:1022): the construction works on tiny matrices
-                with threadpool_limits(limits=1):
+                with geometry.single_threaded_blas():
                     bound = NautilusBound.compute(
                         pts, log_l, log_l_min, self.log_v_live,
                         enlarge_per_dim=self.enlarge_per_dim,
