@@ -147,6 +147,21 @@ class _DeviceBoundBase(_Persistent):
 # primitive bounds
 # ---------------------------------------------------------------------------
 
+def minimum_volume_enclosing_ellipsoid(points, n_max=100, n_batch=20):
+    """Reference bounds/basic.py:175-241 under its own name: centre ``c``,
+    shape matrix ``A`` ((x - c)^T A (x - c) <= 1) and ``A^-1`` of the batched
+    Khachiyan iteration, computed on the device (``geometry.mvee``)."""
+    return geometry.mvee(points, n_max, n_batch)
+
+
+def invert_symmetric_positive_semidefinite_matrix(m):
+    """Reference bounds/basic.py:154-172: inverse through the Cholesky factor
+    (a single small matrix: host LAPACK)."""
+    from scipy.linalg import cho_factor, cho_solve
+    m = np.asarray(m, dtype=float)
+    return cho_solve(cho_factor(m, lower=True), np.eye(len(m)))
+
+
 class UnitCube(_DeviceBoundBase):
     """Unit hypercube (reference bounds/basic.py:9-151)."""
 

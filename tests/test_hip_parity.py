@@ -389,6 +389,13 @@ def test_mvee_kernel_matches_reference(dev, d):
     u_h = khachiyan_weights_numpy(pts)
     assert np.allclose(u, u_h, rtol=0, atol=1e-9)
     c, a, a_inv = geometry.mvee(pts)
+    # the reference's module-level names (bounds/basic.py:154, 175)
+    from nautilus_amd import bounds
+    c2, a2, a2_inv = bounds.minimum_volume_enclosing_ellipsoid(pts)
+    assert np.array_equal(c, c2) and np.array_equal(a, a2)
+    assert np.allclose(
+        bounds.invert_symmetric_positive_semidefinite_matrix(a), a_inv,
+        rtol=1e-9, atol=1e-12 * np.abs(a_inv).max())
     assert np.allclose(c, c_o, rtol=0, atol=1e-9)
     assert np.allclose(a, a_o, rtol=1e-7, atol=1e-8 * np.abs(a_o).max())
     # every point inside, at least one on the surface (basic.py:236-239)
