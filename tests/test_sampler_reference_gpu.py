@@ -166,3 +166,91 @@ def test_plateau_staircase():
     assert np.isclose(s.log_z, log_z_true, atol=0.1)
     assert np.all(np.isclose(s.shell_log_l_min[1:],
                              np.arange(len(s.bounds) - 1) + 2, rtol=0))
+
+
+# ---- blobs (the reference's tests/test_blobs.py) ---------------------------
+
+def _blob_run(like, vectorized, discard, **kwargs):
+    from nautilus_amd import Sampler
+    s = Sampler(_identity, like, n_dim=2, n_live=200, vectorized=vectorized,
+                n_networks=0, **kwargs)
+    s.run(f_live=0.2, n_like_max=2000, discard_exploration=discard)
+    return s
+
+
+def _ll(x):
+    return -np.linalg.norm(x - 0.5, axis=-1) * 0.001
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.int64])
+@pytest.mark.parametrize('vectorized', [True, False])
+@pytest.mark.parametrize('discard', [True, False])
+def test_blobs_single(dtype, vectorized, discard):
+    """tests/test_blobs.py:14-39: one blob keeps its dtype and follows its
+    point, also through equal-weight resampling."""
+    def like(x):
+        if vectorized:
+            return _ll(x), (10 * x[:, 0]).astype(dtype)
+        return _ll(x), dtype(10 * x[0])
+    s = _blob_run(like, vectorized, discard)
+    s.posterior(return_blobs=True)
+    points, _, _, blobs = s.posterior(return_blobs=True, equal_weight=True)
+    assert len(points) == len(blobs)
+    assert blobs.dtype == dtype
+    assert np.all((10 * points[:, 0]).astype(dtype) == blobs)
+
+
+@pytest.mark.parametrize('vectorized', [True, False])
+@pytest.mark.parametrize('discard', [True, False])
+def test_blobs_multi(vectorized, discard):
+    """tests/test_blobs.py:42-65: several blobs become the fields blob_0,
+    blob_1 with their own dtypes."""
+    def like(x):
+        if vectorized:
+            return (_ll(x), x[:, 0].astype(np.float32),
+                    x[:, 1].astype(np.float32))
+        return _ll(x), np.float32(x[0]), np.float32(x[1])
+    s = _blob_run(like, vectorized, discard)
+    points, _, _, blobs = s.posterior(return_blobs=True)
+    assert len(points) == len(blobs)
+    assert blobs['blob_0'].dtype == np.float32
+    assert blobs['blob_1'].dtype == np.float32
+    assert np.all(points[:, 0].astype(np.float32) == blobs['blob_0'])
+    assert np.all(points[:, 1].astype(np.float32) == blobs['blob_1'])
+
+
+def _two_blobs(vectorized):
+    def like(x):
+        if vectorized:
+            return _ll(x), x[:, 0], x[:, 1]
+        return _ll(x), x[0], x[1]
+    return like
+
+
+@pytest.mark.parametrize('vectorized', [True, False])
+@pytest.mark.parametrize('discard', [True, False])
+def test_blobs_structured_dtype(vectorized, discard):
+    """tests/test_blobs.py:68-91: a structured ``blobs_dtype`` (bytes and
+    int16 fields)."""
+    dt = [('a', '|S10'), ('b', np.int16)]
+    s = _blob_run(_two_blobs(vectorized), vectorized, discard, blobs_dtype=dt)
+    points, _, _, blobs = s.posterior(return_blobs=True)
+    assert len(points) == len(blobs)
+    assert blobs['a'].dtype == dt[0][1] and blobs['b'].dtype == dt[1][1]
+    assert np.all(points[:, 0].astype(dt[0][1]) == blobs['a'])
+    assert np.all(points[:, 1].astype(dt[1][1]) == blobs['b'])
+
+
+@pytest.mark.parametrize('vectorized', [True, False])
+@pytest.mark.parametrize('discard', [True, False])
+@pytest.mark.parametrize('as_array', [False, True])
+def test_blobs_single_dtype(vectorized, discard, as_array):
+    """tests/test_blobs.py:94-135: one dtype for all blobs gives a 2-D array,
+    whether the likelihood returns the blobs one by one or as one array."""
+    like = (lambda x: (_ll(x), x[..., :2])) if as_array else \
+        _two_blobs(vectorized)
+    s = _blob_run(like, vectorized, discard, blobs_dtype=np.float32)
+    points, _, _, blobs = s.posterior(return_blobs=True)
+    assert len(points) == len(blobs)
+    assert np.all(points[:, 0].astype(np.float32) == blobs[:, 0])
+    assert np.all(points[:, 1].astype(np.float32) == blobs[:, 1])
