@@ -25,7 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('name')
     ap.add_argument('--n-eff', type=float, default=10000)
-    ap.add_argument('--n-batch', type=int, default=8192)
+    ap.add_argument('--n-batch', type=int, default=None,
+                    help='default: the configuration\'s own batch size')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--timeout', type=float, default=np.inf)
     args = ap.parse_args()
@@ -33,7 +34,8 @@ def main():
     t0 = time.time()
     s = Sampler(unit_prior, c['likelihood'], n_dim=c['n_dim'],
                 n_live=c['n_live'],
-                n_networks=c['n_networks'], n_batch=args.n_batch,
+                n_networks=c['n_networks'],
+                n_batch=args.n_batch or c['n_batch'],
                 vectorized=True, seed=args.seed)
     ok = s.run(n_eff=args.n_eff, discard_exploration=True,
                timeout=args.timeout)
@@ -44,6 +46,7 @@ def main():
     mean = np.average(pts, weights=w, axis=0)
     print(json.dumps(dict(
         config=args.name, finished=bool(ok), wall_s=round(wall, 2),
+        n_batch=args.n_batch or c['n_batch'],
         log_z=float(s.log_z), analytic_log_z=c['analytic_log_z'],
         n_eff=float(s.n_eff), n_like=int(s.n_like), n_bounds=len(s.bounds),
         n_neural_last=len(s.bounds[-1].neural_bounds)

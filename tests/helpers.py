@@ -157,3 +157,19 @@ def mvee_numpy_batch(point_sets, n_max=100, n_batch=20):
         scale = np.amax(np.einsum('ij,ij->i', diff @ a, diff))
         out.append((c, a / scale, a_inv * scale))
     return out
+
+
+def rosenbrock_log_z_exact(n_dim, m=2000):
+    """Evidence of the Rosenbrock likelihood of BASELINE config 3 (x = 10 u - 5,
+    identity prior) by transfer quadrature: the integrand is a chain, so
+    f_k(x_k) = exp(-(1 - x_k)^2) * int exp(-100 (x_{k+1} - x_k^2)^2) f_{k+1}
+    is one matrix-vector product per dimension on an m-point grid (converged
+    to 1e-8 at m = 2000; -137.4875 for n_dim = 30)."""
+    from scipy.special import logsumexp
+    h = 10.0 / m
+    x = -5 + (np.arange(m) + 0.5) * h
+    kern = -100.0 * (x[None, :] - x[:, None]**2)**2
+    logf = np.zeros(m)
+    for _ in range(n_dim - 1):
+        logf = logsumexp(kern + logf[None, :], axis=1) + np.log(h) - (1 - x)**2
+    return logsumexp(logf) + np.log(h) - n_dim * np.log(10.0)

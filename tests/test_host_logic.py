@@ -236,3 +236,16 @@ def test_prior_device_spec():
     assert p.device
     p.add_parameter('e', dist=expon())
     assert p.device_spec() is None and not p.device
+
+
+def test_rosenbrock_exact_evidence_helper():
+    """The transfer quadrature behind BASELINE config 3's evidence: equal to
+    brute-force quadrature in two dimensions, and the value quoted in
+    nautilus_amd/configs.py in thirty."""
+    from helpers import rosenbrock_log_z_exact
+    g = (np.arange(1000) + 0.5) / 1000
+    x = 10 * np.stack(np.meshgrid(g, g, indexing='ij'), axis=-1) - 5
+    brute = np.log(np.mean(np.exp(-(100 * (x[..., 1] - x[..., 0]**2)**2 +
+                                    (1 - x[..., 0])**2))))
+    assert abs(rosenbrock_log_z_exact(2, 1000) - brute) < 1e-10
+    assert abs(rosenbrock_log_z_exact(30, 1000) - (-137.4875)) < 1e-4
