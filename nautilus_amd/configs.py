@@ -35,7 +35,7 @@ def baseline_config(name):
         cov = s**2 * (0.5 * np.ones((d, d)) + 0.5 * np.eye(d))
         return dict(
             likelihood=GaussianLikelihood(np.full(d, 0.5), cov), n_dim=d,
-            n_live=2000, n_networks=4, n_batch=4096, analytic_log_z=0.0,
+            n_live=2000, n_networks=4, n_batch=256, analytic_log_z=0.0,
             description='20-dim correlated Gaussian, n_live=2000')
     if name == 'C3':
         return dict(

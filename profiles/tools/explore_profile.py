@@ -5,7 +5,7 @@ import numpy as np, torch
 from nautilus_amd import GaussianLikelihood, Sampler, unit_prior, emulator
 d = 50
 like = GaussianLikelihood(np.full(d, 0.5), np.eye(d) * 0.05**2)
-s = Sampler(unit_prior, like, n_dim=d, n_live=2000, n_networks=4, n_batch=8192, vectorized=True, seed=0)
+s = Sampler(unit_prior, like, n_dim=d, n_live=2000, n_networks=4, n_batch=16384, vectorized=True, seed=0)
 stats = []
 orig = emulator.train_ensembles
 def wrapped(jobs):
