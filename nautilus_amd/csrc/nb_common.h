@@ -69,7 +69,7 @@ __host__ __device__ inline int64_t nb_hdr(const double* blob, int i) {
   return ((const int64_t*)blob)[i];
 }
 
-__host__ __device__ inline int nb_ell_block_size(int dt) {
+__host__ __device__ constexpr int nb_ell_block_size(int dt) {
   return 2 + 3 * dt * 16 + dt * dt * NB_TILE;   // even => 16-byte aligned tiles
 }
 // tiles of one network given KT1

@@ -354,8 +354,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       const int K = (int)nb_hdr(blob, NB_H_K);
       const int M = (int)nb_hdr(blob, NB_H_M);
       const int E = (int)nb_hdr(blob, NB_H_E);
-      const double* ulo = blob + nb_hdr(blob, NB_H_OFF_ULO);
-      const double* uhi = blob + nb_hdr(blob, NB_H_OFF_UHI);
+      const bool use_cube = nb_hdr(blob, NB_H_USECUBE) != 0;
       const long long ell_stride = nb_hdr(blob, NB_H_ELL_STRIDE);
       const long long neural_stride = nb_hdr(blob, NB_H_NEURAL_STRIDE);
       // contains() of a bound with periodic dimensions sees recentred points;
@@ -377,14 +376,18 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       const int n_a = kt1 * NB_HT1 * NB_TILE;                   // layer 1
       constexpr int KA = (DT + 2) / 2;                  // k-tiles of chunk A
       const int n_a0 = (DT >= 5) ? KA * NB_HT1 * NB_TILE : n_a;
-      const bool ell_dma = DBUF && nb_ell_block_size(DT) + 128 <= w_doubles;
+      // a neural bound's block is staged together with what follows it in
+      // the blob: threshold, mean and inverse scale of the standardisation
+      constexpr int NBLK = nb_ell_block_size(DT) + 2 + 2 * DP;
+      // (whole 1 KB DMA chunks into region B, 38 tiles)
+      const bool ell_dma = DBUF && ((NBLK + 127) / 128) * 128 <= 38 * NB_TILE;
       const bool early = ell_dma && M > 0 && E > 0 &&
                          (m_sample || m_score);
       const bool pre = DT <= NB_PRE_DT && early &&
                        (K == 0 || (m_sample && K == 1));
       if (pre) {
         __syncthreads();                               // LDS free
-        dma_weights<NW>(nblk, tlds, nb_ell_block_size(DT), wave, lane);
+        dma_weights<NW>(nblk, tlds, NBLK, wave, lane);
         dma_weights<NW>(nblk + nb_ell_block_size(DT) + 2 + 2 * DP, wlds, n_a0,
                         wave, lane);
       }
@@ -427,16 +430,20 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           if (!__syncthreads_or(maybe ? 1 : 0)) continue;
         }
 
+        // unit-cube limits of slot (ks, lg) = feature 8 (ks >> 1) + 2 lg +
+        // (ks & 1): [0, 1) for the features of a bound clipped to the cube,
+        // unbounded otherwise (what nb_api.hip stores at off_ulo / off_uhi;
+        // computed here, the loads were serialised by the compiler)
         bool cbad[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) cbad[t] = false;
 #pragma unroll
         for (int ks = 0; ks < 4 * DT; ++ks) {
-          const int f = 4 * ks + lg;
-          const double lov = ulo[f], hiv = uhi[f];
+          const int f = 8 * (ks >> 1) + 2 * lg + (ks & 1);
+          const bool boxed = use_cube && f < n_dim;
 #pragma unroll
           for (int t = 0; t < TPW; ++t)
-            cbad[t] |= !(xin[t][ks] >= lov && xin[t][ks] < hiv);
+            cbad[t] |= boxed && !(xin[t][ks] >= 0.0 && xin[t][ks] < 1.0);
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -509,7 +516,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
             // (m == 0 of a pre-issued bound: copies in flight, points loaded)
             if (!(pre && m == 0)) {
               __syncthreads();                         // LDS free
-              dma_weights<NW>(nb_m, tlds, nb_ell_block_size(DT), wave, lane);
+              dma_weights<NW>(nb_m, tlds, NBLK, wave, lane);
               if (early) dma_weights<NW>(nets, wlds, n_a0, wave, lane);
               load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin,
                                    shift);
@@ -520,10 +527,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           } else {
             load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
             __syncthreads();
-            stage_weights<NW>(nb_m, wlds, nb_ell_block_size(DT));
+            stage_weights<NW>(nb_m, wlds, NBLK);
             __syncthreads();
             ell_eval<DT, TPW>(wlds, n_dim, xin, lane, y, box_bad, r2);
           }
+          // (in LDS until the first weight DMA of this neural bound lands)
+          const double* blk_lds = ell_dma ? tlds : wlds;
           NB_TS(1);
           bool wave_need = false;
 #pragma unroll
@@ -567,8 +576,8 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
           }
 
           if (E > 0 && n_need > 0) {
-            const double thr = nb_m[nb_ell_block_size(DT)];
-            const double* mean = nb_m + nb_ell_block_size(DT) + 2;
+            const double thr = blk_lds[nb_ell_block_size(DT)];
+            const double* mean = blk_lds + nb_ell_block_size(DT) + 2;
             const double* scale = mean + DP;
             // standardised input (neural.py:115), constant 1 at column D
             double tin[TPW][KS1MAX];
@@ -642,6 +651,10 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
                 __syncthreads();
                 issue(0, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+              } else {
+                // the standardisation vectors were read from region B, which
+                // the first stage refills
                 __syncthreads();
               }
               NB_TS(2);

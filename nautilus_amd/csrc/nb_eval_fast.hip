@@ -17,7 +17,7 @@
 //    of the next stage sliced into the k-steps (nb_mlp.h).
 //
 // LDS: [resident block][region A: layer 1, KT1 x 7 tiles][region B: layers
-// 2-4, 38 tiles]; 159 KB at n_dim = 50.  Eligible: n_dim <= 63 (region A),
+// 2-4, 38 tiles]; 158 KB at n_dim = 50.  Eligible: n_dim <= 63 (region A),
 // one neural bound with E >= 1 networks, MODE_SAMPLE with at most one outer
 // member or MODE_SCORE; everything else goes through nb_eval.hip.
 #include "nb_common.h"
@@ -59,7 +59,7 @@ struct FastArgs {
 };
 
 constexpr int fast_resident_doubles(int dt) {
-  return 2 + 7 * 16 * dt + dt * (dt + 1) / 2 * NB_TILE;
+  return 2 + 5 * 16 * dt + dt * (dt + 1) / 2 * NB_TILE;
 }
 constexpr int FAST_B_DOUBLES =
     (NB_HT1 * NB_HT2 + NB_HT2 * NB_HT3 + NB_HT3) * NB_TILE;
@@ -188,13 +188,11 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
   double* res = lds;
   double* reg_a = lds + RES;
   double* reg_b = reg_a + NA_D;
-  // resident block: [n_ell, thr][lo][hi][c][ulo][uhi][mean][1/scale][tiles]
+  // resident block: [n_ell, thr][lo][hi][c][mean][1/scale][tiles]
   const double* r_lo = res + 2;
   const double* r_hi = r_lo + DP;
   const double* r_c = r_hi + DP;
-  const double* r_ulo = r_c + DP;
-  const double* r_uhi = r_ulo + DP;
-  const double* r_mean = r_uhi + DP;
+  const double* r_mean = r_c + DP;
   const double* r_isc = r_mean + DP;
   const double* r_tiles = r_isc + DP;
 
@@ -205,6 +203,7 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
   const double* blob = a.blob;
   const int n_dim = (int)nb_hdr(blob, NB_H_NDIM);
   const int K = (int)nb_hdr(blob, NB_H_K);
+  const bool use_cube = nb_hdr(blob, NB_H_USECUBE) != 0;
   const int E = (int)nb_hdr(blob, NB_H_E);
   const int ks1 = (n_dim + 1 + 3) >> 2;
   const double* nb_m = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
@@ -249,19 +248,15 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
 
   // ---- resident block ----------------------------------------------------
   {
-    const double* ulo = blob + nb_hdr(blob, NB_H_OFF_ULO);
-    const double* uhi = blob + nb_hdr(blob, NB_H_OFF_UHI);
     const double* mean = nb_m + nb_ell_block_size(DT) + 2;
     for (int i = threadIdx.x; i < 2 + 3 * DP; i += 64 * NW)
       res[i] = (i == 1) ? nb_m[nb_ell_block_size(DT)] : nb_m[i];
     for (int i = threadIdx.x; i < DP; i += 64 * NW) {
-      res[2 + 3 * DP + i] = ulo[i];
-      res[2 + 4 * DP + i] = uhi[i];
-      res[2 + 5 * DP + i] = mean[i];
-      res[2 + 6 * DP + i] = mean[DP + i];
+      res[2 + 3 * DP + i] = mean[i];
+      res[2 + 4 * DP + i] = mean[DP + i];
     }
     const double* tsrc = nb_m + 2 + 3 * DP;
-    double* tdst = res + 2 + 7 * DP;
+    double* tdst = res + 2 + 5 * DP;
 #pragma unroll
     for (int ht = 0; ht < DT; ++ht)
 #pragma unroll
@@ -314,10 +309,12 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
       for (int t = 0; t < T; ++t) cbad[t] = false;
 #pragma unroll
       for (int ks = 0; ks < 4 * DT; ++ks) {
-        const double lov = r_ulo[4 * ks + lg], hiv = r_uhi[4 * ks + lg];
+        // slot (ks, lg) holds feature 8 (ks >> 1) + 2 lg + (ks & 1)
+        const int f = 8 * (ks >> 1) + 2 * lg + (ks & 1);
+        const bool boxed = use_cube && f < n_dim;
 #pragma unroll
         for (int t = 0; t < T; ++t)
-          cbad[t] |= !(xin[t][ks] >= lov && xin[t][ks] < hiv);
+          cbad[t] |= boxed && !(xin[t][ks] >= 0.0 && xin[t][ks] < 1.0);
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
