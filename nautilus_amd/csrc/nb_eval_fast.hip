@@ -222,9 +222,6 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
     dma_src = src; dma_dst = dst; dma_c = wave; dma_n = n_doubles >> 7;
   };
   auto dma_tick = [&]() __attribute__((always_inline)) {
-#if defined(NBF_EXP) && (NBF_EXP == 1 || NBF_EXP == 2)
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < NBF_TB; ++i)
       if (dma_c < dma_n) {
@@ -235,9 +232,6 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
       }
   };
   auto dma_flush = [&]() __attribute__((always_inline)) {
-#if defined(NBF_EXP) && NBF_EXP == 1
-    if (sup >= 0) return;
-#endif
     while (dma_c < dma_n) {
       __builtin_amdgcn_global_load_lds(
           (nbf_gptr)(dma_src + dma_c * 128 + 2 * lane),
@@ -375,9 +369,6 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
       double h1[T][4 * NB_HT1];
       // -- stage 1: layer 1 from region A, layers 2-4 -> region B ----------
       dma_begin(w_e + NA_D, reg_b, NB_D);
-#if defined(NBF_EXP) && NBF_EXP == 2
-      dma_flush();
-#endif
       if (wave_mlp) {
         double a0[FlFirst<SPLIT, NB_HT1>::NA];
         fl_read_first<SPLIT, NB_HT1>(reg_a, lane, a0);
@@ -405,9 +396,6 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
         load_points_raw<DT, T>(a.x, npt, nvalid, n_dim, a.n, lane, xraw);
       }
       dma_begin(nets + (LAST ? 0 : (e + 1) * net_stride), reg_a, NA_D);
-#if defined(NBF_EXP) && NBF_EXP == 2
-      dma_flush();
-#endif
       if (wave_mlp) {
         const double* w2 = reg_b;
         const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
