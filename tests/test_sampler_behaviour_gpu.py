@@ -63,6 +63,15 @@ def test_enlarge_per_dim_leaves_one_bound():
     assert np.isclose(s.log_z, -4 * 0.5**3 / 3 * 0.001, rtol=0, atol=1e-4)
 
 
+def test_constant_likelihood_builds_no_bound():
+    """tests/test_sampler.py:334-348: log Z = 0 and only the unit cube."""
+    from nautilus_amd import Sampler
+    s = Sampler(ident, lambda x: 0, 2, n_live=500, seed=0)
+    s.run(f_live=0.1, n_eff=0)
+    assert np.isclose(s.log_z, 0)
+    assert len(s.bounds) == 1
+
+
 def test_empty_shells_at_the_end():
     from nautilus_amd import Sampler
     s = Sampler(ident, bowl, n_dim=2, n_networks=0, seed=0, n_update=1,
