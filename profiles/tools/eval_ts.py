@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.')  # run from the repo root
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import numpy as np, torch, time
 from oracle import mlp_oracle as mo
 from nautilus_amd import device, _lib
