@@ -864,8 +864,8 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
   const bool sparse = (a.mode == MODE_ANY || a.mode == MODE_ASSOC);
   // two tiles per wavefront up to n_dim = 64; beyond that the per-lane state
   // (y, standardised input, hidden activations of two tiles) no longer fits
-  // the register file
-  constexpr int TPW = (DT <= 4) ? 2 : 1;
+  // the register file (one tile, see below)
+  constexpr int TPW = 2;
 #ifdef NB_EVAL_GATHER
   if constexpr (DT <= 4) {
     if (sparse && need <= 160 * 1024)
@@ -876,8 +876,20 @@ int launch_eval(const EvalArgs& a, int kt1_max, hipStream_t stream) {
 #endif
   // (8 wavefronts x 1 tile was measured as well: +7 % at D = 20, -2 % at
   // D = 50, where the 256-register budget per wavefront forces ~100 spills)
-  if (sparse) return launch_eval_impl<DT, 1, TPW, 4, true>(a, lds_tiles, stream);
-  return launch_eval_impl<DT, 1, TPW, 4, false>(a, lds_tiles, stream);
+  // n_dim > 64: one tile per wavefront, and there the weight stream decides
+  // (174 KB of DMA per network against ~12 B/clk a CU sustains): eight
+  // wavefronts share every staged weight byte between 128 points instead of
+  // 64.  Measured +9 % at D = 100, +13 % at D = 80, +8 % at D = 65 over four
+  // wavefronts although the 256-register budget spills 130-330 registers of
+  // cold per-point state.
+  if constexpr (DT >= 5) {
+    if (sparse) return launch_eval_impl<DT, 1, 1, 8, true>(a, lds_tiles, stream);
+    return launch_eval_impl<DT, 1, 1, 8, false>(a, lds_tiles, stream);
+  } else {
+    if (sparse)
+      return launch_eval_impl<DT, 1, TPW, 4, true>(a, lds_tiles, stream);
+    return launch_eval_impl<DT, 1, TPW, 4, false>(a, lds_tiles, stream);
+  }
 }
 
 }  // namespace
