@@ -5,44 +5,38 @@
 // passes of a workgroup.  Same arithmetic as nb_eval.hip (bit-identical
 // scores), different schedule:
 //
-//  * everything that does not change between passes stays in LDS for the whole
-//    launch: the ellipsoid block (lower-triangular tiles only), the cube
-//    limits, the standardisation vectors (nb_eval.hip re-fetches them per
-//    pass, the small vectors with one dependent global load per k-step);
-//  * the points of pass p + 1 are loaded into registers during the last MLP
-//    stage of pass p (the standardised input's registers are dead there), and
-//    layer 1 of the first network is fetched into its region during that stage
-//    as well, so a pass starts with everything it needs on the CU;
-//  * the MLP layers run as one operand pipeline per stage with the weight DMA
-//    of the next stage sliced into the k-steps (nb_mlp.h).
+//  * EIGHT wavefronts x one 16-point tile (two wavefronts per SIMD, 256
+//    registers each, no spills up to n_dim = 63): while one wavefront of a
+//    SIMD waits for LDS operands, issues a weight DMA or runs the per-pass
+//    prologue, the other feeds the matrix pipe.  (Four wavefronts x two tiles
+//    -- every A operand shared by two tiles, one wavefront per SIMD -- reached
+//    0.66 of the fp64 MFMA peak at n_dim = 50; this shape reaches 0.74, and
+//    0.70 at n_dim = 100 where the four-wavefront kernel of nb_eval.hip gets
+//    0.37.)  The weight stream sets the pace -- 66 to 101 tiles per network
+//    against ~12 B/clk of DMA a CU sustains -- so a staged weight byte has to
+//    serve as many points as the registers allow: 128 per pass.
+//  * two LDS regions of 38 tiles alternate between feeding the matrix cores
+//    and being refilled by global_load_lds; the ellipsoid block (centre,
+//    lower-triangular tiles, threshold, mean, inverse scale) travels through
+//    them like a stage of its own: it is fetched during the last stage of
+//    the previous pass, layer 1 of the first network under the per-pass
+//    prologue.  Layer 1 runs in two K chunks where it exceeds a region
+//    (n_dim >= 80).  Stages of a pass:
+//      [ellipsoid + standardisation] ([L1] or [L1 a][L1 b], [L2-4]) x E
+//  * the points of pass p + 1 are loaded raw into registers during the last
+//    stage of pass p (the standardised input's registers are dead there) and
+//    masked when the pass starts;
+//  * the layers of a stage run as one operand pipeline with the weight DMA of
+//    the next stage sliced into the k-steps (nb_mlp.h).
 //
-// LDS: [resident block][region A: layer 1, KT1 x 7 tiles][region B: layers
-// 2-4, 38 tiles]; 158 KB at n_dim = 50.  Eligible: n_dim <= 63 (region A),
-// one neural bound with E >= 1 networks, MODE_SAMPLE with at most one outer
-// member or MODE_SCORE; everything else goes through nb_eval.hip.
+// Eligible: n_dim <= 128, one neural bound with E >= 1 networks, MODE_SAMPLE
+// with at most one outer member or MODE_SCORE; everything else goes through
+// nb_eval.hip.
 #include "nb_common.h"
 
 #include <type_traits>
 
 #include "nb_mlp.h"
-
-// k-steps between two DMA instructions of a wavefront in stage 1 / stage 2,
-// operand prefetch distance of layers 3 / 4
-#ifndef NBF_P1
-#define NBF_P1 2
-#endif
-#ifndef NBF_P2
-#define NBF_P2 4
-#endif
-#ifndef NBF_TB
-#define NBF_TB 1                  // DMA instructions per tick
-#endif
-#ifndef NBF_PD3
-#define NBF_PD3 2
-#endif
-#ifndef NBF_PD4
-#define NBF_PD4 5
-#endif
 
 namespace {
 
@@ -58,43 +52,30 @@ struct FastArgs {
   unsigned long long* counters;   // optional, as in nb_eval.hip
 };
 
-constexpr int fast_resident_doubles(int dt) {
-  return 2 + 5 * 16 * dt + dt * (dt + 1) / 2 * NB_TILE;
-}
 constexpr int FAST_B_DOUBLES =
     (NB_HT1 * NB_HT2 + NB_HT2 * NB_HT3 + NB_HT3) * NB_TILE;
 
 typedef const void __attribute__((address_space(1))) * nbf_gptr;
 typedef void __attribute__((address_space(3))) * nbf_lptr;
 
-// y = B_inv (x - c) and the member's box test from the resident block
+// y = B_inv (x - c) from the staged block: centre + lower-triangular tiles
+// (no box test: a neural bound's ellipsoid spans all dimensions)
 template <int DT, int T>
-__device__ __forceinline__ void ell_eval_resident(
-    const double* lo, const double* hi, const double* c, const double* tiles,
-    int n_dim, const double (&xin)[T][4 * DT], int lane,
-    double (&y)[T][4 * DT], bool (&box_bad)[T], double (&r2)[T]) {
+__device__ __forceinline__ void ell_eval_centre(
+    const double* c, const double* tiles, int n_dim,
+    const double (&xin)[T][4 * DT], int lane, double (&y)[T][4 * DT],
+    double (&r2)[T]) {
   const int lg = lane >> 4;
   double d[T][4 * DT];
-  bool bad[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) bad[t] = false;
 #pragma unroll
   for (int ks = 0; ks < 4 * DT; ++ks) {
-    const int f = 4 * ks + lg;
-    const double lov = lo[f], hiv = hi[f], cv = c[f];
+    const double cv = c[4 * ks + lg];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const double xv = xin[t][ks];
-      bad[t] |= !(xv >= lov && xv < hiv);
-      d[t][ks] = xv - cv;
-    }
+    for (int t = 0; t < T; ++t) d[t][ks] = xin[t][ks] - cv;
   }
   double part[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    box_bad[t] = point_any(bad[t], lane);
-    part[t] = 0.0;
-  }
+  for (int t = 0; t < T; ++t) part[t] = 0.0;
 #pragma unroll
   for (int ht = 0; ht < DT; ++ht) {
     if (16 * ht < n_dim) {
@@ -176,25 +157,33 @@ __device__ __forceinline__ void points_from_raw(
     }
 }
 
+constexpr int FAST_REGION = 38 * NB_TILE;            // doubles per region
+
 template <int DT, int KT1>
-__global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
-  constexpr int T = 2, NW = 4, DP = 16 * DT;
-  constexpr int KS1 = 4 * KT1;               // k-steps of layer 1 (padded)
-  constexpr int SPLIT = DT <= 2 ? 8 : 2;     // output tiles per block
-  constexpr int RES = fast_resident_doubles(DT);
-  constexpr int NA_D = KT1 * NB_HT1 * NB_TILE;
-  constexpr int NB_D = FAST_B_DOUBLES;
+__global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
+  constexpr int T = 1, NW = 8, DP = 16 * DT;
+  constexpr int KS1 = 4 * KT1;
+  // layer 1 in one stage if it fits a region, else in two K chunks
+  constexpr bool TWO = KT1 * NB_HT1 * NB_TILE > FAST_REGION;
+  constexpr int KA = TWO ? (KT1 + 1) / 2 : KT1;    // k-tiles of chunk a
+  constexpr int NT = DT * (DT + 1) / 2;            // lower-triangular tiles
+  // the block in LDS: [c (one 1 KB piece)][NT tiles][thr, pad, mean, 1/scale].
+  // (A neural bound's ellipsoid spans all dimensions -- nb_bound_create checks
+  // it -- so its per-dimension box limits are infinite and stay behind.)
+  constexpr int HEAD = 128;
+  constexpr int TAIL = HEAD + NT * NB_TILE;
+  constexpr int TC = (2 + 2 * DP + 127) / 128;     // 1 KB pieces of the tail
+  constexpr int ELL_CHUNKS = 1 + 2 * NT + TC;
+  static_assert(DP <= HEAD, "centre fits the head");
+  static_assert(TAIL + TC * 128 <= FAST_REGION, "ellipsoid block fits a region");
+  static_assert(KA * NB_HT1 * NB_TILE <= FAST_REGION, "layer-1 chunk fits");
+  constexpr int NA_D = KA * NB_HT1 * NB_TILE;               // chunk a
+  constexpr int NB1_D = (KT1 - KA) * NB_HT1 * NB_TILE;      // chunk b
+  constexpr int NC_D = FAST_B_DOUBLES;                      // layers 2-4
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* res = lds;
-  double* reg_a = lds + RES;
-  double* reg_b = reg_a + NA_D;
-  // resident block: [n_ell, thr][lo][hi][c][mean][1/scale][tiles]
-  const double* r_lo = res + 2;
-  const double* r_hi = r_lo + DP;
-  const double* r_c = r_hi + DP;
-  const double* r_mean = r_c + DP;
-  const double* r_isc = r_mean + DP;
-  const double* r_tiles = r_isc + DP;
+  auto reg = [&](int i) __attribute__((always_inline)) {
+    return lds + (i & 1) * FAST_REGION;
+  };
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -211,66 +200,56 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
   const double* nets = nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
   const long long n_super = (a.n + 16 * NW * T - 1) / (16 * NW * T);
   unsigned long long cnt_ell = 0, cnt_mlp = 0;
-
   long long sup = blockIdx.x;
-  // ---- weight DMA (global_load_lds_dwordx4, 1 KB per instruction) --------
+
+  // ---- DMA: a linear run of 1 KB pieces, or the packed ellipsoid block ---
   const double* dma_src = nullptr;
   double* dma_dst = nullptr;
-  int dma_c = 0, dma_n = 0;                 // chunk index of this wavefront
+  int dma_c = 0, dma_n = 0;
+  bool dma_ell = false;
   auto dma_begin = [&](const double* src, double* dst, int n_doubles)
       __attribute__((always_inline)) {
     dma_src = src; dma_dst = dst; dma_c = wave; dma_n = n_doubles >> 7;
+    dma_ell = false;
+  };
+  auto dma_begin_ell = [&](double* dst) __attribute__((always_inline)) {
+    dma_src = nb_m; dma_dst = dst; dma_c = wave; dma_n = ELL_CHUNKS;
+    dma_ell = true;
+  };
+  auto dma_one = [&]() __attribute__((always_inline)) {
+    int s_off, d_off;
+    if (!dma_ell) {
+      s_off = d_off = dma_c * 128;
+    } else if (dma_c < 1) {                         // centre
+      s_off = 2 + 2 * DP;
+      d_off = 0;
+    } else if (dma_c < 1 + 2 * NT) {                // tile p = (ht, kt <= ht)
+      const int p = (dma_c - 1) >> 1, half = (dma_c - 1) & 1;
+      int ht = 0;
+      while ((ht + 1) * (ht + 2) / 2 <= p) ++ht;
+      const int kt = p - ht * (ht + 1) / 2;
+      s_off = 2 + 3 * DP + (kt * DT + ht) * NB_TILE + half * 128;
+      d_off = HEAD + p * NB_TILE + half * 128;
+    } else {                                        // threshold, mean, 1/scale
+      const int i = dma_c - 1 - 2 * NT;
+      s_off = nb_ell_block_size(DT) + i * 128;
+      d_off = TAIL + i * 128;
+    }
+    __builtin_amdgcn_global_load_lds(
+        (nbf_gptr)(dma_src + s_off + 2 * lane),
+        (nbf_lptr)(dma_dst + d_off), 16, 0, 0);
+    dma_c += NW;
   };
   auto dma_tick = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NBF_TB; ++i)
-      if (dma_c < dma_n) {
-        __builtin_amdgcn_global_load_lds(
-            (nbf_gptr)(dma_src + dma_c * 128 + 2 * lane),
-            (nbf_lptr)(dma_dst + dma_c * 128), 16, 0, 0);
-        dma_c += NW;
-      }
+    if (dma_c < dma_n) dma_one();
   };
   auto dma_flush = [&]() __attribute__((always_inline)) {
-    while (dma_c < dma_n) {
-      __builtin_amdgcn_global_load_lds(
-          (nbf_gptr)(dma_src + dma_c * 128 + 2 * lane),
-          (nbf_lptr)(dma_dst + dma_c * 128), 16, 0, 0);
-      dma_c += NW;
-    }
+    while (dma_c < dma_n) dma_one();
   };
 
-  // ---- resident block ----------------------------------------------------
-  {
-    const double* mean = nb_m + nb_ell_block_size(DT) + 2;
-    for (int i = threadIdx.x; i < 2 + 3 * DP; i += 64 * NW)
-      res[i] = (i == 1) ? nb_m[nb_ell_block_size(DT)] : nb_m[i];
-    for (int i = threadIdx.x; i < DP; i += 64 * NW) {
-      res[2 + 3 * DP + i] = mean[i];
-      res[2 + 4 * DP + i] = mean[DP + i];
-    }
-    const double* tsrc = nb_m + 2 + 3 * DP;
-    double* tdst = res + 2 + 5 * DP;
-#pragma unroll
-    for (int ht = 0; ht < DT; ++ht)
-#pragma unroll
-      for (int kt = 0; kt <= ht; ++kt)
-        for (int i = threadIdx.x; i < NB_TILE; i += 64 * NW)
-          tdst[(ht * (ht + 1) / 2 + kt) * NB_TILE + i] =
-              tsrc[(kt * DT + ht) * NB_TILE + i];
-    dma_begin(nets, reg_a, NA_D);
-    dma_flush();
-  }
-
-#ifdef NB_DBG_TIMING
-  // cycle stamps of wavefront 0 of workgroup 0, accumulated in registers
-  // (profiles/tools/fast_ts.py)
-  long long t_prev = clock64();
-  long long ts_acc[7] = {0, 0, 0, 0, 0, 0, 0};
-#define NBF_TS(i) do { const long long t_now = clock64(); ts_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define NBF_TS(i)
-#endif
+  int q = 0;                         // reg(q): ellipsoid block of this pass
+  dma_begin_ell(reg(0));
+  dma_flush();
   long long pt[T];
   bool valid[T];
   double2 xraw[T][2 * DT];
@@ -280,12 +259,18 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
     valid[t] = pt[t] < a.n;
   }
   load_points_raw<DT, T>(a.x, pt, valid, n_dim, a.n, lane, xraw);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const double thr = res[1];
 
   for (; sup < n_super; sup += gridDim.x) {
-    // ---- this pass's points have arrived in xraw --------------------------
+    // layer 1 (chunk a) of the first network -> the other region, under the
+    // prologue; the ellipsoid block and the points are waited for here
+    dma_begin(nets, reg(q ^ 1), NA_D);
+    dma_flush();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NA_D / 128 + NW - 1) / NW)
+                 : "memory");
+    __syncthreads();
+    const double* blk = reg(q);
+    const double thr = blk[TAIL];
+
     bool in_cube[T], acc_outer[T], want[T];
     double xin[T][4 * DT];
 #pragma unroll
@@ -296,14 +281,11 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
     }
     points_from_raw<DT, T>(xraw, valid, n_dim, lane, xin);
     if (m_sample) {
-      // unit-cube clip of the union (union.py:313-314) and the acceptance of
-      // the overlap-corrected draw (union.py:318-319) with k = K
       bool cbad[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) cbad[t] = false;
 #pragma unroll
       for (int ks = 0; ks < 4 * DT; ++ks) {
-        // slot (ks, lg) holds feature 8 (ks >> 1) + 2 lg + (ks & 1)
         const int f = 8 * (ks >> 1) + 2 * lg + (ks & 1);
         const bool boxed = use_cube && f < n_dim;
 #pragma unroll
@@ -326,9 +308,9 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
 
     double y[T][4 * DT], r2[T];
     bool box_bad[T], inside_e[T], need[T];
-    ell_eval_resident<DT, T>(r_lo, r_hi, r_c, r_tiles, n_dim, xin, lane, y,
-                             box_bad, r2);
-    NBF_TS(0);
+    ell_eval_centre<DT, T>(blk, blk + HEAD, n_dim, xin, lane, y, r2);
+#pragma unroll
+    for (int t = 0; t < T; ++t) box_bad[t] = false;
     bool wave_mlp = false;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -340,51 +322,72 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
     }
     wave_mlp = __any(wave_mlp);
 
-    // standardised input (neural.py:115), constant 1 at column n_dim
     double tin[T][KS1];
+    {
+      const double* r_mean = blk + TAIL + 2;
+      const double* r_isc = r_mean + DP;
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) {
-      const int f = 4 * ks + lg;
-      if (ks < 4 * DT) {
-        const double mv = r_mean[f], sv = r_isc[f];
+      for (int ks = 0; ks < KS1; ++ks) {
+        const int f = 4 * ks + lg;
+        if (ks < 4 * DT) {
+          const double mv = r_mean[f], sv = r_isc[f];
 #pragma unroll
-        for (int t = 0; t < T; ++t)
-          tin[t][ks] = (f < n_dim) ? (y[t][ks] - mv) * sv
-                                   : ((f == n_dim) ? 1.0 : 0.0);
-      } else {
+          for (int t = 0; t < T; ++t)
+            tin[t][ks] = (f < n_dim) ? (y[t][ks] - mv) * sv
+                                     : ((f == n_dim) ? 1.0 : 0.0);
+        } else {
 #pragma unroll
-        for (int t = 0; t < T; ++t) tin[t][ks] = (f == n_dim) ? 1.0 : 0.0;
+          for (int t = 0; t < T; ++t) tin[t][ks] = (f == n_dim) ? 1.0 : 0.0;
+        }
       }
     }
+    // the block has been read; layer 1 (chunk a) has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     double total[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) total[t] = 0.0;
-    NBF_TS(1);
+    int cur = q ^ 1;                 // region of the stage about to run
 
-    // one network = two stages; region A holds its layer 1 on entry
+    auto stage_end = [&]() __attribute__((always_inline)) {
+      dma_flush();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    };
     auto network = [&](int e, auto last_c) __attribute__((always_inline)) {
       constexpr bool LAST = decltype(last_c)::value;
       const double* w_e = nets + e * net_stride;
       double h1[T][4 * NB_HT1];
-      // -- stage 1: layer 1 from region A, layers 2-4 -> region B ----------
-      dma_begin(w_e + NA_D, reg_b, NB_D);
-      if (wave_mlp) {
-        double a0[FlFirst<SPLIT, NB_HT1>::NA];
-        fl_read_first<SPLIT, NB_HT1>(reg_a, lane, a0);
-        fl_layer_from<T, SPLIT, KS1, 3, NB_HT1, false, NBF_P1, 1, 0>(
-            reg_a, ks1, tin, lane, h1, a0,
-            []() __attribute__((always_inline)) {}, dma_tick);
-        fl_pad<T, NB_HT1, 25, 0>(h1, lane);                  // unit 100
+      if constexpr (TWO) {
+        // -- L1 chunk a; chunk b -> other region
+        dma_begin(w_e + NA_D, reg(cur ^ 1), NB1_D);
+        if (wave_mlp)
+          fl_chunk<T, KS1, NB_HT1, 0, 4 * KA, 2>(reg(cur), ks1, tin, lane, h1,
+                                                dma_tick);
+        stage_end();
+        // -- L1 chunk b; layers 2-4 -> other region
+        dma_begin(w_e + NA_D + NB1_D, reg(cur ^ 1), NC_D);
+        if (wave_mlp) {
+          fl_chunk<T, KS1, NB_HT1, 4 * KA, KS1, 1>(reg(cur), ks1, tin, lane,
+                                                  h1, dma_tick);
+          fl_pad<T, NB_HT1, 25, 0>(h1, lane);
+        }
+        stage_end();
+      } else {
+        // -- layer 1; layers 2-4 -> other region
+        dma_begin(w_e + NA_D, reg(cur ^ 1), NC_D);
+        if (wave_mlp) {
+          fl_chunk<T, KS1, NB_HT1, 0, KS1, 1>(reg(cur), ks1, tin, lane, h1,
+                                             dma_tick);
+          fl_pad<T, NB_HT1, 25, 0>(h1, lane);
+        }
+        stage_end();
       }
-      NBF_TS(2);
-      dma_flush();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      NBF_TS(3);
-      // -- stage 2: layers 2-4 from region B, next layer 1 -> region A -----
+      // -- layers 2-4; next network's chunk a, or the ellipsoid block of the
+      // next pass, -> other region
       if constexpr (LAST) {
-        // the next pass's points (tin is dead from here on)
         const long long nsup = sup + gridDim.x;
         long long npt[T];
         bool nvalid[T];
@@ -394,46 +397,44 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
           nvalid[t] = npt[t] < a.n;
         }
         load_points_raw<DT, T>(a.x, npt, nvalid, n_dim, a.n, lane, xraw);
+        dma_begin_ell(reg(cur ^ 1));
+      } else {
+        dma_begin(nets + (e + 1) * net_stride, reg(cur ^ 1), NA_D);
       }
-      dma_begin(nets + (LAST ? 0 : (e + 1) * net_stride), reg_a, NA_D);
       if (wave_mlp) {
-        const double* w2 = reg_b;
+        const double* w2 = reg(cur);
         const double* w3 = w2 + NB_HT1 * NB_HT2 * NB_TILE;
         const double* w4 = w3 + NB_HT2 * NB_HT3 * NB_TILE;
         double h2[T][4 * NB_HT2], h3[T][4 * NB_HT3], o[T][4];
-        double a2[FlFirst<SPLIT, NB_HT2>::NA], a3[FlFirst<SPLIT, NB_HT3>::NA],
-            a4[FlFirst<SPLIT, 1>::NA];
-        fl_read_first<SPLIT, NB_HT2>(w2, lane, a2);
-        fl_layer_from<T, SPLIT, 26, 0, NB_HT2, true, NBF_P2, 1, 0>(
+        double a2[FlFirst<8, NB_HT2>::NA], a3[FlFirst<8, NB_HT3>::NA],
+            a4[FlFirst<8, 1>::NA];
+        fl_read_first<8, NB_HT2>(w2, lane, a2);
+        fl_layer_from<T, 8, 26, 0, NB_HT2, true, 2, 1, 0>(
             w2, 26, h1, lane, h2, a2,
             [&]() __attribute__((always_inline)) {
-              fl_read_first<SPLIT, NB_HT3>(w3, lane, a3);
+              fl_read_first<8, NB_HT3>(w3, lane, a3);
             },
             dma_tick);
-        fl_pad<T, NB_HT2, 12, 2>(h2, lane);                  // unit 50
-        fl_layer_from<T, SPLIT, 13, 0, NB_HT3, true, NBF_P2, NBF_PD3, 0>(
+        fl_pad<T, NB_HT2, 12, 2>(h2, lane);
+        fl_layer_from<T, 8, 13, 0, NB_HT3, true, 2, 2, 0>(
             w3, 13, h2, lane, h3, a3,
             [&]() __attribute__((always_inline)) {
-              fl_read_first<SPLIT, 1>(w4, lane, a4);
+              fl_read_first<8, 1>(w4, lane, a4);
             },
             dma_tick);
-        fl_pad<T, NB_HT3, 5, 0>(h3, lane);                   // unit 20
-        fl_layer_from<T, SPLIT, 6, 0, 1, true, NBF_P2, NBF_PD4, 0>(
+        fl_pad<T, NB_HT3, 5, 0>(h3, lane);
+        fl_layer_from<T, 8, 6, 0, 1, true, 2, 5, 0>(
             w4, 6, h3, lane, o, a4, []() __attribute__((always_inline)) {},
             dma_tick);
 #pragma unroll
         for (int t = 0; t < T; ++t) total[t] += o[t][0];
       }
-      NBF_TS(4);
-      dma_flush();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      NBF_TS(5);
+      stage_end();
     };
     for (int e = 0; e + 1 < E; ++e) network(e, std::false_type{});
     network(E - 1, std::true_type{});
+    q = cur;                         // where the next pass's block landed
 
-    // ---- epilogue ---------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const double score = __shfl(total[t], lane & 15) / (double)E;
@@ -448,12 +449,7 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
         a.out_f64[2 * pt[t] + 1] = score;
       }
     }
-    NBF_TS(6);
   }
-#ifdef NB_DBG_TIMING
-  if (a.counters != nullptr && threadIdx.x == 0 && blockIdx.x == 0)
-    for (int i = 0; i < 7; ++i) a.counters[8 + i] += ts_acc[i];
-#endif
   if (a.counters != nullptr && lane == 0) {
     atomicAdd(&a.counters[1], cnt_ell);
     atomicAdd(&a.counters[2], cnt_mlp);
@@ -462,9 +458,7 @@ __global__ void __launch_bounds__(256) nb_eval_fast_kernel(FastArgs a) {
 
 template <int DT, int KT1>
 int launch_fast(const FastArgs& a, hipStream_t stream) {
-  const size_t lds = ((size_t)fast_resident_doubles(DT) +
-                      (size_t)KT1 * NB_HT1 * NB_TILE + FAST_B_DOUBLES) *
-                     sizeof(double);
+  const size_t lds = (size_t)2 * FAST_REGION * sizeof(double);
   static bool configured = false;
   if (!configured) {
     const hipError_t e = hipFuncSetAttribute(
@@ -478,9 +472,9 @@ int launch_fast(const FastArgs& a, hipStream_t stream) {
     configured = true;
   }
   const long long n_super = (a.n + 127) / 128;
-  long long blocks = n_super < 256 ? n_super : 256;   // one workgroup per CU
+  long long blocks = n_super < 256 ? n_super : 256;
   hipLaunchKernelGGL((nb_eval_fast_kernel<DT, KT1>), dim3((unsigned)blocks),
-                     dim3(256), lds, stream, a);
+                     dim3(512), lds, stream, a);
   return NB_OK;
 }
 
@@ -488,10 +482,10 @@ int launch_fast(const FastArgs& a, hipStream_t stream) {
 
 unsigned long long* nb_eval_counters();
 
-// n_dim <= 63, one neural bound with networks, and for proposals at most one
-// outer member (the draw then needs no overlap count)
+// one neural bound with networks, and for proposals at most one outer member
+// (the draw then needs no overlap count)
 bool nb_eval_fast_eligible(int n_dim, int K, int M, int E, bool sample) {
-  if (n_dim > 63 || M != 1 || E < 1) return false;
+  if (n_dim > 128 || M != 1 || E < 1) return false;
   return !sample || K <= 1;
 }
 
@@ -514,6 +508,15 @@ int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample,
     case 12: rc = launch_fast<3, 3>(a, stream); break;
     case 13: rc = launch_fast<3, 4>(a, stream); break;
     case 16: rc = launch_fast<4, 4>(a, stream); break;
+    case 17: rc = launch_fast<4, 5>(a, stream); break;
+    case 20: rc = launch_fast<5, 5>(a, stream); break;
+    case 21: rc = launch_fast<5, 6>(a, stream); break;
+    case 24: rc = launch_fast<6, 6>(a, stream); break;
+    case 25: rc = launch_fast<6, 7>(a, stream); break;
+    case 28: rc = launch_fast<7, 7>(a, stream); break;
+    case 29: rc = launch_fast<7, 8>(a, stream); break;
+    case 32: rc = launch_fast<8, 8>(a, stream); break;
+    case 33: rc = launch_fast<8, 9>(a, stream); break;
     default:
       nb_set_error("nb_launch_eval_fast: n_dim=%d not eligible", n_dim);
       return NB_ERR_UNSUPPORTED;

@@ -133,6 +133,78 @@ __device__ __forceinline__ void fl_block(
   }
 }
 
+// K-chunked form of fl_block for a layer whose weights exceed an LDS region
+// (layer 1 for n_dim > 64): k-steps [KS_LO, KS_HI) of all output tiles of the
+// layer, `out` carries the pre-activations between the chunks, `w` is the
+// chunk in LDS (k-tile index relative to KS_LO / 4).  The runtime-guarded
+// k-steps are the last three of the layer.
+template <int T, int KSMAX, int HT, int KS_LO, int KS_HI, int TICK_P, int NIN,
+          int NOUT, class Tick>
+__device__ __forceinline__ void fl_chunk(
+    const double* w, int ks_n, const double (&in)[T][NIN], int lane,
+    double (&out)[T][NOUT], Tick&& tick) {
+  using S = FlShape<HT, 0, HT>;
+  constexpr int NF = S::NF, NA = S::NA, NFL = S::NFL;
+  static_assert(KS_LO % 4 == 0 && KS_LO < KS_HI && KS_HI <= KSMAX, "chunk");
+  constexpr bool FIRST = (KS_LO == 0);
+  constexpr int KS_U = (KS_HI < KSMAX - 3) ? KS_HI : KSMAX - 3;
+  static_assert(KS_U > KS_LO, "at least one unguarded k-step per chunk");
+  nb_d4 acc[T][NF];
+  double rem[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[t][h][r] = FIRST ? 0.0 : out[t][4 * h + r];
+    rem[t] = FIRST ? 0.0 : out[t][4 * NFL];
+  }
+  auto step = [&](int ks, const double (&a)[NA]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t][h] = MFMA(a[h], in[t][ks], acc[t][h]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) rem[t] = NB_MFMA4(a[NF], in[t][ks], rem[t]);
+  };
+  auto arrived = [&](const double (&a)[NA]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(a[i]));
+  };
+  double a[2][NA];
+  fl_read_a<HT, 0, HT>(w, 0, lane, a[0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = KS_LO; ks < KS_U; ++ks) {
+    const int i = ks - KS_LO;
+    arrived(a[i & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < KS_U) fl_read_a<HT, 0, HT>(w, i + 1, lane, a[(i + 1) & 1]);
+    if (i % TICK_P == 0) tick();
+    __builtin_amdgcn_sched_barrier(0);
+    step(ks, a[i & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int ks = (KS_LO > KS_U ? KS_LO : KS_U); ks < KS_HI; ++ks) {
+    if (ks < ks_n) {
+      double ag[NA];
+      fl_read_a<HT, 0, HT>(w, ks - KS_LO, lane, ag);
+      step(ks, ag);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][4 * h + r] = acc[t][h][r];
+    out[t][4 * NFL] = rem[t];
+  }
+}
+
 // a layer = blocks of SPLIT output tiles chained through their first operands
 template <int T, int SPLIT, int KSMAX, int NGUARD, int HT, bool RELU_IN,
           int TICK_P, int PD, int H0, int NIN, int NOUT, class Next, class Tick>
