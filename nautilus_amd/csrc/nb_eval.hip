@@ -24,8 +24,12 @@
 // the tile per MFMA.
 //
 // Workgroup structure: 4 wavefronts x 2 tiles = 128 points per workgroup pass
-// (1 tile per wavefront for n_dim > 64), one workgroup per CU (the kernel
+// (8 wavefronts x 1 tile for n_dim > 64), one workgroup per CU (the kernel
 // uses the whole register file), grid-stride over the 128-point super tiles.
+// The launches NautilusBound.sample spends its time in -- one neural bound, at
+// most one outer member -- go through nb_eval_fast.hip instead; this kernel
+// serves every other shape: bound lists (shell exclusion / association),
+// unions with several members, several neural bounds, overlap counts.
 // Emulator weights are the bulk of the operand traffic (132 KB per network
 // at D = 50), so they stream through two LDS regions of 38 tiles: while one
 // region feeds the matrix cores the other is refilled by global_load_lds DMA
@@ -34,8 +38,9 @@
 // (conflict-free ds_read_b64) and each wavefront shares every A operand
 // between its two tiles.  The partial last tile of every layer (4, 2, 4, 1
 // units) runs on v_mfma_f64_4x4x4_4b_f64.  Ellipsoid blocks are staged in LDS
-// per bound.  Measured on MI355X (profiles/r01/eval_pmc.md): 39 TFLOP/s
-// algorithmic at D = 50, HBM traffic 1.01x algorithmic, matrix pipe 56 % busy.
+// per bound.  Measured on MI355X: 44 TFLOP/s
+// algorithmic at D = 50 (0.56 of the fp64 MFMA peak), HBM traffic 1.02x
+// algorithmic.
 #include "nb_common.h"
 
 #include <cstdlib>
