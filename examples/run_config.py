@@ -29,6 +29,9 @@ def main():
                     help='default: the configuration\'s own batch size')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--timeout', type=float, default=np.inf)
+    ap.add_argument('--counters', action='store_true',
+                    help='point-evaluation counters of the bound kernels and '
+                         'HIP-event time per kernel family')
     args = ap.parse_args()
     c = baseline_config(args.name)
     t0 = time.time()
@@ -37,10 +40,23 @@ def main():
                 n_networks=c['n_networks'],
                 n_batch=args.n_batch or c['n_batch'],
                 vectorized=True, seed=args.seed)
-    ok = s.run(n_eff=args.n_eff, discard_exploration=True,
-               timeout=args.timeout)
-    torch.cuda.synchronize()
-    wall = time.time() - t0
+    extra = {}
+    if args.counters:
+        from nautilus_amd import device
+        with device.EvalCounters() as counters, \
+                device.KernelTimer() as timer:
+            ok = s.run(n_eff=args.n_eff, discard_exploration=True,
+                       timeout=args.timeout)
+            torch.cuda.synchronize()
+            wall = time.time() - t0
+            extra = dict(counters=counters.read(), kernels={
+                k: dict(launches=v['launches'], s=round(v['ms'] / 1e3, 2))
+                for k, v in timer.totals().items()})
+    else:
+        ok = s.run(n_eff=args.n_eff, discard_exploration=True,
+                   timeout=args.timeout)
+        torch.cuda.synchronize()
+        wall = time.time() - t0
     pts, log_w, _ = s.posterior()
     w = np.exp(log_w)
     mean = np.average(pts, weights=w, axis=0)
@@ -52,7 +68,8 @@ def main():
         n_neural_last=len(s.bounds[-1].neural_bounds)
         if len(s.bounds) > 1 else 0,
         n_proposals=int(s.n_proposals), mean_first3=mean[:3].round(4).tolist(),
-        timing={k: round(v, 2) for k, v in s.timing.items()})))
+        n_in_bound=int(np.sum(s.shell_n_sample)),
+        timing={k: round(v, 2) for k, v in s.timing.items()}, **extra)))
 
 
 if __name__ == '__main__':

@@ -47,13 +47,33 @@ def baseline_config(name):
         return dict(
             likelihood=GaussianMixtureLikelihood(means, 0.02), n_dim=50,
             n_live=5000, n_networks=4, n_batch=16384, analytic_log_z=0.0,
-            description='50-dim 4-mode Gaussian mixture, n_live=5000')
+            means=means, description='50-dim 4-mode Gaussian mixture, n_live=5000')
     if name == 'C5':
         return dict(
             likelihood=FunnelLikelihood(100), n_dim=100, n_live=10000,
-            n_networks=8, n_batch=8192, analytic_log_z=None,
+            n_networks=8, n_batch=8192,
+            analytic_log_z=funnel_log_z(100),
             description='100-dim Neal funnel, n_live=10000, n_networks=8')
     raise ValueError('unknown BASELINE configuration %r' % (name,))
+
+
+def funnel_log_z(n_dim, mu=0.5, sigma0=0.1, k=20.0, c=100.0):
+    """Evidence of the n_dim funnel on the unit cube: the likelihood is a
+    normalised density, so Z is the probability mass inside the cube -- the
+    quantity the reference's own funnel test estimates from 10^6 draws
+    (tests/test_sampler.py:316-322), here by quadrature over x_0:
+    Z = int_0^1 N(x_0; mu, sigma0) [Phi((1 - mu) / s) - Phi(-mu / s)]^(n_dim-1)
+    dx_0 with s = exp(k (x_0 - mu)) / c.  n_dim = 100: -0.07595 (the 10^6-draw
+    estimate with the conditional probabilities integrated out: -0.07597)."""
+    from scipy.integrate import quad
+    from scipy.stats import norm
+
+    def integrand(x0):
+        s = np.exp(k * (x0 - mu)) / c
+        p = norm.cdf((1.0 - mu) / s) - norm.cdf(-mu / s)
+        return norm.pdf(x0, mu, sigma0) * p ** (n_dim - 1)
+    z, _ = quad(integrand, 0.0, 1.0, epsabs=1e-13, epsrel=1e-13, limit=500)
+    return float(np.log(z))
 
 
 def headline_config(n_dim=50):

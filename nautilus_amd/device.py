@@ -536,7 +536,10 @@ class LivePool:
             self.select()
         keep = self.bufs[self.cur][:int(self.counts[self.cur])].clone()
         thr = self.thr.clone()
-        self._alloc(4 * self.k + (1 << 17))
+        # on a likelihood plateau every tied value at the threshold stays in
+        # the pool (n_gt + n_eq values, not n_live): leave room for them and
+        # for as many again before the next rebuild
+        self._alloc(max(4 * self.k, 2 * int(keep.shape[0])) + (1 << 17))
         self.bufs[0][:keep.shape[0]] = keep
         self.counts[0] = keep.shape[0]
         self.thr.copy_(thr)
@@ -639,6 +642,7 @@ class KernelTimer:
 
     def __init__(self):
         self.events = {}
+        self.folded = {}
 
     def __enter__(self):
         KernelTimer.active = self
@@ -647,13 +651,21 @@ class KernelTimer:
     def __exit__(self, *exc):
         KernelTimer.active = None
 
+    def _fold(self, name):
+        # long runs launch 10^5 kernels: keep a bounded number of live events
+        pairs = self.events.pop(name, [])
+        if pairs:
+            pairs[-1][1].synchronize()
+            acc = self.folded.setdefault(name, [0, 0.0])
+            acc[0] += len(pairs)
+            acc[1] += sum(a.elapsed_time(b) for a, b in pairs)
+
     def totals(self):
         torch.cuda.synchronize()
-        out = {}
-        for name, pairs in self.events.items():
-            out[name] = dict(launches=len(pairs),
-                             ms=sum(a.elapsed_time(b) for a, b in pairs))
-        return out
+        for name in list(self.events):
+            self._fold(name)
+        return {name: dict(launches=acc[0], ms=acc[1])
+                for name, acc in self.folded.items()}
 
 
 def _timed(name):
@@ -667,7 +679,10 @@ def _timed(name):
             a.record()
             out = fn(*args, **kwargs)
             b.record()
-            timer.events.setdefault(name, []).append((a, b))
+            pairs = timer.events.setdefault(name, [])
+            pairs.append((a, b))
+            if len(pairs) >= 1024:
+                timer._fold(name)
             return out
         wrapper.__name__ = fn.__name__
         wrapper.__doc__ = fn.__doc__

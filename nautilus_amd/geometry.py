@@ -17,17 +17,21 @@ bounds/basic.py:154-241 (MVEE), 265-316 (Ellipsoid.compute), 471-563
 153-229 (split), 231-267 (trim).
 """
 
+import hashlib
 import itertools
 from collections import OrderedDict
+from contextlib import contextmanager
 
 import numpy as np
-import xxhash
 from scipy.linalg.lapack import dpotrf, dpotri
 from scipy.optimize import minimize
 from scipy.special import gammaln, logsumexp
-from contextlib import contextmanager
-
 from threadpoolctl import threadpool_limits
+
+try:                      # ~10x faster than hashlib; optional
+    import xxhash
+except ImportError:       # pragma: no cover
+    xxhash = None
 
 _BLAS_LIMITED = 0
 
@@ -98,8 +102,12 @@ def _cache_key(points, enlarge_per_dim):
     rows = _host_rows(points)
     if rows is None:
         return None
-    return (rows.shape, xxhash.xxh64(rows.view(np.uint8).reshape(-1)).digest(),
-            float(enlarge_per_dim))
+    flat = rows.view(np.uint8).reshape(-1)
+    if xxhash is not None:
+        digest = xxhash.xxh64(flat).digest()
+    else:
+        digest = hashlib.blake2b(flat, digest_size=16).digest()
+    return (rows.shape, digest, float(enlarge_per_dim))
 
 
 def _ellipsoid_task(points, enlarge_per_dim):

@@ -250,11 +250,20 @@ def read_bound(cls, group, rng=None):
         bound.outer_bound._queue().clear()
         bound.n_sample = int(group.attrs['n_sample'])
         bound.n_reject = int(group.attrs['n_reject'])
-        if 'amd_points' in group and 'amd_philox_seed' in group.attrs:
-            _set_queue(bound, np.array(group['amd_points'], dtype=float))
-        else:                            # a file written by the reference
-            _set_queue(bound, _queue_points(
-                bound, np.array(group['points'], dtype=float)))
+        file_pts = np.array(group['points'], dtype=float)
+        raw = (np.array(group['amd_points'], dtype=float)
+               if 'amd_points' in group and 'amd_philox_seed' in group.attrs
+               else None)
+        # 'amd_points' is only trusted while it still describes 'points': the
+        # reference's update() (bounds/nautilus.py:328-342) rewrites 'points'
+        # alone when it continues a file written here
+        if (raw is not None and raw.shape == file_pts.shape and
+                (len(raw) == 0 or np.allclose(
+                    bound.shift.transform(raw) if bound.shift is not None
+                    else raw, file_pts, rtol=0, atol=1e-12))):
+            _set_queue(bound, raw)
+        else:                            # written / continued by the reference
+            _set_queue(bound, _queue_points(bound, file_pts))
     elif cls is nb.PhaseShift:
         bound.periodic = np.array(group.attrs['periodic'])
         bound.centers = np.array(group.attrs['centers'], dtype=float)

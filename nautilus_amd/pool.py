@@ -44,6 +44,23 @@ def _start_method():
     return 'fork'
 
 
+def _require_picklable(likelihood):
+    """A fork server starts its workers from a clean process: the likelihood
+    reaches them by pickle.  Say so instead of a bare PicklingError from the
+    pool's initializer."""
+    import pickle
+    try:
+        pickle.dumps(likelihood)
+    except Exception as err:
+        raise ValueError(
+            'The HIP runtime of this process is already initialised, so the '
+            'likelihood workers are started through a fork server and the '
+            'likelihood must be picklable (a module-level function, not a '
+            'lambda or closure): {}.  Create the Sampler with pool=<int> '
+            'before any other GPU use, or pass a pool object.'.format(err)
+        ) from err
+
+
 class NautilusPool:
     """``map`` / ``size`` over an integer (a new ``multiprocessing`` pool), a
     ``multiprocessing.Pool``, an executor, a dask client or anything else
@@ -51,7 +68,10 @@ class NautilusPool:
 
     def __init__(self, pool, likelihood=None):
         if isinstance(pool, numbers.Integral) and not isinstance(pool, bool):
-            context = multiprocessing.get_context(_start_method())
+            method = _start_method()
+            if method != 'fork' and likelihood is not None:
+                _require_picklable(likelihood)
+            context = multiprocessing.get_context(method)
             self.pool = context.Pool(int(pool), initializer=_install_likelihood,
                                      initargs=(likelihood, ))
         else:

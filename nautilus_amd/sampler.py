@@ -437,6 +437,7 @@ class Sampler:
                         '_shell_max'):
                 setattr(self, key, np.delete(getattr(self, key), s))
         self._later = {}
+        self._live = None
         self.shell_n_sample_exp = np.copy(self.shell_n_sample)
         self.shell_end_exp = np.array([len(ll) for ll in self.log_l])
         self.explored = True
@@ -682,7 +683,9 @@ class Sampler:
         t2 = time()
         self._pts[shell].append(pts)
         self._ll_dev[shell].append(log_l_dev)
-        if not self.explored and self.__dict__.get('_live') is not None:
+        if self.explored:
+            self._live = None      # log_v_live rebuilds it from the shells
+        elif self.__dict__.get('_live') is not None:
             self._live.add(log_l_dev)
         self.log_l[shell] = np.append(self.log_l[shell], log_l)
         if blobs is not None:                      # sampler.py:1137-1141

@@ -337,6 +337,44 @@ def e2e_cases():
     save('shellstats', **arrays)
 
 
+def liveset_case():
+    """The live set of the exploration phase (sampler.py:1147-1190): snapshots
+    of the per-shell log L, volumes and counts of a reference run in progress
+    with the reference's own ``f_live`` / ``log_v_live`` at that moment."""
+    s = nautilus.Sampler(lambda x: x, gauss3, n_dim=3, n_live=300,
+                         n_networks=0, vectorized=True, seed=11, n_batch=64)
+    snaps = []
+    orig = s.add_samples
+    calls = [0]
+
+    def recording(*args, **kwargs):
+        out = orig(*args, **kwargs)
+        calls[0] += 1
+        if not s.explored and calls[0] % 9 == 0 and len(s.bounds) > 0:
+            snaps.append(dict(
+                log_l=[np.copy(ll) for ll in s.log_l],
+                shell_log_v=np.copy(s.shell_log_v),
+                shell_n=np.copy(s.shell_n), f_live=s.f_live,
+                log_v_live=s.log_v_live, log_z=s.log_z,
+                n_bounds=len(s.bounds)))
+        return out
+    s.add_samples = recording
+    s.run(n_eff=500)
+    arrays = dict(n_snap=len(snaps), n_live=300)
+    for k, sn in enumerate(snaps):
+        arrays['s%d_shell_log_v' % k] = sn['shell_log_v']
+        arrays['s%d_shell_n' % k] = sn['shell_n']
+        arrays['s%d_f_live' % k] = sn['f_live']
+        arrays['s%d_log_v_live' % k] = sn['log_v_live']
+        arrays['s%d_log_z' % k] = sn['log_z']
+        arrays['s%d_n_bounds' % k] = sn['n_bounds']
+        for i, ll in enumerate(sn['log_l']):
+            arrays['s%d_log_l_%d' % (k, i)] = ll
+    print('liveset: %d snapshots, last with %d bounds' % (
+        len(snaps), snaps[-1]['n_bounds']))
+    save('liveset', **arrays)
+
+
 def gauss20(x):
     """BASELINE config 2: mu = 0.5, Sigma = sigma^2
     (0.5 11^T + 0.5 I), sigma = 0.05; analytic log Z = 0."""
@@ -411,6 +449,9 @@ if __name__ == '__main__':
     if '--e2e-C2' in sys.argv:
         e2e_config_sweep('C2', range(6), [True], 6)
         sys.exit(0)
+    if '--liveset-only' in sys.argv:
+        liveset_case()
+        sys.exit(0)
     if '--periodic-only' in sys.argv:
         periodic_cases()
         sys.exit(0)
@@ -427,3 +468,4 @@ if __name__ == '__main__':
     neural_and_nautilus_case()
     periodic_cases()
     e2e_cases()
+    liveset_case()

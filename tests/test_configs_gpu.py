@@ -1,15 +1,16 @@
 """The five BASELINE.json configurations at their REAL sizes (n_dim, n_live,
 n_networks, device likelihood) on one GPU.
 
-C1 and C2 run to completion and are held against the analytic evidence and
-the band of the reference's own runs of the same problem
-(tests/golden/e2e_C1.json, e2e_C2.json, written by make_golden.py).  C3, C4
-and C5 need minutes to hours even here (the reference: hours to days), so by
-default they run for a bounded wall time and the test asserts what must hold
-at any point of a run -- every bound built on the device, volumes shrinking,
-evidence finite and consistent with its shells; with ``NB_FULL_CONFIGS=1``
-they run to completion and are compared with the analytic evidence (C4) or
-the committed full runs (profiles/r02/configs.json)."""
+C1, C2 and C3 run to completion and are held against the analytic evidence
+and the reference's own runs of the same problem (tests/golden/e2e_C1.json,
+e2e_C2.json, e2e_C3.json, written by make_golden.py / make_golden_c3.py).  C4
+runs its whole exploration and a sampling phase to a reduced N_eff against the
+analytic evidence.  C5 needs ~20 minutes even here, so by default it runs for
+a bounded wall time and the test asserts what must hold at any point of a run
+-- every bound built on the device, volumes shrinking, evidence finite and
+consistent with its shells; with ``NB_FULL_CONFIGS=1`` C4 and C5 run to the
+reference's default N_eff = 10 000 (committed full runs:
+profiles/r03/configs.json)."""
 
 import json
 import os
@@ -123,43 +124,71 @@ def test_gaussian_configs_against_reference_runs(name, seeds):
 
 
 def _committed(name):
-    path = os.path.join(ROOT, 'profiles', 'r02', 'configs.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get(name)
+    for rnd in ('r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', rnd, 'configs.json')
+        if os.path.exists(path):
+            with open(path) as f:
+                row = json.load(f).get(name)
+            if row is not None and row.get('finished'):
+                return row
+    return None
 
 
-@pytest.mark.parametrize('name,budget,min_bounds', [
-    ('C3', 45.0, 6), ('C4', 60.0, 4), ('C5', 100.0, 2)])
-def test_large_configs_real_size(name, budget, min_bounds):
-    """C3 (30-D Rosenbrock, n_live 3000), C4 (50-D four-mode mixture, n_live
-    5000), C5 (100-D funnel, n_live 10000, 8 networks) at their real sizes.
-    Default: ``budget`` seconds of the run, then the invariants of a run in
-    progress (C5 exercises the n_dim > 64 kernels and the device MVEE /
-    mixture fit at 100 dimensions).  NB_FULL_CONFIGS=1: the whole run."""
-    c, s, done, host_calls = _run(name, timeout=np.inf if FULL else budget)
-    assert not host_calls          # no scikit-learn fallback at any n_dim
+def test_C3_rosenbrock_full_run_against_the_reference():
+    """C3 (30-D Rosenbrock, n_live 3000, NeuralBound active) to completion
+    with the reference's defaults, held against the reference's OWN full run
+    of the same problem (tests/golden/e2e_C3.json: 3.2 h on four cores;
+    make_golden_c3.py).  Both samplers miss the exact evidence (transfer
+    quadrature, helpers.rosenbrock_log_z_exact) by ~0.7: what an emulator
+    cuts off is lost to all later shells."""
+    c, s, done, host_calls = _run('C3')
+    assert not host_calls          # no scikit-learn fallback
     _invariants(c, s)
-    assert len(s.bounds) >= min_bounds
-    if not FULL:
-        return
-    assert done and s.n_eff >= 10000
-    if name == 'C4':
-        # four separated modes: the decomposition finds them
-        assert max(len(b.neural_bounds) for b in s.bounds[1:]) >= 4
-    if name == 'C3':
-        # 30-D Rosenbrock: the reference's own full run (e2e_C3.json, 3.2 h on
-        # four cores) is the yardstick -- it misses the exact evidence
-        # (transfer quadrature, helpers.rosenbrock_log_z_exact) by 0.73, so
-        # does this sampler at the same batch size
-        _, ref = _reference_band('C3')
-        assert abs(s.log_z - ref[0]['log_z']) < 0.3
-        assert 0.8 * ref[0]['n_like'] < s.n_like < 1.25 * ref[0]['n_like']
-        assert abs(len(s.bounds) - ref[0]['n_bounds']) <= 10
-        assert -1.5 < s.log_z - c['analytic_log_z'] < 0.1
-    elif c['analytic_log_z'] is not None:
-        assert abs(s.log_z - c['analytic_log_z']) < 0.05
-    ours = _committed(name)
-    if ours is not None and ours.get('finished'):
+    assert done and s.explored and s.n_eff >= 10000
+    _, ref = _reference_band('C3')
+    assert abs(s.log_z - ref[0]['log_z']) < 0.3
+    assert 0.8 * ref[0]['n_like'] < s.n_like < 1.25 * ref[0]['n_like']
+    assert abs(len(s.bounds) - ref[0]['n_bounds']) <= 10
+    assert -1.5 < s.log_z - c['analytic_log_z'] < 0.1
+    ours = _committed('C3')
+    if ours is not None:
         assert abs(s.log_z - ours['log_z']) < 0.2
+
+
+def test_C4_mixture_explored_and_evidence():
+    """C4 (50-D four-mode mixture, n_live 5000, multi-ellipsoid Union bound):
+    the whole exploration plus a sampling phase to N_eff = 2000 (10 000 with
+    NB_FULL_CONFIGS=1; the exploration is ~95 % of either).  The evidence is
+    analytic (0), and the decomposition must find the four modes: bounds with
+    at least four neural bounds / ellipsoids exist."""
+    c, s, done, host_calls = _run('C4', n_eff=10000 if FULL else 2000)
+    assert not host_calls
+    _invariants(c, s)
+    assert done and s.explored
+    assert max(len(b.neural_bounds) for b in s.bounds[1:]) >= 4
+    assert max(b.n_ell for b in s.bounds[1:]) >= 4
+    # N_eff = 2000: sigma(log Z) ~ 1 / sqrt(N_eff) = 0.022
+    assert abs(s.log_z - c['analytic_log_z']) < (0.05 if FULL else 0.08)
+    # posterior mass splits evenly over the four modes
+    pts, log_w, _ = s.posterior()
+    w = np.exp(log_w)
+    means = c['means']
+    mode = np.argmin(((pts[:, None, :] - means[None]) ** 2).sum(-1), axis=1)
+    share = np.array([w[mode == k].sum() for k in range(len(means))])
+    assert np.all(np.abs(share / share.sum() - 0.25) < 0.06)
+
+
+def test_C5_funnel_real_size():
+    """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
+    the device MVEE / mixture fit at 100 dimensions.  Default: 60 s of the
+    run and the invariants of a run in progress; NB_FULL_CONFIGS=1: the whole
+    run against the Monte-Carlo evidence of the reference's own funnel test
+    (tests/test_sampler.py:311-326) -- the committed full run is in
+    profiles/r03/configs.json."""
+    c, s, done, host_calls = _run('C5', timeout=np.inf if FULL else 60.0)
+    assert not host_calls
+    _invariants(c, s)
+    assert len(s.bounds) >= 2
+    if FULL:
+        assert done and s.n_eff >= 10000
+        assert abs(s.log_z - c['analytic_log_z']) < 0.1

@@ -681,13 +681,8 @@ def test_periodic_nautilus_bound(dev):
     assert abs(full.log_v - float(g['log_v'])) < 0.1
 
 
-@pytest.mark.parametrize('gather', [False, True])
-def test_shell_exclusion_and_association(dev, nautilus_d4, neural_d4, gather,
-                                         monkeypatch):
-    """sampler.py:797-798 and 1213-1219 over a list of nested bounds, with
-    the dense and the gathered kernel variant."""
-    if gather:
-        monkeypatch.setenv('NB_EVAL_GATHER', '1')
+def test_shell_exclusion_and_association(dev, nautilus_d4, neural_d4):
+    """sampler.py:797-798 and 1213-1219 over a list of nested bounds."""
     import torch
     from oracle import bounds_oracle as bo
     g, ob = nautilus_d4

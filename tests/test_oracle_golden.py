@@ -180,6 +180,22 @@ def test_shell_statistics_match_reference():
     assert np.array_equal(lw, g['log_w'])
 
 
+def test_live_set_matches_reference():
+    """f_live / log_v_live (sampler.py:1147-1190) of a reference run in
+    progress: nine snapshots of the per-shell state, the reference's values."""
+    g = load_golden('liveset')
+    for k in range(int(g['n_snap'])):
+        s = so.OSampler.__new__(so.OSampler)
+        s.explored = False
+        s.n_live = int(g['n_live'])
+        s.shell_n = g['s%d_shell_n' % k]
+        s.shell_log_v = g['s%d_shell_log_v' % k]
+        s.bounds = [None] * int(g['s%d_n_bounds' % k])
+        s.log_l = [g['s%d_log_l_%d' % (k, i)] for i in range(len(s.shell_n))]
+        assert s.f_live == float(g['s%d_f_live' % k])
+        assert s.log_v_live == float(g['s%d_log_v_live' % k])
+
+
 def _gauss3(x):
     return -0.5 * np.sum(((x - np.array([0.4, 0.5, 0.6])) / 0.1)**2, axis=-1)
 
