@@ -97,8 +97,10 @@ const char* nb_last_error(void);
 
 /* Upload a bound (host description -> packed HBM blob).  Replaces the
  * in-memory state built by *.compute (basic.py:265-316, union.py:78-151,
- * bounds/neural.py:58-97, nautilus.py:88-144); construction itself (MVEE, GMM
- * split) stays on the host.                */
+ * bounds/neural.py:58-97, nautilus.py:88-144) once the host logic of the
+ * construction has decided the shape; the numerical work of the construction
+ * is further down: nb_mvee_*, nb_gmm_fit, nb_trainer_* (SURVEY.md section 8
+ * rows f1/f2).                                                              */
 int nb_bound_create(const nb_bound_desc* desc, nb_bound** out);
 int nb_bound_destroy(nb_bound* bound);
 int64_t nb_bound_nbytes(const nb_bound* bound);
@@ -357,9 +359,14 @@ int nb_loglike_funnel(const double* u_dev, int64_t n, int32_t n_dim, double mu,
  * mixture/_base.py:fit_predict does).  scratch_dev: n_init *
  * nb_gmm_scratch_doubles(n, n_dim) doubles.  init_labels_dev (optional,
  * [n_init][n] int32 in {0,1}) replaces the k-means initialisation.
- * n_dim <= 63.                                                               */
+ * n_dim <= 128.  After the call the scratch of restart r holds, from double
+ * nb_gmm_logp_offset(n_dim) on, log(w_k N(x_i; mu_k, Sigma_k)) of all points
+ * under the returned parameters, [n] for component 0 then [n] for component 1
+ * -- the hard assignment of union.py:188-197 without a second pass over the
+ * points on the host.                                                         */
 int64_t nb_gmm_out_doubles(int32_t n_dim);
 int64_t nb_gmm_scratch_doubles(int64_t n, int32_t n_dim);
+int64_t nb_gmm_logp_offset(int32_t n_dim);
 int nb_gmm_fit(const double* x_dev, int64_t n, int32_t n_dim, int32_t n_init,
                uint64_t seed, double tol, double reg_covar, int32_t max_iter,
                const int32_t* init_labels_dev, double* out_dev,

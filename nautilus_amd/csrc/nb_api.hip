@@ -824,6 +824,11 @@ int64_t nb_gmm_scratch_doubles(int64_t n, int32_t n_dim) {
   return nb_gmm_scratch_stride_impl(n, n_dim);
 }
 
+int64_t nb_gmm_logp_offset(int32_t n_dim) {
+  const int64_t m = (int64_t)n_dim + 1;
+  return (m * m + 1) & ~(int64_t)1;
+}
+
 int nb_gmm_fit(const double* x, int64_t n, int32_t n_dim, int32_t n_init,
                uint64_t seed, double tol, double reg_covar, int32_t max_iter,
                const int32_t* init_labels, double* out, double* scratch,

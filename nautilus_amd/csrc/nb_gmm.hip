@@ -302,41 +302,9 @@ nb_gmm_kernel(GmmArgs a) {
   double pi0 = 0.5, pi1 = 0.5;
   bool failed = sh_bad != 0;
   const int ks_max = 4 * DT;
-  for (int it = 0; it <= a.max_iter && !failed; ++it) {
-    // M-step (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters)
-    moments(r0);
-    const double s00 = moment(d, d);
-    const double nk0 = s00 + eps10;
-    const double nk1 = ((double)n - s00) + eps10;
-    pi0 = nk0 / (nk0 + nk1);      // _m_step: weights_ /= weights_.sum()
-    pi1 = nk1 / (nk0 + nk1);
-    for (int f = tid; f < d; f += GM_THREADS) {
-      const double s0 = moment(d, f);
-      o_mean[f] = s0 / nk0;
-      o_mean[d + f] = (sall[d * m + f] - s0) / nk1;
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int e = tid; e < d * d; e += GM_THREADS) {
-      const int r = e / d, c = e - r * d;
-      if (c > r) continue;
-      const double s0 = moment(r, c);
-      const double s1 = sall[r * m + c] - s0;
-      const double reg = (r == c) ? a.reg : 0.0;
-      const double m0r = ((volatile double*)o_mean)[r], m0c = ((volatile double*)o_mean)[c];
-      const double m1r = ((volatile double*)o_mean)[d + r], m1c = ((volatile double*)o_mean)[d + c];
-      const double c0 = s0 / nk0 - m0r * m0c + reg;
-      const double c1 = s1 / nk1 - m1r * m1c + reg;
-      o_cov[r * d + c] = c0;
-      o_cov[c * d + r] = c0;
-      o_cov[d * d + r * d + c] = c1;
-      o_cov[d * d + c * d + r] = c1;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (it == a.max_iter || converged) break;
-
-    // E-step (mixture/_base.py:_estimate_log_prob_resp)
+  // weighted log probabilities of both components for all points with the
+  // current parameters (mixture/_base.py:_estimate_weighted_log_prob)
+  auto log_prob = [&]() {
     for (int k = 0; k < 2; ++k) {
       const volatile double* cov = (volatile double*)o_cov + k * d * d;
       const volatile double* mean = (volatile double*)o_mean + k * d;
@@ -397,6 +365,43 @@ nb_gmm_kernel(GmmArgs a) {
       __threadfence_block();
       __syncthreads();
     }
+  };
+  for (int it = 0; it <= a.max_iter && !failed; ++it) {
+    // M-step (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters)
+    moments(r0);
+    const double s00 = moment(d, d);
+    const double nk0 = s00 + eps10;
+    const double nk1 = ((double)n - s00) + eps10;
+    pi0 = nk0 / (nk0 + nk1);      // _m_step: weights_ /= weights_.sum()
+    pi1 = nk1 / (nk0 + nk1);
+    for (int f = tid; f < d; f += GM_THREADS) {
+      const double s0 = moment(d, f);
+      o_mean[f] = s0 / nk0;
+      o_mean[d + f] = (sall[d * m + f] - s0) / nk1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int e = tid; e < d * d; e += GM_THREADS) {
+      const int r = e / d, c = e - r * d;
+      if (c > r) continue;
+      const double s0 = moment(r, c);
+      const double s1 = sall[r * m + c] - s0;
+      const double reg = (r == c) ? a.reg : 0.0;
+      const double m0r = ((volatile double*)o_mean)[r], m0c = ((volatile double*)o_mean)[c];
+      const double m1r = ((volatile double*)o_mean)[d + r], m1c = ((volatile double*)o_mean)[d + c];
+      const double c0 = s0 / nk0 - m0r * m0c + reg;
+      const double c1 = s1 / nk1 - m1r * m1c + reg;
+      o_cov[r * d + c] = c0;
+      o_cov[c * d + r] = c0;
+      o_cov[d * d + r * d + c] = c1;
+      o_cov[d * d + c * d + r] = c1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (it == a.max_iter || converged) break;
+
+    // E-step (mixture/_base.py:_estimate_log_prob_resp)
+    log_prob();
     failed = sh_bad != 0;
     double lse_part = 0.0;
     for (int i = tid; i < n; i += GM_THREADS) {
@@ -412,6 +417,13 @@ nb_gmm_kernel(GmmArgs a) {
     n_iter = it + 1;
     if (fabs(lb - lower) < a.tol) converged = 1;
     lower = lb;
+  }
+  // the log probabilities under the FINAL parameters (those of the last
+  // M-step) stay in the scratch of this restart: Union.split assigns every
+  // point to its more probable component (bounds/union.py:188-197)
+  if (!failed) {
+    log_prob();
+    failed = sh_bad != 0;
   }
   if (tid == 0) {
     out[0] = failed ? -inf : lower;

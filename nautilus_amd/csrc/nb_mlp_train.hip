@@ -14,9 +14,11 @@
 //      from the same 16x16 tile-major weights; every weight operand is
 //      loaded before the first barrier; activations and deltas go row-major
 //      to a stash in global memory (L2 resident, ~0.8 MB per network).
-//  G   one wavefront per 16x16 weight tile: dW = act^T delta contracted over all
-//      rows of the minibatch in a fixed order (deterministic, no atomics),
-//      then the Adam update of that tile in place.  The bias is row K of the
+//  G   one workgroup of four wavefronts per 16x16 weight tile: dW = act^T delta
+//      over the rows of the minibatch, wavefront q contracting k-step q of
+//      every 16-row tile; the four partial tiles meet in LDS, are added in a
+//      fixed order (deterministic, no atomics) and every wavefront applies
+//      Adam to a quarter of the tile in place.  The bias is row K of the
 //      weight matrix (the activations carry a constant 1 in column K).
 //
 // Minibatch order comes from the host (numpy RandomState shuffles identical to
@@ -138,8 +140,9 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
 // cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows)
 // (n_unit is a multiple of 16: thread -> row tid / 16, 16 consecutive units)
 __device__ __forceinline__ void flush_stash(const double* act, double* dst,
-                                            int ld, int n_unit, int tile) {
-  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+                                            int ld, int n_unit, int tile,
+                                            int tid) {
+  const int r = tid >> 4, c = tid & 15;
   double* row = dst + (long long)(tile * 16 + r) * ld;
   for (int u = c; u < n_unit; u += 16) row[u] = act[u * LS + r];
 }
@@ -266,27 +269,55 @@ __device__ long long g_train_ticks[64];
 #define FB_STAMP(i)
 #endif
 
+// LDS of a workgroup: the activation / delta blocks of FB in [unit][row]
+// layout; the G phase reuses everything behind the input block (whose zero
+// padding has to survive the step) for its partial tiles.
+// weight tiles per workgroup and step in the resident kernel (32 workgroups)
+template <int DT>
+struct GTiles {
+  static constexpr int N = (NB_HT1 * (DT + 1) + 38 + 31) / 32;
+};
+
+template <int DT>
+struct FbLds {
+  static constexpr int LD0MAX = 16 * (DT + 1);
+  static constexpr int A0 = 0;
+  static constexpr int A1 = A0 + LD0MAX * LS;
+  static constexpr int A2 = A1 + LD1 * LS;
+  static constexpr int A3 = A2 + LD2 * LS;
+  static constexpr int D4 = A3 + LD3 * LS;
+  static constexpr int D3 = D4 + LD4 * LS;
+  static constexpr int D2 = D3 + LD3 * LS;
+  static constexpr int TOTAL = D2 + LD2 * LS;
+  static constexpr int G_RED = A1;             // 1024 doubles per tile
+};
+
 template <int DT, bool CHECK_DONE>
 __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
                                         int net, int tile, int ep,
                                         long long start, int nb,
                                         const FbRows<DT>& rows,
-                                        bool zero_input) {
+                                        bool zero_input, double* lds) {
   constexpr int KS1MAX = 4 * DT + 1;
   constexpr int LD0MAX = 16 * (DT + 1);
   // activations / deltas of the tile in [unit][row] layout
-  __shared__ __attribute__((aligned(16))) double sA0[LD0MAX * LS];
-  __shared__ __attribute__((aligned(16))) double sA1[LD1 * LS];
-  __shared__ __attribute__((aligned(16))) double sA2[LD2 * LS];
-  __shared__ __attribute__((aligned(16))) double sA3[LD3 * LS];
-  __shared__ __attribute__((aligned(16))) double sD4[LD4 * LS];
-  __shared__ __attribute__((aligned(16))) double sD3[LD3 * LS];
-  __shared__ __attribute__((aligned(16))) double sD2[LD2 * LS];
+  double* sA0 = lds + FbLds<DT>::A0;
+  double* sA1 = lds + FbLds<DT>::A1;
+  double* sA2 = lds + FbLds<DT>::A2;
+  double* sA3 = lds + FbLds<DT>::A3;
+  double* sD4 = lds + FbLds<DT>::D4;
+  double* sD3 = lds + FbLds<DT>::D3;
+  double* sD2 = lds + FbLds<DT>::D2;
 
   if (CHECK_DONE) {
     if (st.scal[4] != 0.0) return;               // network already stopped
   }
-  const int lane = threadIdx.x & 63;
+  // (opaque to the optimiser: the per-lane addresses of this function are
+  // recomputed every step -- a few dozen VALU instructions -- instead of being
+  // hoisted out of the resident kernel's step loop and spilled)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int D = a.n_dim, kt1 = a.kt1;
@@ -335,7 +366,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   // (the padding only has to be cleared once per launch: every step rewrites
   // exactly the rows below ld0)
   if (zero_input) {
-    for (int i = threadIdx.x; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
+    for (int i = tid; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
   }
   lds_barrier();
   FB_STAMP(10);
@@ -349,7 +380,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   if constexpr (DT > 4) load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
   // the stash for the G phase is written as soon as a block is complete
   // (coalesced, fire and forget: the stores overlap the next layer)
-  flush_stash(sA0, A0, ld0, ld0, tile);
+  flush_stash(sA0, A0, ld0, ld0, tile, tid);
 
   // ---- layer 1: output tiles wave, wave + 4 ------------------------------
   {
@@ -377,12 +408,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   load_fwd<6>(W4, 1, 0, 6, lane, w4r);
   load_bwd<1>(W4, 1, wave & 1, lane, b4r);
   load_bwd<5>(W3, NB_HT3, wave, lane, b3r);
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
-    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
-  }
-  flush_stash(sA1, A1, LD1, LD1, tile);
+  flush_stash(sA1, A1, LD1, LD1, tile, tid);
 
   // ---- layer 2: output tile = wave ----------------------------------------
   {
@@ -399,7 +425,14 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(13);
-  flush_stash(sA2, A2, LD2, LD2, tile);
+  // (the operands of the last backward product take the registers layer 2's
+  // have left; five stages until they are needed)
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
+    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
+  }
+  flush_stash(sA2, A2, LD2, LD2, tile, tid);
 
   // ---- layer 3: two output tiles ------------------------------------------
   if (wave < NB_HT3) {
@@ -416,7 +449,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(14);
-  flush_stash(sA3, A3, LD3, LD3, tile);
+  flush_stash(sA3, A3, LD3, LD3, tile, tid);
 
   // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
   if (wave == 0) {
@@ -437,7 +470,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(15);
-  flush_stash(sD4, D4, LD4, LD4, tile);
+  flush_stash(sD4, D4, LD4, LD4, tile, tid);
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
   if (wave < NB_HT3) {
@@ -454,7 +487,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(16);
-  flush_stash(sD3, D3, LD3, LD3, tile);
+  flush_stash(sD3, D3, LD3, LD3, tile, tid);
 
   // ---- delta 2 --------------------------------------------------------------
   {
@@ -471,7 +504,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(17);
-  flush_stash(sD2, D2, LD2, LD2, tile);
+  flush_stash(sD2, D2, LD2, LD2, tile, tid);
 
   // ---- delta 1 --------------------------------------------------------------
   {
@@ -499,21 +532,24 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 template <int DT>
 __global__ void __launch_bounds__(256)
 nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
+  __shared__ __attribute__((aligned(16))) double lds[FbLds<DT>::TOTAL];
   const NetState st = a.nets[blockIdx.y];
   FbRows<DT> rows;
   fb_gather<DT>(a, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb, rows);
   fb_body<DT, true>(a, st, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb,
-                    rows, true);
+                    rows, true, lds);
 }
 
-// ---- G: dW of one 16x16 weight tile over the minibatch + Adam, one wavefront
+// ---- G: dW of 16x16 weight tiles over the minibatch + Adam ------------------
 // the step's loss partials folded into the epoch sum, in tile order
-// (deterministic); one lane
-__device__ __forceinline__ void loss_fold(const NetState& st, int nb) {
+// (deterministic); one wavefront, partial i in lane i
+__device__ __forceinline__ void loss_fold(const NetState& st, int nb,
+                                          int lane) {
   const int n_tiles = (nb + 15) >> 4;
+  const double p = (lane < n_tiles) ? st.scal[8 + lane] : 0.0;
   double acc = st.scal[5];
-  for (int i = 0; i < n_tiles; ++i) acc += st.scal[8 + i];
-  st.scal[5] = acc;
+  for (int i = 0; i < n_tiles; ++i) acc += __shfl(p, i);
+  if (lane == 0) st.scal[5] = acc;
 }
 
 // step size of Adam step t (sklearn _stochastic_optimizers.py:276-279)
@@ -522,20 +558,22 @@ __device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) 
          (1.0 - pow(a.b1, (double)t_adam));
 }
 
-template <bool STANDALONE>
-__device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
-                                       int gt, int lane, int nb,
-                                       double lr_t) {
-  if (STANDALONE) {
-    if (st.scal[4] != 0.0) return;
-  }
-  const int li = lane & 15, lg = lane >> 4;
+constexpr int G_ROWT = MAXB / 16;   // 16-row tiles of a minibatch
+
+struct GTile {
+  const double* as;   // activations, column block of the tile (wave-uniform)
+  const double* bs;   // deltas, column block of the tile (wave-uniform)
+  int lda, ldb;       // row strides
+  long long woff;     // offset of the weight tile
+};
+
+// (everything here is wave-uniform: scalar registers)
+__device__ __forceinline__ GTile g_decode(const TrainArgs& a,
+                                          const NetState& st, int gt) {
   const int kt1 = a.kt1;
   const int ld0 = 16 * kt1;
-  const int n_tiles = (nb + 15) >> 4;
   const int n_gt1 = kt1 * NB_HT1, n_gt2 = NB_HT1 * NB_HT2,
             n_gt3 = NB_HT2 * NB_HT3;
-
   const double* A0 = st.stash;
   const double* A1 = A0 + MAXB * ld0;
   const double* A2 = A1 + MAXB * LD1;
@@ -544,35 +582,50 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
   const double* D2 = D1 + MAXB * LD1;
   const double* D3 = D2 + MAXB * LD2;
   const double* D4 = D3 + MAXB * LD3;
-
-  // two-launch form: the first workgroup also folds the step's loss (the
-  // resident kernel gives that to an otherwise idle wavefront)
-  if (STANDALONE && gt == 0 && lane == 0) loss_fold(st, nb);
-
-  const double* As; const double* Bs; int lda, ldb, kt, ht;
-  long long woff;
+  int kt, ht;
+  GTile t;
   if (gt < n_gt1) {
-    kt = gt / NB_HT1; ht = gt % NB_HT1; As = A0; lda = ld0; Bs = D1;
-    ldb = LD1;
-    woff = (long long)(kt * NB_HT1 + ht) * NB_TILE;
+    kt = gt / NB_HT1; ht = gt % NB_HT1; t.as = A0; t.lda = ld0; t.bs = D1;
+    t.ldb = LD1;
+    t.woff = (long long)(kt * NB_HT1 + ht) * NB_TILE;
   } else if (gt < n_gt1 + n_gt2) {
     const int g = gt - n_gt1;
-    kt = g / NB_HT2; ht = g % NB_HT2; As = A1; lda = LD1; Bs = D2; ldb = LD2;
-    woff = (long long)(n_gt1 + kt * NB_HT2 + ht) * NB_TILE;
+    kt = g / NB_HT2; ht = g % NB_HT2; t.as = A1; t.lda = LD1; t.bs = D2;
+    t.ldb = LD2;
+    t.woff = (long long)(n_gt1 + kt * NB_HT2 + ht) * NB_TILE;
   } else if (gt < n_gt1 + n_gt2 + n_gt3) {
     const int g = gt - n_gt1 - n_gt2;
-    kt = g / NB_HT3; ht = g % NB_HT3; As = A2; lda = LD2; Bs = D3; ldb = LD3;
-    woff = (long long)(n_gt1 + n_gt2 + kt * NB_HT3 + ht) * NB_TILE;
+    kt = g / NB_HT3; ht = g % NB_HT3; t.as = A2; t.lda = LD2; t.bs = D3;
+    t.ldb = LD3;
+    t.woff = (long long)(n_gt1 + n_gt2 + kt * NB_HT3 + ht) * NB_TILE;
   } else {
     const int g = gt - n_gt1 - n_gt2 - n_gt3;
-    kt = g; ht = 0; As = A3; lda = LD3; Bs = D4; ldb = LD4;
-    woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
+    kt = g; ht = 0; t.as = A3; t.lda = LD3; t.bs = D4; t.ldb = LD4;
+    t.woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
   }
+  t.as += 16 * kt;
+  t.bs += 16 * ht;
+  return t;
+}
+
+// operands of quarter `wave` of a tile: rows 16 rt + 4 wave + lg
+__device__ __forceinline__ void g_load(const GTile& t, int n_rt, int wave,
+                                       int lane, double* av, double* bv) {
+  const int li = lane & 15, lg = lane >> 4;
+  const int oa = (4 * wave + lg) * t.lda + li;
+  const int ob = (4 * wave + lg) * t.ldb + li;
+#pragma unroll
+  for (int rt = 0; rt < G_ROWT; ++rt) {
+    const bool on = rt < n_rt;
+    av[rt] = on ? t.as[oa + rt * 16 * t.lda] : 0.0;
+    bv[rt] = on ? t.bs[ob + rt * 16 * t.ldb] : 0.0;
+  }
+}
+
 #ifdef NB_TRAIN_TIMING
-  long long g_prev = (long long)__builtin_amdgcn_s_memtime();
 #define G_STAMP(i)                                                            \
   do {                                                                        \
-    if (!STANDALONE && gt == 0 && lane == 0) {                                \
+    if (MAXT > 1 && first == 0 && threadIdx.x == 0) {                         \
       const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
       g_train_ticks[i] += t_now - g_prev;                                     \
       g_prev = t_now;                                                         \
@@ -581,56 +634,93 @@ __device__ __forceinline__ void g_body(const TrainArgs& a, const NetState& st,
 #else
 #define G_STAMP(i)
 #endif
-  // dW tile = act^T delta over the rows of the minibatch (fixed order).  All
-  // operand loads are issued before the first MFMA (one memory latency per
-  // tile instead of one per k-step).
-  const double* ap = As + (long long)lg * lda + 16 * kt + li;
-  const double* bp = Bs + (long long)lg * ldb + 16 * ht + li;
-  const int n_steps = n_tiles * 4;
-  constexpr int MAXS = MAXB / 4;
-  double av[MAXS], bv[MAXS];
+
+// Tiles first, first + stride, ... (< n_gt, at most MAXT of them) of one
+// network, by a workgroup of four wavefronts.  Wavefront q contracts the rows
+// 16 rt + 4 q + lg of the minibatch (k-step q of every 16-row tile, in the
+// order of rt), so a tile is four independent chains of at most 13 MFMAs on
+// four SIMDs; all operand loads of a tile are issued before the chain of the
+// previous one.  The partial tiles go through LDS; wavefront r then owns rows
+// lg + 4 r of every tile: gradient = ((p0 + p1) + p2) + p3, Adam (sklearn
+// _stochastic_optimizers.py:255-287) in place.
+template <int MAXT>
+__device__ __forceinline__ void g_phase(const TrainArgs& a, const NetState& st,
+                                        int first, int stride, int nb,
+                                        double lr_t, double* red) {
+  int lane = threadIdx.x & 63;
+  // (opaque to the optimiser: per-lane addresses derived from it are
+  // recomputed every step instead of being kept -- and spilled -- across the
+  // forward / backward pass)
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int n_gt = nb_net_tiles(a.kt1);
+  const int n_rt = (nb + 15) >> 4;
+#ifdef NB_TRAIN_TIMING
+  long long g_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  GTile tl[MAXT];
+  double av[2][G_ROWT], bv[2][G_ROWT];
+  double w_old[MAXT], m_old[MAXT], v_old[MAXT];
 #pragma unroll
-  for (int s = 0; s < MAXS; ++s) {
-    const bool on = s < n_steps;
-    av[s] = on ? ap[(long long)s * 4 * lda] : 0.0;
-    bv[s] = on ? bp[(long long)s * 4 * ldb] : 0.0;
+  for (int i = 0; i < MAXT; ++i) {
+    const int gt = first + i * stride;
+    if (gt < n_gt) tl[i] = g_decode(a, st, gt);
   }
-  // ... including the tile's weights and Adam moments
-  double w_old[4], m_old[4], v_old[4];
+  if (first < n_gt) g_load(tl[0], n_rt, wave, lane, av[0], bv[0]);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long idx = woff + (lg + 4 * r) * 16 + li;
-    w_old[r] = st.W[idx]; m_old[r] = st.M[idx]; v_old[r] = st.V[idx];
+  for (int i = 0; i < MAXT; ++i) {
+    if (first + i * stride < n_gt) {
+      const long long idx = tl[i].woff + (lg + 4 * wave) * 16 + li;
+      w_old[i] = st.W[idx]; m_old[i] = st.M[idx]; v_old[i] = st.V[idx];
+    }
   }
   G_STAMP(30);
-  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
-  for (int s = 0; s < MAXS; s += 2) {
-    acc0 = MFMA(av[s], bv[s], acc0);
-    acc1 = MFMA(av[s + 1], bv[s + 1], acc1);
+  for (int i = 0; i < MAXT; ++i) {
+    if (first + i * stride < n_gt) {
+      if (i + 1 < MAXT) {
+        if (first + (i + 1) * stride < n_gt)
+          g_load(tl[i + 1], n_rt, wave, lane, av[(i + 1) & 1], bv[(i + 1) & 1]);
+      }
+      nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int rt = 0; rt < G_ROWT; ++rt)
+        acc = MFMA(av[i & 1][rt], bv[i & 1][rt], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[((i * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
+    }
   }
   G_STAMP(31);
-
-  // Adam (sklearn _stochastic_optimizers.py:255-287), in place
+  lds_barrier();
   const double inv_nb = 1.0 / (double)nb;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long idx = woff + (lg + 4 * r) * 16 + li;
-    const double g = (acc0[r] + acc1[r]) * inv_nb;
-    const double m = a.b1 * m_old[r] + (1.0 - a.b1) * g;
-    const double v = a.b2 * v_old[r] + (1.0 - a.b2) * (g * g);
-    st.M[idx] = m;
-    st.V[idx] = v;
-    st.W[idx] = w_old[r] + -lr_t * m / (sqrt(v) + a.eps);
+  for (int i = 0; i < MAXT; ++i) {
+    if (first + i * stride < n_gt) {
+      const double* p = red + (i * 16 + wave) * 64 + lane;
+      const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
+      const long long idx = tl[i].woff + (lg + 4 * wave) * 16 + li;
+      const double g = sum * inv_nb;
+      const double m = a.b1 * m_old[i] + (1.0 - a.b1) * g;
+      const double v = a.b2 * v_old[i] + (1.0 - a.b2) * (g * g);
+      st.M[idx] = m;
+      st.V[idx] = v;
+      st.W[idx] = w_old[i] + -lr_t * m / (sqrt(v) + a.eps);
+    }
   }
+  G_STAMP(32);
 }
 
-
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
+  __shared__ __attribute__((aligned(16))) double red[1024];
   const NetState st = a.nets[blockIdx.y];
-  g_body<true>(a, st, (int)blockIdx.x, (int)threadIdx.x, nb,
-               adam_lr(a, t_adam));
+  if (st.scal[4] != 0.0) return;                 // network already stopped
+  // the first workgroup also folds the step's loss (the resident kernel gives
+  // that to its least loaded workgroup)
+  if (blockIdx.x == 0 && threadIdx.x < 64) loss_fold(st, nb, (int)threadIdx.x);
+  g_phase<1>(a, st, (int)blockIdx.x, 1 << 30, nb, adam_lr(a, t_adam), red);
 }
 
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
@@ -675,7 +765,7 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 // write-back, and the barrier is one atomic in that L2.
 // ---------------------------------------------------------------------------
 constexpr int XCD_COUNT = 8;
-constexpr int XCD_SLOTS = 17;            // workgroups per network
+constexpr int XCD_SLOTS = 32;            // workgroups per network: one per CU
 constexpr int SYNC_WORDS = 4;            // counter, error, (unused), ticket
 constexpr int SYNC_LIMIT = 1 << 23;
 
@@ -742,8 +832,12 @@ __global__ void nb_xcc_probe_kernel(int* out) {
 #define TR_STAMP(i)
 #endif
 
+// (two workgroups per CU: the register budget of 256 leaves every CU of an
+// owned XCD a free slot, through which the workgroups of OTHER grids -- a
+// concurrent trainer's, which leave at once here, or any other kernel's --
+// pass while this one is resident)
 template <int DT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
   // own disjoint XCDs; map.net[x] = network of XCD x or -1
@@ -756,6 +850,10 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   // end up with 34 resident workgroups on the 32 CUs of one XCD and wait for
   // each other forever.)
   __shared__ int sh_slot;
+  __shared__ __attribute__((aligned(16))) double lds[FbLds<DT>::TOTAL];
+  static_assert(FbLds<DT>::TOTAL - FbLds<DT>::G_RED >= GTiles<DT>::N * 1024,
+                "the partial tiles of G fit behind the input block");
+  static_assert(XCD_SLOTS == 32, "GTiles assumes 32 workgroups");
   const int n_nets = map.n_nets;
   unsigned xcc_id;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
@@ -766,7 +864,7 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   int* ticket = counter + 3;
   if (threadIdx.x == 0) sh_slot = atomicAdd(ticket, 1);
   __syncthreads();
-  const int slot = sh_slot;
+  const int slot = __builtin_amdgcn_readfirstlane(sh_slot);
   if (slot >= XCD_SLOTS) return;
   const NetState st = a.nets[net];
   int phase = 0;
@@ -774,7 +872,6 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long n = a.n;
   const int steps = (int)((n + a.batch - 1) / a.batch);
-  const int n_gt = nb_net_tiles(a.kt1);
   xcd_barrier(counter, err, phase, XCD_SLOTS);
   long long t_adam = t_adam0;
   FbRows<DT> rows;
@@ -795,7 +892,8 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       TR_STAMP(0);
       if (slot * 16 < nb) {
         if (!have_rows) fb_gather<DT>(a, net, slot, ep, start, nb, rows);
-        fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows, zero_input);
+        fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows, zero_input,
+                           lds);
         zero_input = false;
       }
       TR_STAMP(1);
@@ -804,14 +902,13 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       const double lr_t = adam_lr(a, t_adam);
       xcd_wait(counter, err, phase, XCD_SLOTS);
       TR_STAMP(2);
-      // weight tiles 0 .. n_gt - 1, task n_gt = the loss fold.  (Measured and
-      // rejected: groups of four tiles sharing one operand block staged in
-      // LDS -- 37 % fewer bytes per CU, but the extra barrier and the
-      // LDS round trip cost 4 us per step.)
-      for (int gt = slot * 4 + wave; gt <= n_gt; gt += XCD_SLOTS * 4) {
-        if (gt < n_gt) g_body<false>(a, st, gt, lane, nb, lr_t);
-        else if (lane == 0) loss_fold(st, nb);
-      }
+      // weight tiles slot, slot + 32, ... on the four wavefronts of this
+      // workgroup (all 32 CUs of the XCD take part, also the ones without a
+      // row tile in FB); the last workgroup has the fewest tiles and folds
+      // the loss
+      if (slot == XCD_SLOTS - 1 && wave == 3) loss_fold(st, nb, lane);
+      g_phase<GTiles<DT>::N>(a, st, slot, XCD_SLOTS, nb, lr_t,
+                      lds + FbLds<DT>::G_RED);
       TR_STAMP(3);
       xcd_arrive(counter);
       {
@@ -1044,7 +1141,7 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
     for (int sidx = 0; sidx < steps_per_epoch; ++sidx) {
       const long long start = (long long)sidx * a.batch;
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
-      const dim3 gfb((nb + 15) / 16, t->E), gg(n_gt, t->E), blk(64), blk_fb(256);
+      const dim3 gfb((nb + 15) / 16, t->E), gg(n_gt, t->E), blk(256), blk_fb(256);
       t->t_adam += 1;
       switch (t->dt) {
         case 1: hipLaunchKernelGGL(nb_train_fb_kernel<1>, gfb, blk_fb, 0, s, a, ep, start, nb); break;

@@ -433,13 +433,18 @@ def gmm_fit(x, n_init=10, seed=0, tol=1e-3, reg_covar=1e-6, max_iter=100,
         float(reg_covar), int(max_iter), _ptr(lab) if lab is not None else None,
         _ptr(out), _ptr(scratch), _stream()))
     rec = out.cpu().numpy().reshape(n_init, stride)
+    per = scratch.numel() // n_init
+    off = lib.nb_gmm_logp_offset(d)
     fits = []
-    for r in rec:
+    for i, r in enumerate(rec):
         fits.append(dict(
             lower_bound=float(r[0]), n_iter=int(r[1]), converged=bool(r[2]),
             failed=bool(r[3]), weights=r[4:6].copy(),
             means=r[6:6 + 2 * d].reshape(2, d).copy(),
-            covariances=r[6 + 2 * d:].reshape(2, d, d).copy()))
+            covariances=r[6 + 2 * d:].reshape(2, d, d).copy(),
+            # (2, n) on the device: log(w_k N(x_i; mu_k, Sigma_k)) under the
+            # returned parameters
+            logp=scratch[i * per + off:i * per + off + 2 * n].view(2, n)))
     return fits
 
 
@@ -583,6 +588,13 @@ class LivePool:
             if self._host[3] != 0:
                 raise OverflowError('live pool capacity exceeded')
         return float(self._host[0]), int(self._host[1]), int(self._host[2])
+
+    def smallest_above(self):
+        """Smallest pooled value strictly above the threshold (the likelihood
+        plateau rule of add_bound, sampler.py:1012-1020); call after
+        ``select``."""
+        vals = self.bufs[self.cur][:int(self.counts[self.cur])]
+        return float(vals[vals > self.thr].min())
 
     def shell_stats(self, shells):
         """Rows (#above, logsumexp above, #equal) for the log-L tensors of

@@ -197,8 +197,13 @@ class NeuralNetworkEmulator:
                              hparams=hp))
         results = (train_ensembles(jobs) if comm is None or comm.world == 1
                    else train_ensembles_sharded(jobs, comm))
+        user = {k: v for k, v in dict(neural_network_kwargs).items()
+                if k != 'random_state'}
         for emu, (nets, stats) in zip(emus, results):
             emu.neural_networks, emu.trainer_stats = nets, stats
+            for net in nets:
+                net.sk_params = dict(user)       # checkpoint attributes
+                net.t_ = int(net.n_iter_) * int(stats['n_rows'])
         return emus
 
     @classmethod
@@ -307,6 +312,8 @@ class _TrainJob:
                 coefs, intercepts = self.trainer.weights(i)
                 networks.append(Network(coefs, intercepts, n_iter,
                                         self.trainer.loss_curve(i, n_iter)))
+                # scikit-learn's sample counter (_multilayer_perceptron.py:728)
+                networks[-1].t_ = n_iter * self.n
         stats = dict(n_iter=[abs(int(s)) for s in self.status], n_rows=self.n)
         return networks, stats
 

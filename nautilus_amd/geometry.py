@@ -275,11 +275,12 @@ class _Mixture:
     """The three attributes of a fitted sklearn GaussianMixture that
     Union.split reads (union.py:188-190)."""
 
-    def __init__(self, weights, means, covariances, lower_bound):
+    def __init__(self, weights, means, covariances, lower_bound, logp=None):
         self.weights_ = weights
         self.means_ = means
         self.covariances_ = covariances
         self.lower_bound_ = lower_bound
+        self.logp = logp          # (2, n) cuda tensor from the device fit
 
 
 def _best_of_inits_host(points_t, random_state):
@@ -305,20 +306,25 @@ def _best_of_inits(points_t, random_state):
         return _best_of_inits_host(points_t, random_state)
     best = max(fits, key=lambda f: f['lower_bound'])
     return _Mixture(best['weights'], best['means'], best['covariances'],
-                    best['lower_bound'])
+                    best['lower_bound'], best['logp'])
 
 
 def two_component_labels(points_t, n_points_min, random_state):
     """Hard assignment of points to the two components of a full-covariance
     Gaussian mixture, re-balanced so that both clusters keep at least
-    ``n_points_min`` members (bounds/union.py:185-197).  The EM fit itself is
-    scikit-learn's ``GaussianMixture`` -- the reference's own dependency for
-    this step."""
-    from scipy.stats import multivariate_normal
+    ``n_points_min`` members (bounds/union.py:185-197).  The EM fit
+    (scikit-learn's ``GaussianMixture`` restated) leaves the
+    weighted log probabilities of its final parameters on the device; only
+    2 n doubles come back."""
     gmm = _best_of_inits(points_t, random_state)
-    logp = np.vstack([multivariate_normal.logpdf(
-        points_t, mean=gmm.means_[i], cov=gmm.covariances_[i]) +
-        np.log(gmm.weights_[i]) for i in range(2)]).T
+    logp_dev = getattr(gmm, 'logp', None)
+    if logp_dev is not None:
+        logp = logp_dev.t().cpu().numpy()
+    else:                 # the scikit-learn fallback of _best_of_inits_host
+        from scipy.stats import multivariate_normal
+        logp = np.vstack([multivariate_normal.logpdf(
+            points_t, mean=gmm.means_[i], cov=gmm.covariances_[i]) +
+            np.log(gmm.weights_[i]) for i in range(2)]).T
     labels = np.argmax(logp, axis=1)
     if not np.all(np.bincount(labels, minlength=2) >= n_points_min):
         small = np.argmin(np.bincount(labels, minlength=2))

@@ -276,16 +276,54 @@ def read_bound(cls, group, rng=None):
 # emulator (neural.py:118-187)
 # ---------------------------------------------------------------------------
 
+# what MLPRegressor.__dict__ holds after the reference's fit (neural.py:79-88
+# defaults; scikit-learn 1.7) and neural.py:128-137 therefore writes as
+# attributes: constructor parameters first, fitted state after them
+_SK_PARAMS = dict(
+    activation='relu', solver='adam', alpha=0, batch_size='auto',
+    learning_rate='constant', learning_rate_init=1e-2, power_t=0.5,
+    max_iter=10000, loss='squared_error', hidden_layer_sizes=(100, 50, 20),
+    shuffle=True, random_state=None, tol=0, verbose=False, warm_start=False,
+    momentum=0.9, nesterovs_momentum=True, early_stopping=False,
+    validation_fraction=0.1, beta_1=0.9, beta_2=0.999, epsilon=1e-8,
+    n_iter_no_change=10, max_fun=15000)
+_SK_KWARGS = dict(learning_rate_init='learning_rate_init', beta_1='beta_1',
+                  beta_2='beta_2', epsilon='epsilon', batch_size='batch_size',
+                  max_iter='max_iter', n_iter_no_change='n_iter_no_change',
+                  tol='tol')
+
+
+def _network_attrs(net, index):
+    """Attribute dict of network ``index`` as the reference writes it."""
+    attrs = dict(_SK_PARAMS)
+    attrs['random_state'] = index                    # neural.py:31
+    attrs.update(getattr(net, 'sk_params', {}))
+    curve = np.asarray(net.loss_curve_, dtype=float)
+    attrs.update(
+        n_features_in_=int(np.shape(net.coefs_[0])[0]), n_outputs_=1,
+        n_iter_=int(net.n_iter_),
+        t_=int(getattr(net, 't_', 0)), n_layers_=int(net.n_layers_),
+        out_activation_='identity', loss_curve_=curve,
+        _no_improvement_count=int(getattr(
+            net, '_no_improvement_count',
+            len(curve) - 1 - int(np.argmin(curve)) if len(curve) else 0)),
+        best_loss_=float(np.min(curve)) if len(curve) else np.inf,
+        loss_=float(curve[-1]) if len(curve) else np.inf)
+    attrs.update(getattr(net, 'sk_state', {}))
+    return attrs
+
+
 def write_emulator(emu, group):
     group.attrs['n_networks'] = len(emu.neural_networks)
     for i, net in enumerate(emu.neural_networks):
-        # the scalar attributes scikit-learn's predict() needs, so that the
-        # reference can load the file into MLPRegressor objects
-        scalars = dict(n_layers_=net.n_layers_, n_iter_=net.n_iter_,
-                       n_outputs_=1, out_activation_='identity',
-                       n_features_in_=int(np.shape(net.coefs_[0])[0]))
-        for key, val in scalars.items():
-            group.attrs['{}_{}'.format(key, i)] = val
+        # everything the reference's loop over MLPRegressor.__dict__ writes
+        # (what has no HDF5 equivalent is skipped there as well), so that the
+        # reference loads the file into MLPRegressor objects
+        for key, val in _network_attrs(net, i).items():
+            try:
+                group.attrs['{}_{}'.format(key, i)] = val
+            except (TypeError, ValueError):
+                pass
         for k in range(net.n_layers_ - 1):
             group.create_dataset('coefs_{}_{}'.format(k, i),
                                  data=net.coefs_[k])
@@ -303,10 +341,20 @@ def read_emulator(group):
                  for k in range(n_layers - 1)]
         icpts = [np.array(group['intercepts_{}_{}'.format(k, i)])
                  for k in range(n_layers - 1)]
-        key = 'n_iter__{}'.format(i)
-        nets.append(Network(coefs, icpts,
-                            int(group.attrs[key]) if key in group.attrs
-                            else 0))
+        # the remaining attributes of network i (neural.py:176-178) travel
+        # along unchanged, so that a later write() reproduces the file
+        stored = {}
+        for key in group.attrs.keys():
+            name, _, idx = key.rpartition('_')
+            if idx == str(i) and name:
+                stored[name] = group.attrs[key]
+        net = Network(coefs, icpts, int(stored.get('n_iter_', 0)),
+                      stored.get('loss_curve_'))
+        net.sk_params = {k: stored[k] for k in _SK_PARAMS if k in stored}
+        net.sk_state = {k: stored[k] for k in
+                        ('t_', '_no_improvement_count', 'best_loss_', 'loss_')
+                        if k in stored}
+        nets.append(net)
     return NeuralNetworkEmulator.from_weights(
         np.array(group['mean']), np.array(group['scale']), nets)
 

@@ -288,19 +288,23 @@ class Sampler:
                 else -np.inf for ll in self._ll_dev])
         return pool
 
+    def _live_threshold(self):
+        """(n_live-th largest stored log L, #above, #equal) from the pool."""
+        pool = self._live_pool()
+        try:
+            return pool.select()
+        except OverflowError:               # many batches without a selection
+            self._live = None
+            return self._live_pool().select()
+
     def _live_sums(self):
         """(log sum of the weights of the n_live points of largest log L,
         log sum of their volumes): sampler.py:1162-1169 and 1186-1190 with the
         selection and the per-shell sums on the device.  Ties at the
         threshold (likelihood plateaus) share the remaining places equally --
         the reference takes an arbitrary subset of them."""
-        pool = self._live_pool()
-        try:
-            thr, n_gt, n_eq = pool.select()
-        except OverflowError:               # many batches without a selection
-            self._live = None
-            pool = self._live_pool()
-            thr, n_gt, n_eq = pool.select()
+        thr, n_gt, n_eq = self._live_threshold()
+        pool = self._live
         shells = [s for s in range(len(self._ll_dev))
                   if self._ll_dev[s].n > 0 and self._shell_max[s] >= thr]
         rows = pool.shell_stats([self._ll_dev[s].view() for s in shells])
@@ -820,19 +824,25 @@ class Sampler:
         else:
             if verbose:
                 self.print_status('Bounding', end='\r')
-            log_l = np.concatenate(self.log_l)
-            order = np.argsort(log_l)
-            log_l = log_l[order]
-            log_l_min = log_l[-self.n_live]
+            # sampler.py:1004-1020 without sorting anything: the n_live-th
+            # largest log L and the counts above / at it come from the live
+            # pool's radix selection on the device
+            thr, n_gt, n_eq = self._live_threshold()
+            n_total = int(np.sum(self.shell_n))
+            log_l_min = thr
             # likelihood plateaus, sampler.py:1012-1020
-            if (np.sum(log_l == log_l_min) > 1 and
-                    np.sum(log_l > log_l_min) >= self.n_points_min):
-                log_l_min = np.amin(log_l[log_l > log_l_min])
-            if np.all(log_l >= log_l_min):
+            if n_eq > 1 and n_gt >= self.n_points_min:
+                log_l_min = self._live.smallest_above()
+                n_at_or_above = n_gt
+            else:
+                n_at_or_above = n_gt + n_eq
+            if n_at_or_above == n_total:
                 ok = False
             else:
-                pts = torch.cat([p.view() for p in self._pts])[
-                    torch.from_numpy(order).cuda()]
+                # (the reference hands the points over sorted by log L; no
+                # step of the construction depends on their order)
+                log_l = np.concatenate(self.log_l)
+                pts = torch.cat([p.view() for p in self._pts])
                 # host BLAS pinned to one thread as in the reference
                 # (sampler.py:1022): the construction works on tiny matrices
                 with geometry.single_threaded_blas():

@@ -547,6 +547,15 @@ def test_gmm_full_fit(dev):
     best = max(fits, key=lambda f: f['lower_bound'])
     ref = GaussianMixture(n_components=2, n_init=10, random_state=0).fit(x)
     assert abs(best['lower_bound'] - ref.lower_bound_) < 2e-3
+    # the log probabilities the fit leaves on the device (what Union.split's
+    # hard assignment uses, union.py:188-190) against scipy's logpdf with the
+    # returned parameters
+    from scipy.stats import multivariate_normal
+    want = np.vstack([multivariate_normal.logpdf(
+        x, mean=best['means'][k], cov=best['covariances'][k]) +
+        np.log(best['weights'][k]) for k in range(2)])
+    got = best['logp'].cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-8)
     lab = geometry.two_component_labels(x, d + 1, 42)
     agree = max(np.mean(lab == truth), np.mean(lab != truth))
     assert agree == 1.0

@@ -136,3 +136,101 @@ def test_sampler_resume_is_exact(tmp_path, blobs, n_like_max, discard,
         a.write(str(tmp_path / 'run.txt'))
     with pytest.raises(RuntimeError):
         a.write(path)
+
+
+# ---------------------------------------------------------------------------
+# the layout against the reference's own writers (tests/golden/h5_layout.json
+# and ref_checkpoint_*.pkl, written by the REFERENCE through the same shim:
+# tests/golden/make_golden_h5.py)
+# ---------------------------------------------------------------------------
+
+def _ring(x):
+    d = (x[0] - 0.97 + 0.5) % 1.0 - 0.5
+    ll = -0.5 * (d / 0.05)**2 - 0.5 * np.sum(((x[1:] - 0.5) / 0.1)**2)
+    return ll, x[0] + x[1], int(1000 * x[2])
+
+
+def _bowl(x):
+    return -0.5 * np.sum(((x - 0.5) / 0.15)**2)
+
+
+_LAYOUT_CASES = {
+    'periodic_blobs': (_ring, dict(n_dim=3, n_live=200, n_networks=1,
+                                   periodic=np.arange(1), n_batch=50)),
+    'plain': (_bowl, dict(n_dim=2, n_live=150, n_networks=0, n_batch=50))}
+
+
+def _layout():
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, 'h5_layout.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('name', ['periodic_blobs', 'plain'])
+def test_written_tree_equals_the_reference_layout(tmp_path, name):
+    """Every group, dataset and attribute the reference's ``Sampler.write`` /
+    ``write_shell_update`` / bound ``write`` + ``update`` / emulator ``write``
+    emit for this problem exists here with the same kind, rank and
+    ``maxshape`` -- and nothing else except the documented ``amd_*``
+    entries (sampler.py:1253-1377, bounds/*.py, neural.py:118-146)."""
+    from nautilus_amd import Sampler
+    like, kw = _LAYOUT_CASES[name]
+    path = str(tmp_path / 'run.hdf5')
+    s = Sampler(lambda u: u, like, filepath=path, seed=3, **kw)
+    s.run(n_eff=400, f_live=0.05, discard_exploration=False)
+    with fake_h5py.File(path, 'r') as f:
+        ours = fake_h5py.tree_schema(f)
+    ref = _layout()['layout'][name]
+    extra = sorted(k for k in ours if k not in ref)
+    assert all('amd_' in k for k in extra), extra
+    assert sorted(k for k in ref if k not in ours) == []
+    for key, want in ref.items():
+        assert ours[key] == want, (key, ours[key], want)
+
+
+@pytest.mark.parametrize('name', ['periodic_blobs', 'plain'])
+def test_resume_from_a_file_written_by_the_reference(tmp_path, name):
+    """``io.read_sampler`` / ``read_bound`` / ``read_emulator`` on the
+    reference's own checkpoint of a finished run (periodic parameter, two
+    blobs, one network; and a plain one): the restored sampler reports the
+    reference's evidence, counts and posterior, its bounds the reference's
+    volumes and queues, and it keeps running and updating the file."""
+    import os
+    import shutil
+    from conftest import GOLDEN
+    from nautilus_amd import Sampler
+    like, kw = _LAYOUT_CASES[name]
+    ref = _layout()['reference'][name]
+    path = str(tmp_path / 'ref.hdf5')
+    shutil.copy(os.path.join(GOLDEN, 'ref_checkpoint_%s.pkl' % name), path)
+    s = Sampler(lambda u: u, like, filepath=path, resume=True, **kw)
+    assert s.explored == ref['explored'] and s.n_like == ref['n_like']
+    assert len(s.bounds) == ref['n_bounds']
+    assert np.array_equal(s.shell_n, ref['shell_n'])
+    assert np.array_equal(s.shell_n_sample, ref['shell_n_sample'])
+    assert abs(s.log_z - ref['log_z']) < 1e-12
+    assert abs(s.n_eff - ref['n_eff']) < 1e-9 * ref['n_eff']
+    assert (s.blobs is not None) == ref['blobs']
+    for b, log_v, n_queue in zip(s.bounds, ref['bound_log_v'],
+                                 ref['bound_queue']):
+        assert abs(b.log_v - log_v) < 1e-12
+        if hasattr(b, 'points'):
+            assert len(b.points) == n_queue
+    out = s.posterior(return_blobs=ref['blobs'])
+    pts, log_w = out[0], out[1]
+    assert len(pts) == ref['n_points']
+    mean = np.average(pts, weights=np.exp(log_w), axis=0)
+    assert np.allclose(mean, ref['posterior_mean'], rtol=0, atol=1e-12)
+    # every restored bound answers like its stored points say: what the
+    # reference kept in a shell lies inside that shell's bound
+    for b, p in zip(s.bounds[1:], s.points[1:]):
+        if len(p):
+            assert np.all(b.contains(p))
+    # ... and the run continues from there, updating the reference's file
+    assert s.run(n_eff=2 * ref['n_eff'], f_live=0.05)
+    assert s.n_eff >= 2 * ref['n_eff']
+    assert abs(s.log_z - ref['log_z']) < 0.25
+    with fake_h5py.File(path, 'r') as f:
+        assert int(f['sampler'].attrs['n_like']) == s.n_like
