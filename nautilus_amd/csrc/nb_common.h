@@ -19,6 +19,22 @@
 
 typedef double nb_d4 __attribute__((ext_vector_type(4)));
 
+// Pointers to global memory, typed as such for device code.  A pointer the
+// compiler cannot trace back to a kernel argument -- loaded from a descriptor
+// in memory, or laundered through an empty asm -- is a generic ("flat")
+// pointer to it: every access becomes flat_load / flat_store, which count
+// against the LDS counter as well (each wait for an LDS read then also waits
+// for every global load in flight) and cannot use scalar-base addressing.
+// (Casting back and forth does not help: the optimiser folds the round trip;
+// the pointer has to keep the address space in its type.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NB_G __attribute__((address_space(1)))
+#else
+#define NB_G
+#endif
+typedef NB_G double nb_gd;
+typedef NB_G int nb_gi;
+
 // ---------------------------------------------------------------------------
 // Device "bound blob": one contiguous array of doubles per bound, built on the
 // host by nb_api.cpp (BlobBuilder) and uploaded once.  The first NB_HDR

@@ -43,7 +43,7 @@ namespace {
 struct FastArgs {
   const double* blob;
   int sample;                     // 1: flags of nb_accept, 0: (r2, score)
-  const double* x;
+  const nb_gd* x;
   long long n;
   unsigned char* out_u8;
   double* out_f64;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void ell_eval_centre(
 // so that nothing waits for the loads where they are issued.
 template <int DT, int T>
 __device__ __forceinline__ void load_points_raw(
-    const double* __restrict__ x, const long long (&pt)[T],
+    const nb_gd* __restrict__ x, const long long (&pt)[T],
     const bool (&valid)[T], int n_dim, long long n, int lane,
     double2 (&raw)[T][2 * DT]) {
   const int lg = lane >> 4;
@@ -121,17 +121,17 @@ __device__ __forceinline__ void load_points_raw(
   if ((n_dim & 1) == 0) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const double* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+      const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
-        raw[t][j] = *(const double2*)(row + (f < n_dim ? f : n_dim - 2));
+        raw[t][j] = *(const NB_G double2*)(row + (f < n_dim ? f : n_dim - 2));
       }
     }
   } else {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const double* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+      const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
@@ -495,7 +495,7 @@ int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample,
                         unsigned long long offset, hipStream_t stream) {
   if (n <= 0) return NB_OK;
   FastArgs a;
-  a.blob = blob_dev; a.sample = sample ? 1 : 0; a.x = x; a.n = n;
+  a.blob = blob_dev; a.sample = sample ? 1 : 0; a.x = (const nb_gd*)x; a.n = n;
   a.out_u8 = out_u8; a.out_f64 = out_f64; a.seed = seed; a.offset = offset;
   a.counters = nb_eval_counters();
   const int dt = (n_dim + 15) / 16, kt1 = (n_dim + 1 + 15) / 16;

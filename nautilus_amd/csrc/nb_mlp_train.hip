@@ -37,83 +37,48 @@ namespace {
 
 constexpr int MAXB = 208;        // minibatch rows padded to 16 (batch <= 200)
 constexpr int LD1 = 112, LD2 = 64, LD3 = 32, LD4 = 16;
-constexpr int NWAVE = 8;
+constexpr int G_ROWT = MAXB / 16;   // 16-row tiles of a minibatch
+// transposed copies of the weight tiles of layers 2-4 (operands of the
+// backward products): [ht][kt] tiles, element (hh, kk) = W[16 kt + kk][16 ht + hh]
+constexpr int WT2 = 0;
+constexpr int WT3 = WT2 + NB_HT2 * NB_HT1 * NB_TILE;
+constexpr int WT4 = WT3 + NB_HT3 * NB_HT2 * NB_TILE;
+constexpr int WT_DOUBLES = WT4 + 1 * NB_HT3 * NB_TILE;
+
+// Data written by one CU of an XCD and read by another in the same step
+// (weights, stash, loss partials, flags) is read with device-scope loads
+// (sc1): they never hit the reading CU's L1 and are served by the XCD's L2,
+// where the writer's write-through stores are.  (The alternative, dropping
+// the L1 behind every barrier with buffer_inv sc1, also invalidates the L2's
+// clean lines on this part -- measured: 4.6 us per step.)
+__device__ __forceinline__ double ld_xcd(const nb_gd* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct NetState {
-  double* W; double* M; double* V;   // tile-major weights and Adam moments
-  double* stash;                     // A0 A1 A2 A3 D1 D2 D3 D4
-  double* loss_curve;
-  double* scal;   // [0] adam t  [1] best loss  [2] stale  [3] n_iter  [4] done
+  nb_gd* W; nb_gd* M; nb_gd* V;      // tile-major weights and Adam moments
+  nb_gd* WT;                         // transposed tiles of layers 2-4
+  nb_gd* stash;                      // A0 A1 A2 A3 D1 D2 D3 D4
+  nb_gd* loss_curve;
+  nb_gd* scal;    // [0] adam t  [1] best loss  [2] stale  [3] n_iter  [4] done
 };
 
 struct TrainArgs {
   const NetState* nets;
-  const double* X;       // (n, D) standardised inputs
-  const double* y;       // (n)
-  const int* perm;       // (E, n_epochs, n)
+  const nb_gd* X;       // (n, D) standardised inputs
+  const nb_gd* y;       // (n)
+  const nb_gi* perm;    // (E, n_epochs, n)
+  const nb_gi* jobs;    // G phase: n_jobs records of G_JOB_INTS ints
+  int n_jobs;
   long long n;
   int n_dim, kt1, n_epochs, max_iter, n_iter_no_change, batch;
   double tol, lr, b1, b2, eps;
 };
 
-// out[h] = sum_k in[k] W[k][h] for one layer, tiles [kt][HT]
-template <int KSMAX, int HT>
-__device__ __forceinline__ void fwd_layer(const double* __restrict__ w,
-                                          int ks_n, const double* in, int lane,
-                                          double* out, bool relu) {
-#pragma unroll
-  for (int ht = 0; ht < HT; ++ht) {
-    nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < KSMAX; ++ks) {
-      if (ks < ks_n) {
-        const double a = w[((ks >> 2) * HT + ht) * NB_TILE + (ks & 3) * 64 + lane];
-        acc = MFMA(a, in[ks], acc);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      out[4 * ht + r] = relu ? fmax(acc[r], 0.0) : acc[r];
-  }
-}
-
-// din[k] = sum_h dout[h] W[k][h]  (k over KT tiles, h over HS k-steps of 4)
-template <int KT, int HT, int HS>
-__device__ __forceinline__ void bwd_layer(const double* __restrict__ w,
-                                          const double* dout, int lane,
-                                          double* din) {
-  const int li = lane & 15, lg = lane >> 4;
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int hs = 0; hs < HS; ++hs) {
-      const int h0 = 4 * hs;
-      const double a = w[(kt * HT + (h0 >> 4)) * NB_TILE + li * 16 +
-                         (h0 & 15) + lg];
-      acc = MFMA(a, dout[hs], acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) din[4 * kt + r] = acc[r];
-  }
-}
-
-// write a register block (unit = 4*j + lg of point li) to stash[pt][ld]
-template <int NREG>
-__device__ __forceinline__ void put_stash(double* __restrict__ base, int ld,
-                                          int pt, int lane, const double* v) {
-  const int lg = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < NREG; ++j) base[(long long)pt * ld + 4 * j + lg] = v[j];
-}
-
 // ---------------------------------------------------------------------------
-// Step = two launches (kernel boundaries give grid-wide ordering and
-// visibility for ~1.5 us each on MI355X, far cheaper than an in-kernel grid
-// barrier across XCDs):
-//   nb_train_fb_kernel  grid (row tiles of the minibatch, networks), 1 wave
-//   nb_train_g_kernel   grid (weight tiles, networks), 1 wave
-// and one nb_train_epoch_kernel per epoch for the stopping rule.
+// Step = FB then G (the two-launch form runs them as two kernels, the kernel
+// boundary being the grid-wide synchronisation; the resident form separates
+// them by barriers in the L2 of one XCD).
 // ---------------------------------------------------------------------------
 // ---- FB: forward + backward deltas of one 16-row tile ---------------------
 // Four wavefronts share the tile: every layer's output tiles are split over
@@ -139,35 +104,41 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
 
 // cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows)
 // (n_unit is a multiple of 16: thread -> row tid / 16, 16 consecutive units)
-__device__ __forceinline__ void flush_stash(const double* act, double* dst,
+__device__ __forceinline__ void flush_stash(const double* act, nb_gd* dst,
                                             int ld, int n_unit, int tile,
                                             int tid) {
-  const int r = tid >> 4, c = tid & 15;
-  double* row = dst + (long long)(tile * 16 + r) * ld;
-  for (int u = c; u < n_unit; u += 16) row[u] = act[u * LS + r];
+  const unsigned r = tid >> 4, c = tid & 15;
+  nb_gd* row = dst + (tile * 16) * ld;               // wave-uniform
+  const unsigned off = r * ld + c;
+  for (int u = 0; u < n_unit; u += 16) row[off + u] = act[(c + u) * LS + r];
 }
 
-// A operands of one forward output tile, loaded up front
-template <int KSMAX>
-__device__ __forceinline__ void load_fwd(const double* __restrict__ w, int ht_n,
-                                         int ht, int ks_n, int lane,
-                                         double* wr) {
+// A operands of one 16x16 output tile, k-steps 0 .. N-1: `tile0` points at
+// the tile of k-tile 0 (wave-uniform), consecutive k-tiles are TSTRIDE tiles
+// apart; the operand of a k-step is one contiguous 512-byte row block.  The
+// same form serves the forward products (tiles [kt][ht] of W) and, through
+// the transposed copy, the backward ones (tiles [ht][kt] of WT).
+template <int N, int TSTRIDE>
+__device__ __forceinline__ void load_ops(const nb_gd* __restrict__ tile0,
+                                         unsigned lane, double* wr) {
 #pragma unroll
-  for (int ks = 0; ks < KSMAX; ++ks)
-    wr[ks] = (ks < ks_n)
-        ? w[((ks >> 2) * ht_n + ht) * NB_TILE + (ks & 3) * 64 + lane] : 0.0;
+  for (int s = 0; s < N; ++s)
+    wr[s] = ld_xcd(
+        &tile0[(unsigned)((s >> 2) * TSTRIDE * NB_TILE + (s & 3) * 64) + lane]);
 }
 
-// A operands of one backward output tile (transposed access)
-template <int HS>
-__device__ __forceinline__ void load_bwd(const double* __restrict__ w, int ht_n,
-                                         int kt, int lane, double* wr) {
-  const int li = lane & 15, lg = lane >> 4;
+// ... of layer 1: only the k-steps of the last k-tile depend on n_dim
+template <int KT1>
+__device__ __forceinline__ void load_ops_l1(const nb_gd* __restrict__ tile0,
+                                            int ks1, unsigned lane,
+                                            double* wr) {
+  load_ops<4 * (KT1 - 1), NB_HT1>(tile0, lane, wr);
 #pragma unroll
-  for (int hs = 0; hs < HS; ++hs) {
-    const int h0 = 4 * hs;
-    wr[hs] = w[(kt * ht_n + (h0 >> 4)) * NB_TILE + li * 16 + (h0 & 15) + lg];
-  }
+  for (int s = 4 * (KT1 - 1); s < 4 * KT1; ++s)
+    wr[s] = (s < ks1)
+        ? ld_xcd(&tile0[(unsigned)((s >> 2) * NB_HT1 * NB_TILE + (s & 3) * 64) +
+                        lane])
+        : 0.0;
 }
 
 template <int N>
@@ -184,37 +155,27 @@ __device__ __forceinline__ nb_d4 mma(const double* wr, const double* in) {
   return acc0;
 }
 
-// forward output tile `ht`: acc = sum_ks W[ks][ht] * in[ks]
-template <int KSMAX>
-__device__ __forceinline__ nb_d4 fwd_tile(const double* __restrict__ w,
-                                          int ht_n, int ht, int ks_n,
-                                          const double* in, int lane) {
-  nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+// ... with a runtime number of k-steps in the last k-tile (same order of
+// summation: even k-steps into one accumulator, odd ones into the other)
+template <int N>
+__device__ __forceinline__ nb_d4 mma_l1(const double* wr, const double* in,
+                                        int ks_n) {
+  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
-  for (int ks = 0; ks < KSMAX; ++ks) {
-    if (ks < ks_n) {
-      const double a = w[((ks >> 2) * ht_n + ht) * NB_TILE + (ks & 3) * 64 + lane];
-      acc = MFMA(a, in[ks], acc);
+  for (int k = 0; k < N - 4; k += 2) {
+    acc0 = MFMA(wr[k], in[k], acc0);
+    acc1 = MFMA(wr[k + 1], in[k + 1], acc1);
+  }
+#pragma unroll
+  for (int k = N - 4; k < N; ++k) {
+    if (k < ks_n) {
+      if (k & 1) acc1 = MFMA(wr[k], in[k], acc1);
+      else acc0 = MFMA(wr[k], in[k], acc0);
     }
   }
-  return acc;
-}
-
-// backward output tile `kt`: acc = sum_hs W[kt][hs]^T * dout[hs]
-template <int HS>
-__device__ __forceinline__ nb_d4 bwd_tile(const double* __restrict__ w,
-                                          int ht_n, int kt, const double* dout,
-                                          int lane) {
-  const int li = lane & 15, lg = lane >> 4;
-  nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int hs = 0; hs < HS; ++hs) {
-    const int h0 = 4 * hs;
-    const double a = w[(kt * ht_n + (h0 >> 4)) * NB_TILE + li * 16 +
-                       (h0 & 15) + lg];
-    acc = MFMA(a, dout[hs], acc);
-  }
-  return acc;
+  for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+  return acc0;
 }
 
 // The rows of a tile's minibatch slice: permutation entry, the k-steps of the
@@ -222,175 +183,166 @@ __device__ __forceinline__ nb_d4 bwd_tile(const double* __restrict__ w,
 // data, so the resident kernel fetches the NEXT step's rows while it waits at
 // the barrier that ends the current one (two dependent global latencies off
 // the critical path).
-template <int DT>
+template <int KT1>
 struct FbRows {
-  long long row;
-  double x[DT + 1];
+  double x[KT1];
   double yv;
 };
 
-template <int DT>
-__device__ __forceinline__ void fb_gather(const TrainArgs& a, int net, int tile,
-                                          int ep, long long start, int nb,
-                                          FbRows<DT>& in) {
-  constexpr int KS1MAX = 4 * DT + 1;
-  const int lane = threadIdx.x & 63;
+// row index of this lane's point in the minibatch slice starting at `start`
+// of epoch `ep` (rows past the end of the slice read entry 0 and are masked
+// later)
+__device__ __forceinline__ int fb_row_index(const TrainArgs& a, int net,
+                                            int tile, int ep, long long start,
+                                            int nb) {
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  const nb_gi* perm = a.perm + ((long long)net * a.n_epochs + ep) * a.n + start;
+  const int pt = tile * 16 + (lane & 15);
+  return perm[pt < nb ? pt : 0];
+}
+
+template <int KT1>
+__device__ __forceinline__ void fb_gather(const TrainArgs& a, int tile, int nb,
+                                          int row, FbRows<KT1>& in) {
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int D = a.n_dim, ld0 = 16 * a.kt1;
-  const int* perm = a.perm + ((long long)net * a.n_epochs + ep) * a.n;
-  const int pt = tile * 16 + li;
-  const bool valid = pt < nb;
-  in.row = valid ? perm[start + pt] : 0;
+  const int D = a.n_dim;
+  const bool valid = tile * 16 + li < nb;
+  const nb_gd* xr = a.X + (long long)row * D;
 #pragma unroll
-  for (int j = 0; j < DT + 1; ++j) {
-    const int ks = 4 * j + wave;
-    const int f = 4 * ks + lg;
-    double v = 0.0;
-    if (ks < KS1MAX && 4 * ks < ld0)
-      v = (f < D) ? (valid ? a.X[in.row * D + f] : 0.0)
-                  : ((f == D) ? 1.0 : 0.0);
-    in.x[j] = v;
+  for (int j = 0; j < KT1; ++j) {
+    const int f = 4 * (4 * j + wave) + lg;
+    const double v = xr[f < D ? f : D - 1];
+    in.x[j] = (f < D) ? (valid ? v : 0.0) : ((f == D) ? 1.0 : 0.0);
   }
-  in.yv = (wave == 0 && lg == 0 && valid) ? a.y[in.row] : 0.0;
+  const double yv = a.y[row];
+  in.yv = (wave == 0 && lg == 0 && valid) ? yv : 0.0;
 }
 
 #ifdef NB_TRAIN_TIMING
+// In-kernel time stamps (debug build only).  A stamp is s_memtime into LDS --
+// no vector-memory instruction, so it does not wait for the loads in flight
+// (an earlier form accumulated into global memory at every stamp and thereby
+// charged the whole latency of prefetched operands to the stage it sat in);
+// workgroup 0 of network 0 folds the differences once per step.
 __device__ long long g_train_ticks[64];
-#define FB_STAMP(i)                                                           \
+__shared__ long long s_ts[48];
+#define NB_STAMP(cond, i)                                                     \
   do {                                                                        \
-    if (net == 0 && tile == 0 && threadIdx.x == 0) {                          \
-      const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
-      g_train_ticks[i] += t_now - fb_prev;                                    \
-      fb_prev = t_now;                                                        \
-    }                                                                         \
+    if ((cond) && threadIdx.x == 0)                                           \
+      s_ts[i] = (long long)__builtin_amdgcn_s_memtime();                      \
   } while (0)
+#define FB_STAMP(i) NB_STAMP(net == 0 && tile == 0, i)
 #else
 #define FB_STAMP(i)
 #endif
 
 // LDS of a workgroup: the activation / delta blocks of FB in [unit][row]
-// layout; the G phase reuses everything behind the input block (whose zero
-// padding has to survive the step) for its partial tiles.
-// weight tiles per workgroup and step in the resident kernel (32 workgroups)
-template <int DT>
-struct GTiles {
-  static constexpr int N = (NB_HT1 * (DT + 1) + 38 + 31) / 32;
-};
-
-template <int DT>
+// layout; the G phase reuses everything behind the input block for its
+// partial tiles.
+template <int KT1>
 struct FbLds {
-  static constexpr int LD0MAX = 16 * (DT + 1);
+  static constexpr int LD0 = 16 * KT1;
   static constexpr int A0 = 0;
-  static constexpr int A1 = A0 + LD0MAX * LS;
+  static constexpr int A1 = A0 + LD0 * LS;
   static constexpr int A2 = A1 + LD1 * LS;
   static constexpr int A3 = A2 + LD2 * LS;
   static constexpr int D4 = A3 + LD3 * LS;
   static constexpr int D3 = D4 + LD4 * LS;
   static constexpr int D2 = D3 + LD3 * LS;
-  static constexpr int TOTAL = D2 + LD2 * LS;
+  static constexpr int D1 = D2 + LD2 * LS;
+  static constexpr int TOTAL = D1 + LD1 * LS;
   static constexpr int G_RED = A1;             // 1024 doubles per tile
 };
 
-template <int DT, bool CHECK_DONE>
+struct StashPtrs {
+  nb_gd *A0, *A1, *A2, *A3, *D1, *D2, *D3, *D4;
+};
+__device__ __forceinline__ StashPtrs stash_ptrs(const NetState& st, int ld0) {
+  StashPtrs p;
+  p.A0 = st.stash;
+  p.A1 = p.A0 + MAXB * ld0;
+  p.A2 = p.A1 + MAXB * LD1;
+  p.A3 = p.A2 + MAXB * LD2;
+  p.D1 = p.A3 + MAXB * LD3;
+  p.D2 = p.D1 + MAXB * LD1;
+  p.D3 = p.D2 + MAXB * LD2;
+  p.D4 = p.D3 + MAXB * LD3;
+  return p;
+}
+
+template <int KT1, bool CHECK_DONE>
 __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
-                                        int net, int tile, int ep,
-                                        long long start, int nb,
-                                        const FbRows<DT>& rows,
-                                        bool zero_input, double* lds) {
-  constexpr int KS1MAX = 4 * DT + 1;
-  constexpr int LD0MAX = 16 * (DT + 1);
+                                        int net, int tile, int nb,
+                                        const FbRows<KT1>& rows, double* lds) {
+  constexpr int KS1 = 4 * KT1;
+  constexpr int LD0 = 16 * KT1;
   // activations / deltas of the tile in [unit][row] layout
-  double* sA0 = lds + FbLds<DT>::A0;
-  double* sA1 = lds + FbLds<DT>::A1;
-  double* sA2 = lds + FbLds<DT>::A2;
-  double* sA3 = lds + FbLds<DT>::A3;
-  double* sD4 = lds + FbLds<DT>::D4;
-  double* sD3 = lds + FbLds<DT>::D3;
-  double* sD2 = lds + FbLds<DT>::D2;
+  double* sA0 = lds + FbLds<KT1>::A0;
+  double* sA1 = lds + FbLds<KT1>::A1;
+  double* sA2 = lds + FbLds<KT1>::A2;
+  double* sA3 = lds + FbLds<KT1>::A3;
+  double* sD4 = lds + FbLds<KT1>::D4;
+  double* sD3 = lds + FbLds<KT1>::D3;
+  double* sD2 = lds + FbLds<KT1>::D2;
+  double* sD1 = lds + FbLds<KT1>::D1;
 
   if (CHECK_DONE) {
     if (st.scal[4] != 0.0) return;               // network already stopped
   }
-  // (opaque to the optimiser: the per-lane addresses of this function are
-  // recomputed every step -- a few dozen VALU instructions -- instead of being
+  // (opaque to the optimiser: the per-lane offsets of this function are
+  // recomputed every step -- a few VALU instructions -- instead of being
   // hoisted out of the resident kernel's step loop and spilled)
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
+  const unsigned lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int D = a.n_dim, kt1 = a.kt1;
-  const int ld0 = 16 * kt1;
-  const int ks1 = (D + 1 + 3) >> 2;
+  const int ks1 = (a.n_dim + 1 + 3) >> 2;
 
-  double* W1 = st.W;
-  double* W2 = W1 + kt1 * NB_HT1 * NB_TILE;
-  double* W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
-  double* W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
-  double* A0 = st.stash;
-  double* A1 = A0 + MAXB * ld0;
-  double* A2 = A1 + MAXB * LD1;
-  double* A3 = A2 + MAXB * LD2;
-  double* D1 = A3 + MAXB * LD3;
-  double* D2 = D1 + MAXB * LD1;
-  double* D3 = D2 + MAXB * LD2;
-  double* D4 = D3 + MAXB * LD3;
+  const nb_gd* W1 = st.W;
+  const nb_gd* W2 = W1 + KT1 * NB_HT1 * NB_TILE;
+  const nb_gd* W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
+  const nb_gd* W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
+  const nb_gd* T2 = st.WT + WT2;
+  const nb_gd* T3 = st.WT + WT3;
+  const nb_gd* T4 = st.WT + WT4;
+  const StashPtrs sp = stash_ptrs(st, LD0);
 
   const int pt = tile * 16 + li;
   const bool valid = pt < nb;
 
   // ---- weight operands: every wavefront loads the A operands of ITS output
-  // tiles straight into registers, one layer ahead of their use.  A wavefront
-  // can only keep ~64 vector-memory instructions in flight: issuing all ~110
-  // loads of the step up front (as an earlier version did) stalls it until
-  // half of them have returned -- 4.5 us of the step.  Now layer 1 (+ layer 2
-  // for n_dim <= 64) goes out first, the rest after the layer-1 products
-  // (the barriers between the layers are compiler barriers for memory
-  // operations, so the loads stay where they are written; they only wait
-  // for LDS, so operands stay in flight across them). ----------------------
-#ifdef NB_TRAIN_TIMING
-  long long fb_prev = (long long)__builtin_amdgcn_s_memtime();
-#endif
-  double w1r[2][KS1MAX], w2r[26], w3r[13], w4r[6], b4r[1], b3r[5], b2r[2][13];
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
-    load_fwd<KS1MAX>(W1, NB_HT1, ht, ks1, lane, w1r[rep]);
-  }
-  if constexpr (DT <= 4) load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
+  // tiles straight into registers (wave-uniform tile address + lane offset,
+  // one contiguous 512-byte row block per operand), a layer or more ahead of
+  // their use; nothing else sits in the memory queue in front of them -- the
+  // stash stores of the step are issued at the very end. ---------------------
+  double w1r[2][KS1], w2r[26], w3r[13], w4r[6], b4r[1], b3r[5], b2r[2][13];
+  const int ht1b = (wave + 4 < NB_HT1) ? wave + 4 : wave;
+  load_ops_l1<KT1>(W1 + wave * NB_TILE, ks1, lane, w1r[0]);
+  load_ops_l1<KT1>(W1 + ht1b * NB_TILE, ks1, lane, w1r[1]);
+  if constexpr (KT1 <= 4) load_ops<26, NB_HT2>(W2 + wave * NB_TILE, lane, w2r);
 
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
-  // (all of it: rows >= ld0 are multiplied by zero weights and must not
-  // hold NaN bit patterns)
-  // (the padding only has to be cleared once per launch: every step rewrites
-  // exactly the rows below ld0)
-  if (zero_input) {
-    for (int i = tid; i < LD0MAX * LS; i += 256) sA0[i] = 0.0;
-  }
-  lds_barrier();
-  FB_STAMP(10);
 #pragma unroll
-  for (int j = 0; j < DT + 1; ++j) {
-    const int ks = 4 * j + wave;
-    if (ks < KS1MAX && 4 * ks < ld0) sA0[(4 * ks + lg) * LS + li] = rows.x[j];
-  }
+  for (int j = 0; j < KT1; ++j)
+    sA0[(4 * (4 * j + wave) + lg) * LS + li] = rows.x[j];
   lds_barrier();
   FB_STAMP(11);
-  if constexpr (DT > 4) load_fwd<26>(W2, NB_HT2, wave, 26, lane, w2r);
-  // the stash for the G phase is written as soon as a block is complete
-  // (coalesced, fire and forget: the stores overlap the next layer)
-  flush_stash(sA0, A0, ld0, ld0, tile, tid);
+  if constexpr (KT1 > 4) load_ops<26, NB_HT2>(W2 + wave * NB_TILE, lane, w2r);
 
   // ---- layer 1: output tiles wave, wave + 4 ------------------------------
   {
-    double in[KS1MAX];
-    lds_operand<KS1MAX>(sA0, lane, in);
+    double in[KS1];
+    lds_operand<KS1>(sA0, lane, in);
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int ht = wave + 4 * rep;
       if (ht < NB_HT1) {
-        const nb_d4 acc = mma<KS1MAX>(w1r[rep], in);
+        const nb_d4 acc = mma_l1<KS1>(w1r[rep], in, ks1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double v = fmax(acc[r], 0.0);
@@ -404,11 +356,10 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   lds_barrier();
   FB_STAMP(12);
   // the remaining operands, in the order of use (in flight during layer 2)
-  load_fwd<13>(W3, NB_HT3, wave & 1, 13, lane, w3r);
-  load_fwd<6>(W4, 1, 0, 6, lane, w4r);
-  load_bwd<1>(W4, 1, wave & 1, lane, b4r);
-  load_bwd<5>(W3, NB_HT3, wave, lane, b3r);
-  flush_stash(sA1, A1, LD1, LD1, tile, tid);
+  load_ops<13, NB_HT3>(W3 + (wave & 1) * NB_TILE, lane, w3r);
+  load_ops<6, 1>(W4, lane, w4r);
+  load_ops<1, NB_HT3>(T4 + (wave & 1) * NB_TILE, lane, b4r);
+  load_ops<5, NB_HT2>(T3 + wave * NB_TILE, lane, b3r);
 
   // ---- layer 2: output tile = wave ----------------------------------------
   {
@@ -427,12 +378,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(13);
   // (the operands of the last backward product take the registers layer 2's
   // have left; five stages until they are needed)
-#pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
-    const int ht = (wave + 4 * rep < NB_HT1) ? wave + 4 * rep : wave;
-    load_bwd<13>(W2, NB_HT2, ht, lane, b2r[rep]);
-  }
-  flush_stash(sA2, A2, LD2, LD2, tile, tid);
+  load_ops<13, NB_HT1>(T2 + wave * NB_TILE, lane, b2r[0]);
+  load_ops<13, NB_HT1>(T2 + ht1b * NB_TILE, lane, b2r[1]);
 
   // ---- layer 3: two output tiles ------------------------------------------
   if (wave < NB_HT3) {
@@ -449,9 +396,9 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(14);
-  flush_stash(sA3, A3, LD3, LD3, tile, tid);
 
   // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
+  double lp = 0.0;
   if (wave == 0) {
     double in[6];
     lds_operand<6>(sA3, lane, in);
@@ -464,13 +411,11 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       const double v = (unit == 0) ? d40 : 0.0;
       sD4[unit * LS + li] = v;
     }
-    double lp = 0.5 * d40 * d40;
+    lp = 0.5 * d40 * d40;
     for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
-    if (lane == 0) st.scal[8 + tile] = lp;
   }
   lds_barrier();
   FB_STAMP(15);
-  flush_stash(sD4, D4, LD4, LD4, tile, tid);
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
   if (wave < NB_HT3) {
@@ -487,7 +432,6 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(16);
-  flush_stash(sD3, D3, LD3, LD3, tile, tid);
 
   // ---- delta 2 --------------------------------------------------------------
   {
@@ -504,7 +448,6 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(17);
-  flush_stash(sD2, D2, LD2, LD2, tile, tid);
 
   // ---- delta 1 --------------------------------------------------------------
   {
@@ -520,24 +463,63 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
           const int unit = 16 * kt + 4 * r + lg;
           double v = acc[r];
           if (sA1[unit * LS + li] == 0.0 || unit == NB_H1) v = 0.0;
-          D1[(long long)pt * LD1 + unit] = v;
+          sD1[unit * LS + li] = v;
         }
       }
     }
   }
-
+  lds_barrier();
   FB_STAMP(18);
+  // ---- the stash for the G phase, all of it at the end: every block is still
+  // in LDS.  (Written per stage as soon as a block was complete, the stores
+  // sat in the same in-order memory queue as the weight operands of the next
+  // stages, and every stage ended up waiting for a store acknowledgement.)
+  flush_stash(sA0, sp.A0, LD0, LD0, tile, tid);
+  flush_stash(sA1, sp.A1, LD1, LD1, tile, tid);
+  flush_stash(sA2, sp.A2, LD2, LD2, tile, tid);
+  flush_stash(sA3, sp.A3, LD3, LD3, tile, tid);
+  flush_stash(sD4, sp.D4, LD4, LD4, tile, tid);
+  flush_stash(sD3, sp.D3, LD3, LD3, tile, tid);
+  flush_stash(sD2, sp.D2, LD2, LD2, tile, tid);
+  flush_stash(sD1, sp.D1, LD1, LD1, tile, tid);
+  if (wave == 0 && lane == 0) st.scal[8 + tile] = lp;
+  FB_STAMP(19);
 }
 
-template <int DT>
+// A 16-row tile past the end of a short minibatch (the last step of an
+// epoch): its delta rows are cleared, so that G can contract all G_ROWT row
+// tiles of the stash without looking at the batch size (stale activations
+// times zero deltas).
+__device__ __forceinline__ void fb_clear_deltas(const NetState& st, int ld0,
+                                                int tile) {
+  const StashPtrs sp = stash_ptrs(st, ld0);
+  const unsigned tid = threadIdx.x;
+  nb_gd* d1 = sp.D1 + tile * 16 * LD1;
+  nb_gd* d2 = sp.D2 + tile * 16 * LD2;
+  nb_gd* d3 = sp.D3 + tile * 16 * LD3;
+  nb_gd* d4 = sp.D4 + tile * 16 * LD4;
+  for (unsigned i = tid; i < 16 * LD1; i += 256) d1[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD2; i += 256) d2[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD3; i += 256) d3[i] = 0.0;
+  if (tid < 16 * LD4) d4[tid] = 0.0;
+}
+
+template <int KT1>
 __global__ void __launch_bounds__(256)
 nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
-  __shared__ __attribute__((aligned(16))) double lds[FbLds<DT>::TOTAL];
+  __shared__ __attribute__((aligned(16))) double lds[FbLds<KT1>::TOTAL];
   const NetState st = a.nets[blockIdx.y];
-  FbRows<DT> rows;
-  fb_gather<DT>(a, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb, rows);
-  fb_body<DT, true>(a, st, (int)blockIdx.y, (int)blockIdx.x, ep, start, nb,
-                    rows, true, lds);
+  const int tile = (int)blockIdx.x;
+  if (tile * 16 >= nb) {
+    if (st.scal[4] == 0.0) fb_clear_deltas(st, 16 * KT1, tile);
+    return;
+  }
+  for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
+  __syncthreads();
+  FbRows<KT1> rows;
+  fb_gather<KT1>(a, tile, nb,
+                 fb_row_index(a, (int)blockIdx.y, tile, ep, start, nb), rows);
+  fb_body<KT1, true>(a, st, (int)blockIdx.y, tile, nb, rows, lds);
 }
 
 // ---- G: dW of 16x16 weight tiles over the minibatch + Adam ------------------
@@ -546,8 +528,8 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
 __device__ __forceinline__ void loss_fold(const NetState& st, int nb,
                                           int lane) {
   const int n_tiles = (nb + 15) >> 4;
-  const double p = (lane < n_tiles) ? st.scal[8 + lane] : 0.0;
-  double acc = st.scal[5];
+  const double p = (lane < n_tiles) ? ld_xcd(&st.scal[8 + lane]) : 0.0;
+  double acc = ld_xcd(&st.scal[5]);
   for (int i = 0; i < n_tiles; ++i) acc += __shfl(p, i);
   if (lane == 0) st.scal[5] = acc;
 }
@@ -558,169 +540,187 @@ __device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) 
          (1.0 - pow(a.b1, (double)t_adam));
 }
 
-constexpr int G_ROWT = MAXB / 16;   // 16-row tiles of a minibatch
+// A job of the G phase: a block of nk x nh (each 1 or 2) weight tiles of one
+// layer -- k-tiles kt0 .. kt0 + nk - 1, output tiles ht0 .. ht0 + nh - 1 --
+// whose gradients share their operand columns: the nk activation column
+// blocks and the nh delta column blocks are read once for the nk * nh tiles.
+// (A CU gets ~16 bytes per clock out of the L2 when everything misses its L1,
+// as it does behind a barrier: the bytes a workgroup pulls per step are what
+// the phase costs.  One tile per job reads two column blocks per tile, a
+// 2 x 2 block one.)  The job list is built by the host (g_jobs) so that one
+// round of 32 workgroups covers a network for every n_dim.
+constexpr int G_JOB_INTS = 5;     // layer (0..3), kt0, nk, ht0, nh
+constexpr int G_MAX_TILES = 4;
 
-struct GTile {
-  const double* as;   // activations, column block of the tile (wave-uniform)
-  const double* bs;   // deltas, column block of the tile (wave-uniform)
-  int lda, ldb;       // row strides
-  long long woff;     // offset of the weight tile
+struct GLayer {
+  const nb_gd* as;    // activations of the layer's input  (rows x lda)
+  const nb_gd* bs;    // deltas of the layer's output      (rows x ldb)
+  int lda, ldb;
+  int ht_n, kt_n;     // tiles of the layer
+  int wbase;          // offset of the layer's tiles in W / M / V
+  int tbase;          // offset of its transposed tiles in WT, -1 for layer 1
 };
 
-// (everything here is wave-uniform: scalar registers)
-__device__ __forceinline__ GTile g_decode(const TrainArgs& a,
-                                          const NetState& st, int gt) {
-  const int kt1 = a.kt1;
-  const int ld0 = 16 * kt1;
+// (wave-uniform: scalar registers)
+__device__ __forceinline__ GLayer g_layer(const NetState& st, int kt1,
+                                          int layer) {
+  const StashPtrs sp = stash_ptrs(st, 16 * kt1);
   const int n_gt1 = kt1 * NB_HT1, n_gt2 = NB_HT1 * NB_HT2,
             n_gt3 = NB_HT2 * NB_HT3;
-  const double* A0 = st.stash;
-  const double* A1 = A0 + MAXB * ld0;
-  const double* A2 = A1 + MAXB * LD1;
-  const double* A3 = A2 + MAXB * LD2;
-  const double* D1 = A3 + MAXB * LD3;
-  const double* D2 = D1 + MAXB * LD1;
-  const double* D3 = D2 + MAXB * LD2;
-  const double* D4 = D3 + MAXB * LD3;
-  int kt, ht;
-  GTile t;
-  if (gt < n_gt1) {
-    kt = gt / NB_HT1; ht = gt % NB_HT1; t.as = A0; t.lda = ld0; t.bs = D1;
-    t.ldb = LD1;
-    t.woff = (long long)(kt * NB_HT1 + ht) * NB_TILE;
-  } else if (gt < n_gt1 + n_gt2) {
-    const int g = gt - n_gt1;
-    kt = g / NB_HT2; ht = g % NB_HT2; t.as = A1; t.lda = LD1; t.bs = D2;
-    t.ldb = LD2;
-    t.woff = (long long)(n_gt1 + kt * NB_HT2 + ht) * NB_TILE;
-  } else if (gt < n_gt1 + n_gt2 + n_gt3) {
-    const int g = gt - n_gt1 - n_gt2;
-    kt = g / NB_HT3; ht = g % NB_HT3; t.as = A2; t.lda = LD2; t.bs = D3;
-    t.ldb = LD3;
-    t.woff = (long long)(n_gt1 + n_gt2 + kt * NB_HT3 + ht) * NB_TILE;
+  GLayer g;
+  if (layer == 0) {
+    g.as = sp.A0; g.lda = 16 * kt1; g.bs = sp.D1; g.ldb = LD1;
+    g.ht_n = NB_HT1; g.kt_n = kt1; g.wbase = 0; g.tbase = -1;
+  } else if (layer == 1) {
+    g.as = sp.A1; g.lda = LD1; g.bs = sp.D2; g.ldb = LD2;
+    g.ht_n = NB_HT2; g.kt_n = NB_HT1; g.wbase = n_gt1 * NB_TILE;
+    g.tbase = WT2;
+  } else if (layer == 2) {
+    g.as = sp.A2; g.lda = LD2; g.bs = sp.D3; g.ldb = LD3;
+    g.ht_n = NB_HT3; g.kt_n = NB_HT2; g.wbase = (n_gt1 + n_gt2) * NB_TILE;
+    g.tbase = WT3;
   } else {
-    const int g = gt - n_gt1 - n_gt2 - n_gt3;
-    kt = g; ht = 0; t.as = A3; t.lda = LD3; t.bs = D4; t.ldb = LD4;
-    t.woff = (long long)(n_gt1 + n_gt2 + n_gt3 + kt) * NB_TILE;
+    g.as = sp.A3; g.lda = LD3; g.bs = sp.D4; g.ldb = LD4;
+    g.ht_n = 1; g.kt_n = NB_HT3;
+    g.wbase = (n_gt1 + n_gt2 + n_gt3) * NB_TILE;
+    g.tbase = WT4;
   }
-  t.as += 16 * kt;
-  t.bs += 16 * ht;
-  return t;
+  return g;
 }
 
-// operands of quarter `wave` of a tile: rows 16 rt + 4 wave + lg
-__device__ __forceinline__ void g_load(const GTile& t, int n_rt, int wave,
-                                       int lane, double* av, double* bv) {
-  const int li = lane & 15, lg = lane >> 4;
-  const int oa = (4 * wave + lg) * t.lda + li;
-  const int ob = (4 * wave + lg) * t.ldb + li;
+// one 16-column block of a stash matrix, rows 16 rt + 4 wave + lg: the
+// operands of quarter `wave` (wave-uniform row-tile address + a lane offset)
+__device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
+                                           int wave, unsigned lane,
+                                           double* v) {
+  const unsigned li = lane & 15, lg = lane >> 4;
+  const unsigned off = lg * ld + li;
+  const nb_gd* p = base + 16 * col + 4 * wave * ld;
 #pragma unroll
   for (int rt = 0; rt < G_ROWT; ++rt) {
-    const bool on = rt < n_rt;
-    av[rt] = on ? t.as[oa + rt * 16 * t.lda] : 0.0;
-    bv[rt] = on ? t.bs[ob + rt * 16 * t.ldb] : 0.0;
+    v[rt] = ld_xcd(&p[off]);
+    p += 16 * ld;
   }
 }
 
 #ifdef NB_TRAIN_TIMING
-#define G_STAMP(i)                                                            \
-  do {                                                                        \
-    if (MAXT > 1 && first == 0 && threadIdx.x == 0) {                         \
-      const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
-      g_train_ticks[i] += t_now - g_prev;                                     \
-      g_prev = t_now;                                                         \
-    }                                                                         \
-  } while (0)
+#define G_STAMP(i) NB_STAMP(timed, i)
 #else
 #define G_STAMP(i)
 #endif
 
-// Tiles first, first + stride, ... (< n_gt, at most MAXT of them) of one
-// network, by a workgroup of four wavefronts.  Wavefront q contracts the rows
+// One job by a workgroup of four wavefronts.  Wavefront q contracts the rows
 // 16 rt + 4 q + lg of the minibatch (k-step q of every 16-row tile, in the
-// order of rt), so a tile is four independent chains of at most 13 MFMAs on
-// four SIMDs; all operand loads of a tile are issued before the chain of the
-// previous one.  The partial tiles go through LDS; wavefront r then owns rows
-// lg + 4 r of every tile: gradient = ((p0 + p1) + p2) + p3, Adam (sklearn
-// _stochastic_optimizers.py:255-287) in place.
-template <int MAXT>
-__device__ __forceinline__ void g_phase(const TrainArgs& a, const NetState& st,
-                                        int first, int stride, int nb,
-                                        double lr_t, double* red) {
-  int lane = threadIdx.x & 63;
-  // (opaque to the optimiser: per-lane addresses derived from it are
+// order of rt; all G_ROWT row tiles -- the delta rows past a short minibatch
+// are zero), so a tile is four independent chains of 13 MFMAs on four SIMDs;
+// all operand loads are issued before the first chain.  The partial tiles go
+// through LDS; wavefront r then owns rows lg + 4 r of every tile: gradient =
+// ((p0 + p1) + p2) + p3, Adam (sklearn _stochastic_optimizers.py:255-287) in
+// place, and for the layers 2-4 the transposed copy the next backward pass
+// reads.  `after_loads` runs behind the operand loads (the resident kernel
+// fetches the next step's input rows there).
+struct GJob { int layer, kt0, nk, ht0, nh; };
+
+__device__ __forceinline__ GJob g_job_record(const TrainArgs& a, int job) {
+  const nb_gi* rec = a.jobs + job * G_JOB_INTS;
+  GJob j;
+  j.layer = __builtin_amdgcn_readfirstlane(rec[0]);
+  j.kt0 = __builtin_amdgcn_readfirstlane(rec[1]);
+  j.nk = __builtin_amdgcn_readfirstlane(rec[2]);
+  j.ht0 = __builtin_amdgcn_readfirstlane(rec[3]);
+  j.nh = __builtin_amdgcn_readfirstlane(rec[4]);
+  return j;
+}
+
+template <class Hook>
+__device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
+                                      const GJob& jb, int nb, double lr_t,
+                                      double* red, Hook&& after_loads,
+                                      bool timed = false) {
+  int lane_ = threadIdx.x & 63;
+  // (opaque to the optimiser: per-lane offsets derived from it are
   // recomputed every step instead of being kept -- and spilled -- across the
   // forward / backward pass)
-  asm volatile("" : "+v"(lane));
+  asm volatile("" : "+v"(lane_));
+  const unsigned lane = lane_;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-  const int n_gt = nb_net_tiles(a.kt1);
-  const int n_rt = (nb + 15) >> 4;
-#ifdef NB_TRAIN_TIMING
-  long long g_prev = (long long)__builtin_amdgcn_s_memtime();
-#endif
-  GTile tl[MAXT];
+  const unsigned li = lane & 15, lg = lane >> 4;
+  const int layer = jb.layer, kt0 = jb.kt0, nk = jb.nk, ht0 = jb.ht0,
+            nh = jb.nh;
+  const GLayer g = g_layer(st, a.kt1, layer);
+  G_STAMP(33);
   double av[2][G_ROWT], bv[2][G_ROWT];
-  double w_old[MAXT], m_old[MAXT], v_old[MAXT];
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int gt = first + i * stride;
-    if (gt < n_gt) tl[i] = g_decode(a, st, gt);
-  }
-  if (first < n_gt) g_load(tl[0], n_rt, wave, lane, av[0], bv[0]);
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    if (first + i * stride < n_gt) {
-      const long long idx = tl[i].woff + (lg + 4 * wave) * 16 + li;
-      w_old[i] = st.W[idx]; m_old[i] = st.M[idx]; v_old[i] = st.V[idx];
-    }
-  }
+  g_load_col(g.as, g.lda, kt0, wave, lane, av[0]);
+  g_load_col(g.bs, g.ldb, ht0, wave, lane, bv[0]);
+  if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, wave, lane, av[1]);
+  if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, wave, lane, bv[1]);
   G_STAMP(30);
+  after_loads();
+  // this lane's element of every tile of the job: row lg + 4 wave, column li
+  const unsigned eoff = (lg + 4 * wave) * 16 + li;
+  double w_old[G_MAX_TILES], m_old[G_MAX_TILES], v_old[G_MAX_TILES];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    if (first + i * stride < n_gt) {
-      if (i + 1 < MAXT) {
-        if (first + (i + 1) * stride < n_gt)
-          g_load(tl[i + 1], n_rt, wave, lane, av[(i + 1) & 1], bv[(i + 1) & 1]);
+  for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+      if (ia < nk && ib < nh) {
+        const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
+        w_old[2 * ia + ib] = ld_xcd(&(st.W + woff)[eoff]);
+        m_old[2 * ia + ib] = ld_xcd(&(st.M + woff)[eoff]);
+        v_old[2 * ia + ib] = ld_xcd(&(st.V + woff)[eoff]);
       }
-      nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int rt = 0; rt < G_ROWT; ++rt)
-        acc = MFMA(av[i & 1][rt], bv[i & 1][rt], acc);
+  for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        red[((i * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
-    }
-  }
+    for (int ib = 0; ib < 2; ++ib)
+      if (ia < nk && ib < nh) {
+        nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int rt = 0; rt < G_ROWT; ++rt)
+          acc = MFMA(av[ia][rt], bv[ib][rt], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(((2 * ia + ib) * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
+      }
   G_STAMP(31);
   lds_barrier();
+  G_STAMP(36);
   const double inv_nb = 1.0 / (double)nb;
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    if (first + i * stride < n_gt) {
-      const double* p = red + (i * 16 + wave) * 64 + lane;
-      const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
-      const long long idx = tl[i].woff + (lg + 4 * wave) * 16 + li;
-      const double g = sum * inv_nb;
-      const double m = a.b1 * m_old[i] + (1.0 - a.b1) * g;
-      const double v = a.b2 * v_old[i] + (1.0 - a.b2) * (g * g);
-      st.M[idx] = m;
-      st.V[idx] = v;
-      st.W[idx] = w_old[i] + -lr_t * m / (sqrt(v) + a.eps);
-    }
-  }
+  for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+      if (ia < nk && ib < nh) {
+        const int t = 2 * ia + ib;
+        const double* p = red + (t * 16 + wave) * 64 + lane;
+        const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
+        const double gr = sum * inv_nb;
+        const double m = a.b1 * m_old[t] + (1.0 - a.b1) * gr;
+        const double v = a.b2 * v_old[t] + (1.0 - a.b2) * (gr * gr);
+        const double w = w_old[t] + -lr_t * m / (sqrt(v) + a.eps);
+        const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
+        (st.M + woff)[eoff] = m;
+        (st.V + woff)[eoff] = v;
+        (st.W + woff)[eoff] = w;
+        if (g.tbase >= 0) {
+          const int toff =
+              g.tbase + ((ht0 + ib) * g.kt_n + kt0 + ia) * NB_TILE;
+          (st.WT + toff)[li * 16 + lg + 4 * wave] = w;
+        }
+      }
   G_STAMP(32);
 }
 
 __global__ void __launch_bounds__(256)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
-  __shared__ __attribute__((aligned(16))) double red[1024];
+  __shared__ __attribute__((aligned(16))) double red[G_MAX_TILES * 1024];
   const NetState st = a.nets[blockIdx.y];
   if (st.scal[4] != 0.0) return;                 // network already stopped
   // the first workgroup also folds the step's loss (the resident kernel gives
   // that to its least loaded workgroup)
   if (blockIdx.x == 0 && threadIdx.x < 64) loss_fold(st, nb, (int)threadIdx.x);
-  g_phase<1>(a, st, (int)blockIdx.x, 1 << 30, nb, adam_lr(a, t_adam), red);
+  g_job(a, st, g_job_record(a, (int)blockIdx.x), nb, adam_lr(a, t_adam), red,
+        []() {});
 }
 
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
@@ -728,11 +728,11 @@ nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
 __device__ __forceinline__ void epoch_body(const TrainArgs& a,
                                            const NetState& st,
                                            long long t_adam) {
-  if (st.scal[4] != 0.0) return;
-  const double loss = st.scal[5] / (double)a.n;
-  int n_iter = (int)st.scal[3];
-  double best = st.scal[1];
-  int stale = (int)st.scal[2];
+  if (ld_xcd(&st.scal[4]) != 0.0) return;
+  const double loss = ld_xcd(&st.scal[5]) / (double)a.n;
+  int n_iter = (int)ld_xcd(&st.scal[3]);
+  double best = ld_xcd(&st.scal[1]);
+  int stale = (int)ld_xcd(&st.scal[2]);
   st.loss_curve[n_iter] = loss;
   n_iter += 1;
   if (loss > best - a.tol) stale += 1; else stale = 0;
@@ -759,9 +759,9 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 // kernel with an agent-scope barrier pays the same write-back inside the
 // kernel (measured: slower).  What does work: consecutive workgroup ids go
 // round-robin over the 8 XCDs (workgroup i -> XCD i mod 8; checked at run
-// time through HW_REG_XCC_ID), so the 17 workgroups {net, net + 8, ...} of a
-// network share one L2.  Within one L2 a producer only has to wait for its
-// stores (s_waitcnt) and a consumer to drop its CU's L1 (buffer_inv): no L2
+// time through HW_REG_XCC_ID), so 32 workgroups of a network -- one per CU --
+// share one L2.  Within one L2 a producer only has to wait for its stores
+// (s_waitcnt) and a consumer to drop its CU's L1 (buffer_inv): no L2
 // write-back, and the barrier is one atomic in that L2.
 // ---------------------------------------------------------------------------
 constexpr int XCD_COUNT = 8;
@@ -781,6 +781,13 @@ __device__ __forceinline__ void xcd_arrive(int* counter) {
   }
 }
 
+// (Nothing may be in flight in the polling wavefront's vector-memory queue:
+// loads return in order, so a poll behind a prefetch would wait for the
+// prefetch's whole latency -- the resident kernel issues its read-only
+// prefetches inside the phases, not between arrive and wait.  A scalar poll,
+// s_load glc, avoids the queue but was measured at several microseconds per
+// round trip.)  The barrier behind the poll orders LDS traffic only; no cache
+// is invalidated -- the data that crosses CUs is read with ld_xcd.
 __device__ __forceinline__ void xcd_wait(int* counter, int* err, int& phase,
                                          int n_wg) {
   if (threadIdx.x == 0) {
@@ -794,10 +801,8 @@ __device__ __forceinline__ void xcd_wait(int* counter, int* err, int& phase,
         break;
       }
     }
-    // invalidate this CU's vector L1: later loads come from the shared L2
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
@@ -820,14 +825,11 @@ __global__ void nb_xcc_probe_kernel(int* out) {
 }
 
 #ifdef NB_TRAIN_TIMING
-#define TR_STAMP(i)                                                           \
-  do {                                                                        \
-    if (net == 0 && slot == 0 && threadIdx.x == 0) {                          \
-      const long long t_now = (long long)__builtin_amdgcn_s_memtime();        \
-      g_train_ticks[i] += t_now - t_prev;                                     \
-      t_prev = t_now;                                                         \
-    }                                                                         \
-  } while (0)
+#define TR_STAMP(i) NB_STAMP(net == 0 && slot == 0, i)
+// order of the stamps within a step of workgroup 0
+__device__ const int g_stamp_order[19] = {0, 11, 12, 13, 14, 15, 16, 17,
+                                          18, 19, 1, 2, 33, 30, 31, 36, 32,
+                                          3, 4};
 #else
 #define TR_STAMP(i)
 #endif
@@ -836,7 +838,7 @@ __global__ void nb_xcc_probe_kernel(int* out) {
 // owned XCD a free slot, through which the workgroups of OTHER grids -- a
 // concurrent trainer's, which leave at once here, or any other kernel's --
 // pass while this one is resident)
-template <int DT>
+template <int KT1>
 __global__ void __launch_bounds__(256, 2)
 nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
@@ -844,16 +846,13 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   // The workgroup asks the hardware which XCD it runs on and takes a ticket
   // there: the first XCD_SLOTS arrivals on an XCD this trainer owns are the
   // network's workgroups, everybody else leaves.  (The dispatcher deals the
-  // workgroups of a grid out round-robin over the XCDs, 17 each for this
+  // workgroups of a grid out round-robin over the XCDs, 32 each for this
   // grid, but not necessarily starting at XCD 0 when several queues are
-  // active -- two concurrent trainers that both assumed blockIdx % 8 could
-  // end up with 34 resident workgroups on the 32 CUs of one XCD and wait for
-  // each other forever.)
+  // active.)
   __shared__ int sh_slot;
-  __shared__ __attribute__((aligned(16))) double lds[FbLds<DT>::TOTAL];
-  static_assert(FbLds<DT>::TOTAL - FbLds<DT>::G_RED >= GTiles<DT>::N * 1024,
+  __shared__ __attribute__((aligned(16))) double lds[FbLds<KT1>::TOTAL];
+  static_assert(FbLds<KT1>::TOTAL - FbLds<KT1>::G_RED >= G_MAX_TILES * 1024,
                 "the partial tiles of G fit behind the input block");
-  static_assert(XCD_SLOTS == 32, "GTiles assumes 32 workgroups");
   const int n_nets = map.n_nets;
   unsigned xcc_id;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
@@ -867,34 +866,68 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   const int slot = __builtin_amdgcn_readfirstlane(sh_slot);
   if (slot >= XCD_SLOTS) return;
   const NetState st = a.nets[net];
+  // this workgroup's job of the G phase (the same in every step)
+  const GJob my_job = g_job_record(a, slot < a.n_jobs ? slot : 0);
   int phase = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long n = a.n;
   const int steps = (int)((n + a.batch - 1) / a.batch);
+  // the zero padding of the input block (rows >= D + 1 of the last k-tile are
+  // multiplied by zero weights and must not hold NaN bit patterns); every
+  // step rewrites exactly the rows it fills
+  for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
   xcd_barrier(counter, err, phase, XCD_SLOTS);
   long long t_adam = t_adam0;
-  FbRows<DT> rows;
+  FbRows<KT1> rows;
   bool have_rows = false;        // rows = the slice of the step about to run
-  bool zero_input = true;        // the padding of the input block, once
+  int row_next = 0;              // ... and the row index of the step after it
 #ifdef NB_TRAIN_TIMING
-  long long t_prev = (long long)__builtin_amdgcn_s_memtime();
+  bool have_stamps = false;
 #endif
   for (int ep = 0; ep < a.n_epochs; ++ep) {
     // uniform over the network's workgroups: the flag only changes in
     // epoch_body, which is followed by a barrier
-    const bool done = ((volatile double*)st.scal)[4] != 0.0;
+    const bool done = ld_xcd(&st.scal[4]) != 0.0;
     for (int sidx = 0; sidx < steps; ++sidx) {
       const long long start = (long long)sidx * a.batch;
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
       t_adam += 1;
       if (done) continue;
+#ifdef NB_TRAIN_TIMING
+      if (net == 0 && slot == 0 && threadIdx.x == 0) {
+        if (have_stamps) {
+          long long prev = s_ts[0];
+          for (int i = 1; i < 19; ++i) {
+            const int k = g_stamp_order[i];
+            g_train_ticks[k] += s_ts[k] - prev;
+            prev = s_ts[k];
+          }
+          const long long now = (long long)__builtin_amdgcn_s_memtime();
+          g_train_ticks[0] += now - prev;
+        }
+        have_stamps = true;
+      }
+#endif
       TR_STAMP(0);
+      // the minibatch slice after this one (next epoch's permutation after
+      // the last step of an epoch)
+      const bool last = sidx + 1 == steps;
+      const int ep2 = last ? ep + 1 : ep;
+      const long long start2 = last ? 0 : start + a.batch;
+      const int nb2 = (int)((n - start2 < a.batch) ? (n - start2) : a.batch);
+      const bool next_rows = ep2 < a.n_epochs && slot * 16 < nb2;
       if (slot * 16 < nb) {
-        if (!have_rows) fb_gather<DT>(a, net, slot, ep, start, nb, rows);
-        fb_body<DT, false>(a, st, net, slot, ep, start, nb, rows, zero_input,
-                           lds);
-        zero_input = false;
+        if (!have_rows)
+          fb_gather<KT1>(a, slot, nb, fb_row_index(a, net, slot, ep, start, nb),
+                         rows);
+        // its row indices are fetched now and consumed after the G phase,
+        // where the rows themselves are fetched behind the barrier signal:
+        // neither of the two dependent loads is waited for where it is issued
+        if (next_rows) row_next = fb_row_index(a, net, slot, ep2, start2, nb2);
+        fb_body<KT1, false>(a, st, net, slot, nb, rows, lds);
+      } else if (slot < G_ROWT) {
+        fb_clear_deltas(st, 16 * KT1, slot);
       }
       TR_STAMP(1);
       // (the step size -- two pow() -- is computed while waiting)
@@ -902,25 +935,31 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       const double lr_t = adam_lr(a, t_adam);
       xcd_wait(counter, err, phase, XCD_SLOTS);
       TR_STAMP(2);
-      // weight tiles slot, slot + 32, ... on the four wavefronts of this
-      // workgroup (all 32 CUs of the XCD take part, also the ones without a
-      // row tile in FB); the last workgroup has the fewest tiles and folds
-      // the loss
+      // jobs slot, slot + 32, ... of the G phase (all 32 CUs of the XCD take
+      // part, also the ones without a row tile in FB; the host's job list
+      // fits one round); the last workgroup folds the loss
       if (slot == XCD_SLOTS - 1 && wave == 3) loss_fold(st, nb, lane);
-      g_phase<GTiles<DT>::N>(a, st, slot, XCD_SLOTS, nb, lr_t,
-                      lds + FbLds<DT>::G_RED);
-      TR_STAMP(3);
-      xcd_arrive(counter);
+      // the rows of the next step (read-only data) are fetched behind the
+      // operand loads of this phase: in flight under its MFMA chains, back
+      // long before the barrier
+      have_rows = next_rows && slot * 16 < nb;
       {
-        // rows of the next step (next epoch's permutation after the last one)
-        const bool last = sidx + 1 == steps;
-        const int ep2 = last ? ep + 1 : ep;
-        const long long start2 = last ? 0 : start + a.batch;
-        const int nb2 = (int)((n - start2 < a.batch) ? (n - start2) : a.batch);
-        have_rows = ep2 < a.n_epochs && slot * 16 < nb2;
-        if (have_rows) fb_gather<DT>(a, net, slot, ep2, start2, nb2, rows);
+        bool fetched = false;
+        for (int job = slot; job < a.n_jobs; job += XCD_SLOTS) {
+          g_job(a, st, job == slot ? my_job : g_job_record(a, job), nb, lr_t,
+                lds + FbLds<KT1>::G_RED,
+                [&]() __attribute__((always_inline)) {
+                  if (have_rows && !fetched)
+                    fb_gather<KT1>(a, slot, nb2, row_next, rows);
+                  fetched = true;
+                },
+                net == 0 && slot == 0);
+          if (job + XCD_SLOTS < a.n_jobs) lds_barrier();   // red is reused
+        }
+        if (have_rows && !fetched) fb_gather<KT1>(a, slot, nb2, row_next, rows);
       }
-      xcd_wait(counter, err, phase, XCD_SLOTS);
+      TR_STAMP(3);
+      xcd_barrier(counter, err, phase, XCD_SLOTS);
       TR_STAMP(4);
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
@@ -939,6 +978,33 @@ void put_w(double* tiles, int ht_n, int k, int h, double v) {
 double get_w(const double* tiles, int ht_n, int k, int h) {
   return tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
                (h & 15)];
+}
+// The job list of the G phase (see g_job): blocks of up to 2 x 2 tiles per
+// layer, shaped so that a network needs at most 32 jobs -- one round of the
+// resident kernel's workgroups -- at every n_dim.
+std::vector<int> g_jobs(int kt1) {
+  std::vector<int> jobs;
+  auto blocks = [&](int layer, int kt_n, int ht_n, int bk, int bh) {
+    for (int kt = 0; kt < kt_n; kt += bk)
+      for (int ht = 0; ht < ht_n; ht += bh) {
+        const int rec[G_JOB_INTS] = {layer, kt, kt + bk <= kt_n ? bk : 1, ht,
+                                     ht + bh <= ht_n ? bh : 1};
+        jobs.insert(jobs.end(), rec, rec + G_JOB_INTS);
+      }
+  };
+  // layer 1 (kt1 x 7 tiles): pairs along k up to 64 dimensions, 2 x 2 beyond
+  blocks(0, kt1, NB_HT1, 2, kt1 <= 4 ? 1 : 2);
+  // layer 2 (7 x 4): pairs along h, 2 x 2 where layer 1 needs the workgroups
+  blocks(1, NB_HT1, NB_HT2, kt1 >= 7 ? 2 : 1, 2);
+  blocks(2, NB_HT2, NB_HT3, 2, 2);      // layer 3 (4 x 2)
+  blocks(3, NB_HT3, 1, 2, 1);           // layer 4 (2 x 1)
+  return jobs;
+}
+
+// transposed copy: tiles [ht][kt], element (hh, kk)
+void put_wt(double* tiles, int kt_n, int k, int h, double v) {
+  tiles[((size_t)(h >> 4) * kt_n + (k >> 4)) * NB_TILE + (h & 15) * 16 +
+        (k & 15)] = v;
 }
 
 }  // namespace
@@ -978,6 +1044,8 @@ struct nb_trainer {
   double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
   long long t_adam = 0;
   int* sync_dev = nullptr;         // per network: counter, error, xcc mask
+  int* jobs_dev = nullptr;         // job list of the G phase
+  int n_jobs = 0;
   bool two_launch = false;         // fall back to two launches per step
   XcdMap xcd_map;                  // XCDs owned by this trainer's networks
   unsigned xcd_owned = 0;
@@ -1002,7 +1070,7 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
   t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
   const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
   const long long curve = t->max_iter;
-  const long long per_net = 3 * t->n_w + stash + curve + 32;
+  const long long per_net = 3 * t->n_w + WT_DOUBLES + stash + curve + 32;
   const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
   hipError_t e = hipMalloc((void**)&t->pool, bytes);
   if (e == hipSuccess) e = hipMemset(t->pool, 0, bytes);
@@ -1011,6 +1079,15 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
   if (e == hipSuccess)
     e = hipMalloc((void**)&t->sync_dev,
                   SYNC_WORDS * XCD_COUNT * sizeof(int));
+  {
+    const std::vector<int> jobs = g_jobs(t->kt1);
+    t->n_jobs = (int)jobs.size() / G_JOB_INTS;
+    if (e == hipSuccess)
+      e = hipMalloc((void**)&t->jobs_dev, jobs.size() * sizeof(int));
+    if (e == hipSuccess)
+      e = hipMemcpy(t->jobs_dev, jobs.data(), jobs.size() * sizeof(int),
+                    hipMemcpyHostToDevice);
+  }
   t->two_launch = n_networks > XCD_COUNT ||
                   getenv("NB_TRAIN_TWO_LAUNCH") != nullptr ||
                   !xcd_pinning_available();
@@ -1047,8 +1124,9 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
   for (int i = 0; i < n_networks; ++i) {
     NetState s;
     double* base = t->pool + (size_t)i * per_net;
-    s.W = base; s.M = s.W + t->n_w; s.V = s.M + t->n_w;
-    s.stash = s.V + t->n_w;
+    s.W = (nb_gd*)base; s.M = s.W + t->n_w; s.V = s.M + t->n_w;
+    s.WT = s.V + t->n_w;
+    s.stash = s.WT + WT_DOUBLES;
     s.loss_curve = s.stash + stash;
     s.scal = s.loss_curve + curve;
     t->nets_host.push_back(s);
@@ -1070,11 +1148,26 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
     for (int h = 0; h < NB_H3; ++h) put_w(w3, NB_HT3, NB_H2, h, b[2][h]);
     for (int k = 0; k < NB_H3; ++k) put_w(w4, 1, k, 0, c[3][k]);
     put_w(w4, 1, NB_H3, 0, b[3][0]);
-    e = hipMemcpy(s.W, w.data(), (size_t)t->n_w * sizeof(double),
+    e = hipMemcpy((void*)s.W, w.data(), (size_t)t->n_w * sizeof(double),
                   hipMemcpyHostToDevice);
+    {
+      // transposed tiles of layers 2-4 (the backward pass's operands)
+      std::vector<double> wt((size_t)WT_DOUBLES, 0.0);
+      for (int k = 0; k <= NB_H1; ++k)
+        for (int h = 0; h < NB_H2; ++h)
+          put_wt(wt.data() + WT2, NB_HT1, k, h, get_w(w2, NB_HT2, k, h));
+      for (int k = 0; k <= NB_H2; ++k)
+        for (int h = 0; h < NB_H3; ++h)
+          put_wt(wt.data() + WT3, NB_HT2, k, h, get_w(w3, NB_HT3, k, h));
+      for (int k = 0; k <= NB_H3; ++k)
+        put_wt(wt.data() + WT4, NB_HT3, k, 0, get_w(w4, 1, k, 0));
+      if (e == hipSuccess)
+        e = hipMemcpy((void*)s.WT, wt.data(), wt.size() * sizeof(double),
+                      hipMemcpyHostToDevice);
+    }
     const double scal0[8] = {0.0, INFINITY, 0.0, 0.0, 0.0, 0.0, 0, 0};
     if (e == hipSuccess)
-      e = hipMemcpy(s.scal, scal0, sizeof scal0, hipMemcpyHostToDevice);
+      e = hipMemcpy((void*)s.scal, scal0, sizeof scal0, hipMemcpyHostToDevice);
     if (e != hipSuccess) break;
   }
   if (e == hipSuccess)
@@ -1107,7 +1200,9 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
                    int32_t* status_host, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   TrainArgs a;
-  a.nets = t->nets_dev; a.X = t->X; a.y = t->y; a.perm = perm_dev;
+  a.nets = t->nets_dev; a.X = (const nb_gd*)t->X; a.y = (const nb_gd*)t->y;
+  a.perm = (const nb_gi*)perm_dev;
+  a.jobs = (const nb_gi*)t->jobs_dev; a.n_jobs = t->n_jobs;
   a.n = t->n; a.n_dim = t->n_dim; a.kt1 = t->kt1; a.n_epochs = n_epochs;
   a.max_iter = t->max_iter; a.n_iter_no_change = t->n_iter_no_change;
   a.batch = (int)((t->n < t->batch) ? t->n : t->batch);
@@ -1120,14 +1215,14 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
     NB_HIP_CHECK(hipMemsetAsync(t->sync_dev, 0,
                                 SYNC_WORDS * XCD_COUNT * sizeof(int), s));
     const dim3 grid(XCD_COUNT * XCD_SLOTS), blk(256);
-    switch (t->dt) {
-#define NB_CASE(DT_)                                                       \
-      case DT_:                                                            \
-        hipLaunchKernelGGL(nb_train_xcd_kernel<DT_>, grid, blk, 0, s, a,   \
+    switch (t->kt1) {
+#define NB_CASE(KT1_)                                                      \
+      case KT1_:                                                           \
+        hipLaunchKernelGGL(nb_train_xcd_kernel<KT1_>, grid, blk, 0, s, a,  \
                            t->xcd_map, t->t_adam, t->sync_dev);            \
         break;
-      NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4)
-      NB_CASE(5) NB_CASE(6) NB_CASE(7) NB_CASE(8)
+      NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
+      NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
 #undef NB_CASE
       default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
     }
@@ -1141,17 +1236,19 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
     for (int sidx = 0; sidx < steps_per_epoch; ++sidx) {
       const long long start = (long long)sidx * a.batch;
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
-      const dim3 gfb((nb + 15) / 16, t->E), gg(n_gt, t->E), blk(256), blk_fb(256);
+      // (all G_ROWT row tiles: the ones past the end of a short minibatch
+      // clear their delta rows)
+      const dim3 gfb(G_ROWT, t->E), gg(t->n_jobs, t->E), blk(256);
       t->t_adam += 1;
-      switch (t->dt) {
-        case 1: hipLaunchKernelGGL(nb_train_fb_kernel<1>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 2: hipLaunchKernelGGL(nb_train_fb_kernel<2>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 3: hipLaunchKernelGGL(nb_train_fb_kernel<3>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 4: hipLaunchKernelGGL(nb_train_fb_kernel<4>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 5: hipLaunchKernelGGL(nb_train_fb_kernel<5>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 6: hipLaunchKernelGGL(nb_train_fb_kernel<6>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 7: hipLaunchKernelGGL(nb_train_fb_kernel<7>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
-        case 8: hipLaunchKernelGGL(nb_train_fb_kernel<8>, gfb, blk_fb, 0, s, a, ep, start, nb); break;
+      switch (t->kt1) {
+#define NB_CASE(KT1_)                                                      \
+        case KT1_:                                                         \
+          hipLaunchKernelGGL(nb_train_fb_kernel<KT1_>, gfb, blk, 0, s, a,  \
+                             ep, start, nb);                               \
+          break;
+        NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
+        NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
+#undef NB_CASE
         default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
       }
       hipLaunchKernelGGL(nb_train_g_kernel, gg, blk, 0, s, a, nb, t->t_adam);
@@ -1240,6 +1337,7 @@ int nb_trainer_destroy(nb_trainer* t) {
   g_xcd_in_use &= ~t->xcd_owned;
   if (t->nets_dev) (void)hipFree(t->nets_dev);
   if (t->sync_dev) (void)hipFree(t->sync_dev);
+  if (t->jobs_dev) (void)hipFree(t->jobs_dev);
   delete t;
   return NB_OK;
 }

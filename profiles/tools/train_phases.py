@@ -18,15 +18,27 @@ for d, nrow in [(50, 24000), (100, 24000)]:
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     fn(buf)
     steps = ne * ((nrow + 199) // 200)
-    v = np.array(list(buf))[:8]
-    fb = np.array(list(buf))[10:22]
-    fbn = ['weights issue + sA0 zero', 'input fill', 'L1', 'L2', 'L3', 'out + d4', 'd3', 'd2', 'd1 (+D1 store)', '-']
-    names = ['loop top', 'FB (gather + fwd/bwd + stash)', 'barrier 1', 'G (dW + Adam)', 'barrier 2 + prefetch']
-    print('D=%d: %.2f us/step wall; ticks/step %.0f (= %.2f us at 2.4 GHz)' % (d, dt / steps * 1e6, v.sum() / steps, v.sum() / steps / 2400))
-    for i in range(5):
-        print('   %-32s %8.0f ticks/step' % (names[i], v[i] / steps))
-    for i in range(10):
-        print('      fb %-28s %8.0f' % (fbn[i], fb[i] / steps))
-    gg = np.array(list(buf))[30:33]
-    for nm, val in zip(['g: decode + loads issued', 'g: MFMA chain (waits for operands)', 'g: Adam + stores'], gg):
-        print('      %-36s %8.0f' % (nm, val / steps))
+    t = np.array(list(buf), dtype=float) / steps
+    fbn = ['weights issued, input block in LDS', 'L1', 'L2',
+           'L3', 'out + d4', 'd3', 'd2', 'd1 (+D1 store issued)',
+           'stash stores issued']
+    fb_total = t[11:20].sum() + t[1]
+    g_total = t[30:37].sum() + t[3]
+    total = t[0] + fb_total + t[2] + g_total + t[4]
+    print('D=%d: %.2f us/step wall; ticks/step %.0f (%.2f GHz if ticks are '
+          'core cycles)' % (d, dt / steps * 1e6, total,
+                            total / (dt / steps * 1e9)))
+    print('   %-36s %8.0f' % ('loop top (incl. stamp folding)', t[0]))
+    print('   %-36s %8.0f' % ('FB', fb_total))
+    for i in range(9):
+        print('      fb %-34s %8.0f' % (fbn[i], t[11 + i]))
+    print('      fb %-32s %8.0f' % ('return', t[1]))
+    print('   %-36s %8.0f' % ('barrier 1 (+ adam_lr)', t[2]))
+    print('   %-36s %8.0f' % ('G', g_total))
+    for nm, k in [('job record + layer decode', 33),
+                  ('operand loads issued', 30),
+                  ('MFMA chains -> LDS', 31), ('LDS barrier', 36),
+                  ('reduce + Adam + stores issued', 32)]:
+        print('      g %-33s %8.0f' % (nm, t[k]))
+    print('      g %-33s %8.0f' % ('return (+ loss fold elsewhere)', t[3]))
+    print('   %-36s %8.0f' % ('barrier 2 + next rows prefetch', t[4]))
