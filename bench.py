@@ -256,8 +256,19 @@ def cpu_baseline(sampler, like_numpy, seconds, cores):
     try:
         n_batch = (100 // cores + (100 % cores != 0)) * cores
         leg = _oracle_leg(sampler, like_numpy, seconds, pool, n_batch)
+        # the reference's default batch hands every worker about one point
+        # per map(); what the same pool path does when each worker gets ~100
+        # points per call rides along (n_batch = 100 x cores)
+        big = _oracle_leg(sampler, like_numpy, 0.5 * seconds, pool,
+                          100 * cores)
     finally:
         pool.close()
+    out['large_batch'] = dict(
+        value=big['value'], cores=cores, n_batch=100 * cores,
+        points_per_s=big['points_per_s'],
+        proposals_per_s=big['proposals_per_s'],
+        sample='%d add_samples steps of n_batch=%d, pool=%d, %.1f s' % (
+            big['steps'], 100 * cores, cores, big['seconds']))
     out.update(
         value=leg['value'], cores=cores, points_per_s=leg['points_per_s'],
         proposals_per_s=leg['proposals_per_s'], pool_start_s=start_s,
@@ -458,7 +469,7 @@ def main():
     flops = ((work['outer_point_evals'] + work['ellipsoid_point_evals']) *
              d * (d + 1) +
              work['emulator_point_evals'] * 2.0 * (100 * d + 6020))
-    ev = kernels.get('nb_eval_kernel', dict(ms=0.0, launches=0))
+    ev = kernels.get('bound_eval', dict(ms=0.0, launches=0))
     achieved_tf = flops / (ev['ms'] * 1e-3) / 1e12 if ev['ms'] > 0 else 0.0
     # HBM bytes per launch: PMC counters cannot be collected from inside this
     # process.  --pmc-traffic re-runs this command under rocprofv3 --pmc
@@ -469,7 +480,7 @@ def main():
                                   '--pmc-traffic); committed measurements: '
                                   'profiles/r02/')
     if args.pmc_traffic and rank == 0 and world == 1:
-        got = pmc_traffic(sys.argv[1:], 'nb_eval_')
+        got = pmc_traffic(sys.argv[1:], 'nb_eval_fast')
         if got is not None:
             traffic = got['bytes_per_launch']
             traffic_src = ('rocprofv3 --pmc child passes of this command: '
@@ -479,10 +490,12 @@ def main():
                                got['write_bytes_per_launch'],
                                got['launches']))
     roofline = dict(
-        kernel='nb_eval_fast_kernel + nb_eval_kernel', kernel_note=(
-            'bound evaluation of the timed steps: proposal acceptance runs '
-            'in nb_eval_fast_kernel, shell exclusion in nb_eval_kernel; '
-            'launches and time are those of both'),
+        kernel='nb_eval_fast_kernel (+ nb_geom_kernel)', kernel_note=(
+            'bound evaluation of the timed steps: proposal acceptance in '
+            'nb_eval_fast_kernel (fused cube test, ellipsoid, emulators); '
+            'shell exclusion = nb_geom_kernel (geometric tests of the later '
+            'bounds) + nb_eval_fast_kernel on the gathered points that reach '
+            'an emulator; calls and HIP-event time are those of all of them'),
         bound='mfma', achieved=achieved_tf,
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
         frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=traffic,

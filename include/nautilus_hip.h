@@ -347,6 +347,40 @@ int nb_loglike_funnel(const double* u_dev, int64_t n, int32_t n_dim, double mu,
                       double sigma0, double k, double c, double* out_dev,
                       void* stream);
 
+/* Two-stage evaluation of bounds with several outer members, several neural
+ * bounds, or of lists of bounds (bounds/union.py:285-289, 316-319;
+ * bounds/nautilus.py:162-169, 212-222; sampler.py:797-798, 1213-1219).
+ *
+ * Stage 1, nb_geom_*: everything that needs no emulator -- periodic
+ * recentring, unit-cube clip, overlap count of the outer members, acceptance
+ * draw, the ellipsoids of the neural bounds.  Per ROW of x two arrays (zeroed
+ * by the caller before the first call) hold the state:
+ *   st[row]  bit 0 kept by the outer union's acceptance draw (sample),
+ *            bit 1 inside / finally accepted, bit 2 PENDING on an emulator,
+ *            bit 3 decided;
+ *   pos[row] = 256 * b + m: the bound of the list (and, for pending rows, the
+ *            neural bound of it) the row is at; for decided-inside rows of a
+ *            list b is the first bound that contains the row.
+ * idx_dev (optional) lists the rows to process (n of them) -- the rows an
+ * emulator turned down come back with their PENDING bit still set and resume
+ * their walk behind (b, m).
+ * Stage 2, nb_neural_score_rows: (r2, score) of neural bound m of `bound` for
+ * the rows idx_dev[0..n) of x, densely packed (out_dev[2 i], [2 i + 1]) --
+ * the pipelined emulator kernel on full tiles.  recentre != 0: the rows are
+ * in the sampler's frame and the bound's periodic shift is applied first, as
+ * contains() does (nautilus.py:162-163); 0 for proposals, which live in the
+ * bound's frame.  A row is inside if score > score_predict_min - 1e-9
+ * (bounds/neural.py:125).                                                    */
+int nb_geom_list(const nb_boundlist* list, int32_t mode /* 0 any, 1 first */,
+                 const double* x_dev, int64_t n_rows, const int64_t* idx_dev,
+                 int64_t n, int32_t* pos_dev, uint8_t* st_dev, void* stream);
+int nb_geom_sample(const nb_bound* bound, uint64_t seed, uint64_t offset,
+                   const double* x_dev, int64_t n_rows, const int64_t* idx_dev,
+                   int64_t n, int32_t* pos_dev, uint8_t* st_dev, void* stream);
+int nb_neural_score_rows(const nb_bound* bound, int32_t m, int32_t recentre,
+                         const double* x_dev, const int64_t* idx_dev,
+                         int64_t n, double* out_dev, void* stream);
+
 /* The mixture fit of Union.split (bounds/union.py:185-187): scikit-learn's
  * GaussianMixture(n_components=2, n_init=n_init, covariance_type='full')
  * restated on the device -- k-means++ / Lloyd initialisation, EM until the

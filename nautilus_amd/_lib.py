@@ -149,6 +149,15 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     'nb_comm_allreduce_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
+    'nb_geom_list': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    'nb_geom_sample': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64,
+                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nb_neural_score_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p]),
     'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
     'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
     'nb_gmm_logp_offset': (C.c_int64, [C.c_int32]),

@@ -14,10 +14,17 @@
 
 // launchers implemented in the kernel translation units
 bool nb_eval_fast_eligible(int n_dim, int K, int M, int E, bool sample);
-int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample,
-                        const double* x, long long n, unsigned char* out_u8,
-                        double* out_f64, unsigned long long seed,
-                        unsigned long long offset, hipStream_t stream);
+int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
+                        int recentre, const double* x, const long long* idx,
+                        long long n,
+                        unsigned char* out_u8, double* out_f64,
+                        unsigned long long seed, unsigned long long offset,
+                        hipStream_t stream);
+int nb_launch_geom(int dt, const double* const* blobs_dev, int nb, int mode,
+                   const double* x, long long n_rows, const long long* idx,
+                   long long n, int* pos, unsigned char* st,
+                   unsigned long long seed, unsigned long long offset,
+                   hipStream_t stream);
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
                    int* out_i32, double* out_f64, unsigned long long seed,
@@ -557,11 +564,48 @@ int nb_neural_score(const nb_bound* b, const double* x, int64_t n, double* out,
   }
 #ifndef NB_NO_FAST_EVAL
   if (nb_eval_fast_eligible(b->n_dim, b->K, b->M, b->E, false))
-    return nb_launch_eval_fast(b->blob_dev, b->n_dim, false, x, n, nullptr,
-                               out, 0, 0, as_stream(stream));
+    return nb_launch_eval_fast(b->blob_dev, b->n_dim, false, 0, 0, x, nullptr, n,
+                               nullptr, out, 0, 0, as_stream(stream));
 #endif
   return nb_launch_eval(b->dt, b->self_list_dev, 1, 4, x, n, nullptr, nullptr,
                         out, 0, 0, as_stream(stream));
+}
+
+int nb_geom_list(const nb_boundlist* l, int32_t mode, const double* x,
+                 int64_t n_rows, const int64_t* idx, int64_t n, int32_t* pos,
+                 uint8_t* st, void* stream) {
+  if (mode != 0 && mode != 1) {
+    nb_set_error("nb_geom_list: mode must be 0 (any) or 1 (first)");
+    return NB_ERR_ARG;
+  }
+  if (l->n == 0) {
+    nb_set_error("nb_geom_list: empty list");
+    return NB_ERR_ARG;
+  }
+  return nb_launch_geom(l->dt, l->ptrs_dev, l->n, mode, x, n_rows,
+                        (const long long*)idx, n, pos, st, 0, 0,
+                        as_stream(stream));
+}
+
+int nb_geom_sample(const nb_bound* b, uint64_t seed, uint64_t offset,
+                   const double* x, int64_t n_rows, const int64_t* idx,
+                   int64_t n, int32_t* pos, uint8_t* st, void* stream) {
+  return nb_launch_geom(b->dt, b->self_list_dev, 1, 2, x, n_rows,
+                        (const long long*)idx, n, pos, st, seed, offset,
+                        as_stream(stream));
+}
+
+int nb_neural_score_rows(const nb_bound* b, int32_t m, int32_t recentre,
+                         const double* x, const int64_t* idx, int64_t n,
+                         double* out, void* stream) {
+  if (m < 0 || m >= b->M || b->E < 1) {
+    nb_set_error("nb_neural_score_rows: neural bound %d of %d (E = %d)", m,
+                 b->M, b->E);
+    return NB_ERR_ARG;
+  }
+  return nb_launch_eval_fast(b->blob_dev, b->n_dim, false, m, recentre, x,
+                             (const long long*)idx, n, nullptr, out, 0, 0,
+                             as_stream(stream));
 }
 
 int nb_propose(const nb_bound* b, uint64_t seed, uint64_t offset, int64_t n,
@@ -579,8 +623,9 @@ int nb_accept(const nb_bound* b, uint64_t seed, uint64_t offset,
 #ifndef NB_NO_FAST_EVAL
   // one neural bound, at most one outer member: the pipelined kernel
   if (nb_eval_fast_eligible(b->n_dim, b->K, b->M, b->E, true))
-    return nb_launch_eval_fast(b->blob_dev, b->n_dim, true, x, n, flags,
-                               nullptr, seed, offset, as_stream(stream));
+    return nb_launch_eval_fast(b->blob_dev, b->n_dim, true, 0, 0, x, nullptr, n,
+                               flags, nullptr, seed, offset,
+                               as_stream(stream));
 #endif
   return nb_launch_eval(b->dt, b->self_list_dev, 1, 2, x, n, flags, nullptr,
                         nullptr, seed, offset, as_stream(stream));

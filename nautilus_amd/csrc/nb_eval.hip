@@ -402,7 +402,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       int k_cnt[TPW];
       double xin[TPW][4 * DT];
       {
-        load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
+        load_points<DT, TPW>((const nb_gd*)a.x, pt, valid, n_dim, a.n, lane, xin, shift);
 
         // Bounding-sphere pre-test (shell exclusion / association): a point
         // of a bound with neural bounds lies inside one of their ellipsoids,
@@ -523,14 +523,14 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               __syncthreads();                         // LDS free
               dma_weights<NW>(nb_m, tlds, NBLK, wave, lane);
               if (early) dma_weights<NW>(nets, wlds, n_a0, wave, lane);
-              load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin,
+              load_points<DT, TPW>((const nb_gd*)a.x, pt, valid, n_dim, a.n, lane, xin,
                                    shift);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             ell_eval<DT, TPW>(tlds, n_dim, xin, lane, y, box_bad, r2);
           } else {
-            load_points<DT, TPW>(a.x, pt, valid, n_dim, a.n, lane, xin, shift);
+            load_points<DT, TPW>((const nb_gd*)a.x, pt, valid, n_dim, a.n, lane, xin, shift);
             __syncthreads();
             stage_weights<NW>(nb_m, wlds, NBLK);
             __syncthreads();

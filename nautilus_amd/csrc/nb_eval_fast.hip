@@ -44,6 +44,10 @@ struct FastArgs {
   const double* blob;
   int sample;                     // 1: flags of nb_accept, 0: (r2, score)
   const nb_gd* x;
+  const long long* idx;           // optional (scores): rows of x to evaluate
+  int m;                          // neural bound of the blob to evaluate
+  int recentre;                   // rows are in the sampler's frame: apply
+                                  // the bound's periodic shift first
   long long n;
   unsigned char* out_u8;
   double* out_f64;
@@ -113,15 +117,14 @@ __device__ __forceinline__ void ell_eval_centre(
 // so that nothing waits for the loads where they are issued.
 template <int DT, int T>
 __device__ __forceinline__ void load_points_raw(
-    const nb_gd* __restrict__ x, const long long (&pt)[T],
-    const bool (&valid)[T], int n_dim, long long n, int lane,
-    double2 (&raw)[T][2 * DT]) {
+    const nb_gd* __restrict__ x, const long long (&row_of)[T], int n_dim,
+    int lane, double2 (&raw)[T][2 * DT]) {
   const int lg = lane >> 4;
   asm volatile("" : "+s"(x));
   if ((n_dim & 1) == 0) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+      const nb_gd* row = x + row_of[t] * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void load_points_raw(
   } else {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+      const nb_gd* row = x + row_of[t] * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
@@ -195,7 +198,11 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   const bool use_cube = nb_hdr(blob, NB_H_USECUBE) != 0;
   const int E = (int)nb_hdr(blob, NB_H_E);
   const int ks1 = (n_dim + 1 + 3) >> 2;
-  const double* nb_m = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
+  const double* shift =
+      (a.recentre != 0 && nb_hdr(blob, NB_H_OFF_SHIFT) != 0)
+          ? blob + nb_hdr(blob, NB_H_OFF_SHIFT) : nullptr;
+  const double* nb_m = blob + nb_hdr(blob, NB_H_OFF_NEURAL) +
+                       a.m * nb_hdr(blob, NB_H_NEURAL_STRIDE);
   const long long net_stride = nb_hdr(blob, NB_H_NET_STRIDE);
   const double* nets = nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
   const long long n_super = (a.n + 16 * NW * T - 1) / (16 * NW * T);
@@ -253,12 +260,19 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   long long pt[T];
   bool valid[T];
   double2 xraw[T][2 * DT];
+  // row of x behind slot p: p itself, or idx[p] (gathered scores); slots past
+  // the end read row 0 and are masked
+  auto row_of = [&](long long p) __attribute__((always_inline)) {
+    return p < a.n ? (a.idx != nullptr ? a.idx[p] : p) : 0ll;
+  };
+  long long nrow[T];             // rows of the pass after the current one
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     pt[t] = ((sup * NW + wave) * T + t) * 16 + (lane & 15);
     valid[t] = pt[t] < a.n;
+    nrow[t] = row_of(pt[t]);
   }
-  load_points_raw<DT, T>(a.x, pt, valid, n_dim, a.n, lane, xraw);
+  load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
 
   for (; sup < n_super; sup += gridDim.x) {
     // layer 1 (chunk a) of the first network -> the other region, under the
@@ -278,8 +292,25 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       pt[t] = ((sup * NW + wave) * T + t) * 16 + (lane & 15);
       valid[t] = pt[t] < a.n;
       in_cube[t] = true;
+      // (the index of the next pass's row, a pass ahead of its loads)
+      nrow[t] = row_of((((sup + gridDim.x) * NW + wave) * T + t) * 16 +
+                       (lane & 15));
     }
     points_from_raw<DT, T>(xraw, valid, n_dim, lane, xin);
+    if (shift != nullptr) {
+      // periodic dimensions are recentred before the test (nautilus.py:
+      // 162-163, periodic.py:69-71): x <- (x + (0.5 - centre)) mod 1
+#pragma unroll
+      for (int ks = 0; ks < 4 * DT; ++ks) {
+        const double sv = shift[4 * ks + lg];
+        const bool on = shift[DP + 4 * ks + lg] != 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const double v = xin[t][ks] + sv;
+          xin[t][ks] = on ? v - floor(v) : xin[t][ks];
+        }
+      }
+    }
     if (m_sample) {
       bool cbad[T];
 #pragma unroll
@@ -388,15 +419,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       // -- layers 2-4; next network's chunk a, or the ellipsoid block of the
       // next pass, -> other region
       if constexpr (LAST) {
-        const long long nsup = sup + gridDim.x;
-        long long npt[T];
-        bool nvalid[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          npt[t] = ((nsup * NW + wave) * T + t) * 16 + (lane & 15);
-          nvalid[t] = npt[t] < a.n;
-        }
-        load_points_raw<DT, T>(a.x, npt, nvalid, n_dim, a.n, lane, xraw);
+        load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
         dma_begin_ell(reg(cur ^ 1));
       } else {
         dma_begin(nets + (e + 1) * net_stride, reg(cur ^ 1), NA_D);
@@ -485,17 +508,22 @@ unsigned long long* nb_eval_counters();
 // one neural bound with networks, and for proposals at most one outer member
 // (the draw then needs no overlap count)
 bool nb_eval_fast_eligible(int n_dim, int K, int M, int E, bool sample) {
-  if (n_dim > 128 || M != 1 || E < 1) return false;
-  return !sample || K <= 1;
+  if (n_dim > 128 || M < 1 || E < 1) return false;
+  // proposals: the fused cube test / acceptance draw of this kernel covers
+  // one neural bound and at most one outer member; scores: any neural bound
+  return !sample || (K <= 1 && M == 1);
 }
 
-int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample,
-                        const double* x, long long n, unsigned char* out_u8,
-                        double* out_f64, unsigned long long seed,
-                        unsigned long long offset, hipStream_t stream) {
+int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
+                        int recentre, const double* x, const long long* idx,
+                        long long n,
+                        unsigned char* out_u8, double* out_f64,
+                        unsigned long long seed, unsigned long long offset,
+                        hipStream_t stream) {
   if (n <= 0) return NB_OK;
   FastArgs a;
   a.blob = blob_dev; a.sample = sample ? 1 : 0; a.x = (const nb_gd*)x; a.n = n;
+  a.idx = idx; a.m = m; a.recentre = recentre;
   a.out_u8 = out_u8; a.out_f64 = out_f64; a.seed = seed; a.offset = offset;
   a.counters = nb_eval_counters();
   const int dt = (n_dim + 15) / 16, kt1 = (n_dim + 1 + 15) / 16;

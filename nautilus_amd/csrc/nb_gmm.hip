@@ -355,7 +355,7 @@ nb_gmm_kernel(GmmArgs a) {
         long long pt[1] = {(long long)tile * 16 + lj};
         bool valid[1] = {pt[0] < n};
         double xin[1][4 * DT];
-        load_points<DT, 1>(x, pt, valid, d, (long long)n, lane, xin);
+        load_points<DT, 1>((const nb_gd*)x, pt, valid, d, (long long)n, lane, xin);
 #pragma unroll
         for (int ks = 0; ks < ks_max; ++ks)
           xin[0][ks] = valid[0] ? xin[0][ks] - mus[4 * ks + lg] : 0.0;

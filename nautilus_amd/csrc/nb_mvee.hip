@@ -528,7 +528,7 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
     long long pt[1] = {(long long)base + tile * 16 + lj};
     bool valid[1] = {tile * 16 + lj < cnt};
     double xin[1][4 * DT];
-    load_points<DT, 1>(pb.xs, pt, valid, d, (long long)n, lane, xin);
+    load_points<DT, 1>((const nb_gd*)pb.xs, pt, valid, d, (long long)n, lane, xin);
 #pragma unroll
     for (int ks = 0; ks < 4 * DT; ++ks)
       if (ks == ks_one && lg == lg_one) xin[0][ks] = valid[0] ? 1.0 : 0.0;

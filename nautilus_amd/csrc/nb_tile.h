@@ -110,7 +110,7 @@ __device__ __forceinline__ void ell_eval(const double* blk,
 // contiguous bytes per instruction.  The per-dimension vectors (lo, hi, c) and
 // the K index of the ellipsoid tiles are stored in slot order by the host.
 template <int DT, int TPW>
-__device__ __forceinline__ void load_points(const double* __restrict__ x,
+__device__ __forceinline__ void load_points(const nb_gd* __restrict__ x,
                                             const long long (&pt)[TPW],
                                             const bool (&valid)[TPW],
                                             int n_dim, long long n, int lane,
@@ -125,12 +125,13 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
   if (even) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const double* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+      const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
         const bool in = valid[t] && f < n_dim;
-        const double2 v = *(const double2*)(row + (f < n_dim ? f : n_dim - 2));
+        const double2 v =
+            *(const NB_G double2*)(row + (f < n_dim ? f : n_dim - 2));
         xin[t][2 * j] = in ? v.x : 0.0;
         xin[t][2 * j + 1] = in ? v.y : 0.0;
       }
@@ -138,7 +139,7 @@ __device__ __forceinline__ void load_points(const double* __restrict__ x,
   } else {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const double* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
+      const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;

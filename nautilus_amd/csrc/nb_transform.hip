@@ -23,7 +23,7 @@ nb_transform_kernel(const double* __restrict__ blk, int n_dim,
     bool valid[1] = {pt[0] < n};
     double xin[1][4 * DT], y[1][4 * DT], r2[1];
     bool box_bad[1];
-    load_points<DT, 1>(x, pt, valid, n_dim, n, lane, xin);
+    load_points<DT, 1>((const nb_gd*)x, pt, valid, n_dim, n, lane, xin);
     ell_eval<DT, 1>(blk, n_dim, xin, lane, y, box_bad, r2);
     if (valid[0]) {
 #pragma unroll

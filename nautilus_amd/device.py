@@ -91,6 +91,12 @@ class DeviceBound:
             fill_member(md, src)
         n_arr = (_lib.NeuralDesc * max(1, self.n_neural))()
         self.n_networks = 0
+        # emulator threshold of every neural bound (bounds/neural.py:125), as
+        # the blob holds it
+        self.thresholds = [float(src.get('score_predict_min', 0.0)) - 1e-9
+                           for src in neural]
+        self.dense_need = None     # share of proposals that reach an emulator
+        self._launches = 0
         for nd, src in zip(n_arr, neural):
             fill_member(nd.ellipsoid, src['ellipsoid'])
             nd.score_predict_min = float(src.get('score_predict_min', 0.0))
@@ -156,10 +162,14 @@ class DeviceBound:
     # -- queries ---------------------------------------------------------
     def contains(self, x):
         x = as_device_points(x, self.n_dim)
-        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
-        _lib.check(self._lib.nb_contains(self._h, _ptr(x), x.shape[0],
-                                         _ptr(mask), _stream()))
-        return mask.bool()
+        st, _ = two_stage([self], self._self_list(), GEOM_ANY, x)
+        return (st & GS_INSIDE) != 0
+
+    def _self_list(self):
+        lst = self.__dict__.get('_list')
+        if lst is None:
+            lst = self._list = DeviceBoundList([self])
+        return lst
 
     def contains_stream(self, x):
         x = as_device_points(x, self.n_dim)
@@ -199,10 +209,28 @@ class DeviceBound:
         return x
 
     def accept(self, seed, offset, x, reuse=False):
-        flags = _buffer('accept', (x.shape[0],), torch.uint8, reuse)
-        _lib.check(self._lib.nb_accept(self._h, seed, offset, _ptr(x),
-                                       x.shape[0], _ptr(flags), _stream()))
-        return flags
+        """Flags of ``sample`` (bit 0: kept by the outer union's acceptance
+        draw, bit 1: accepted) for the proposals ``x`` of stream position
+        ``offset``.  Two routes, same decisions: the fused kernel (cube test,
+        acceptance draw, ellipsoid and emulators of ONE neural bound in one
+        pass over dense tiles) where most proposals reach the emulator, the
+        two-stage route (``two_stage``) for several outer members or neural
+        bounds -- and for bounds whose proposals mostly die in the geometric
+        tests (a funnel's envelope sticks far out of the unit cube): there
+        the emulators only see the survivors."""
+        fused_ok = (self.n_neural == 1 and self.n_members <= 1 and
+                    self.n_networks >= 1)
+        self._launches += 1
+        probe = self.dense_need is None or self._launches % 64 == 0
+        if fused_ok and not probe and self.dense_need > 0.5:
+            flags = _buffer('accept', (x.shape[0],), torch.uint8, reuse)
+            _lib.check(self._lib.nb_accept(self._h, seed, offset, _ptr(x),
+                                           x.shape[0], _ptr(flags),
+                                           _stream()))
+            return flags
+        st, n_need = two_stage([self], self, GEOM_SAMPLE, x, seed, offset)
+        self.dense_need = n_need / max(1, x.shape[0])
+        return st & 3
 
     def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False):
         """One launch of the device ``sample`` pipeline: draw, accept,
@@ -242,17 +270,89 @@ class DeviceBoundList:
         """mask[i] = any bound of the list contains x[i] (uint8 flags for the
         compaction kernels with ``as_flags``)."""
         x = as_device_points(x, self.n_dim)
-        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
-        _lib.check(self._lib.nb_contains_any(self._h, _ptr(x), x.shape[0],
-                                             _ptr(mask), _stream()))
-        return mask if as_flags else mask.bool()
+        st, _ = two_stage(self.bounds, self, GEOM_ANY, x)
+        inside = (st & GS_INSIDE) != 0
+        return inside.to(torch.uint8) if as_flags else inside
 
     def first_containing(self, x):
         x = as_device_points(x, self.n_dim)
-        idx = torch.empty(x.shape[0], dtype=torch.int32, device='cuda')
-        _lib.check(self._lib.nb_first_containing(self._h, _ptr(x), x.shape[0],
-                                                 _ptr(idx), _stream()))
-        return idx
+        st, _, pos = two_stage(self.bounds, self, GEOM_FIRST, x,
+                               return_pos=True)
+        return torch.where((st & GS_INSIDE) != 0, pos >> 8,
+                           torch.full_like(pos, -1))
+
+
+GEOM_ANY, GEOM_FIRST, GEOM_SAMPLE = 0, 1, 2
+GS_OUTER, GS_INSIDE, GS_PENDING, GS_DONE = 1, 2, 4, 8
+GS_NOT_PENDING = 0xFF ^ GS_PENDING
+
+
+def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
+    """Bound evaluation in two stages (``nb_geom_*`` + ``nb_neural_score_rows``,
+    include/nautilus_hip.h): the geometric tests of every point first, then
+    the emulators on dense gathers of exactly the points that wait for them,
+    one gather per (bound, neural bound); points an emulator turns down go
+    back to the geometric stage and walk on.  ``bounds``: the DeviceBound
+    objects behind ``target`` (a DeviceBoundList, or the DeviceBound itself
+    for ``GEOM_SAMPLE``).  Returns (status bytes per point, number of points
+    that reached an emulator[, positions])."""
+    lib = _lib.load()
+    n = x.shape[0]
+    st = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    pos = torch.zeros(n, dtype=torch.int32, device='cuda')
+    n_need = 0
+    if n == 0 or len(bounds) == 0:
+        return (st, 0, pos) if return_pos else (st, 0)
+    idx, n_act = None, n
+    while True:
+        if mode == GEOM_SAMPLE:
+            _lib.check(lib.nb_geom_sample(
+                target._h, seed, offset, _ptr(x), n,
+                _ptr(idx) if idx is not None else None, n_act, _ptr(pos),
+                _ptr(st), _stream()))
+        else:
+            _lib.check(lib.nb_geom_list(
+                target._h, mode, _ptr(x), n,
+                _ptr(idx) if idx is not None else None, n_act, _ptr(pos),
+                _ptr(st), _stream()))
+        sub = st if idx is None else st[idx]
+        pend = torch.nonzero(sub & GS_PENDING).squeeze(1)
+        if pend.numel() == 0:
+            break
+        if idx is not None:
+            pend = idx[pend]
+        n_need += int(pend.numel())
+        keys = pos[pend]
+        if len(bounds) > 1 or bounds[0].n_neural > 1:
+            order = torch.argsort(keys, stable=True)
+            pend, keys = pend[order], keys[order]
+            groups, sizes = torch.unique_consecutive(keys, return_counts=True)
+            groups, sizes = groups.tolist(), sizes.tolist()
+        else:
+            groups, sizes = [0], [int(pend.numel())]
+        scores = _buffer('two_stage_scores', (pend.numel(), 2),
+                         torch.float64, False)
+        ok = torch.empty(pend.numel(), dtype=torch.bool, device='cuda')
+        at = 0
+        for key, size in zip(groups, sizes):
+            b, m = key >> 8, key & 255
+            rows = pend[at:at + size]
+            out = scores[at:at + size]
+            _lib.check(lib.nb_neural_score_rows(
+                bounds[b]._h, m, 0 if mode == GEOM_SAMPLE else 1, _ptr(x),
+                _ptr(rows), size, _ptr(out), _stream()))
+            ok[at:at + size] = out[:, 1] > bounds[b].thresholds[m]
+            at += size
+        st[pend[ok]] = (st[pend[ok]] & GS_NOT_PENDING) | (GS_INSIDE | GS_DONE)
+        back = pend[~ok]
+        if back.numel() == 0:
+            break
+        if mode == GEOM_SAMPLE and bounds[0].n_neural == 1:
+            # no other neural bound could take them
+            st[back] = (st[back] & GS_NOT_PENDING) | GS_DONE
+            break
+        idx, n_act = back.contiguous(), int(back.numel())
+    return (st, n_need, pos) if return_pos else (st, n_need)
 
 
 MAX_DIM = 128          # n_dim limit of the device kernels
@@ -702,15 +802,19 @@ def _timed(name):
     return deco
 
 
-DeviceBound.contains = _timed('nb_eval_kernel')(DeviceBound.contains)
-DeviceBound.accept = _timed('nb_eval_kernel')(DeviceBound.accept)
-DeviceBound.neural_score = _timed('nb_eval_kernel')(DeviceBound.neural_score)
+# HIP-event time per kernel family (bench.py).  'bound_eval' = everything that
+# evaluates bounds on the matrix cores -- the fused acceptance kernel
+# (nb_eval_fast_kernel), the geometric stage (nb_geom_kernel) and the gathered
+# emulator scores behind it.
+DeviceBound.contains = _timed('bound_eval')(DeviceBound.contains)
+DeviceBound.accept = _timed('bound_eval')(DeviceBound.accept)
+DeviceBound.neural_score = _timed('bound_eval')(DeviceBound.neural_score)
 DeviceBound.propose = _timed('nb_draw_kernel')(DeviceBound.propose)
 DeviceBound.contains_stream = _timed('nb_ell_stream_kernel')(
     DeviceBound.contains_stream)
-DeviceBoundList.contains_any = _timed('nb_eval_kernel')(
+DeviceBoundList.contains_any = _timed('bound_eval')(
     DeviceBoundList.contains_any)
-DeviceBoundList.first_containing = _timed('nb_eval_kernel')(
+DeviceBoundList.first_containing = _timed('bound_eval')(
     DeviceBoundList.first_containing)
 compact_rows = _timed('nb_compact')(compact_rows)
 shell_stats = _timed('nb_lse')(shell_stats)

@@ -125,11 +125,14 @@ class Trainer:
         _lib.check(self._lib.nb_trainer_weights(self._h, net, cp, ip))
         return coefs, intercepts
 
-    def __del__(self):
+    def close(self):
         h = getattr(self, '_h', None)
         if h:
             self._lib.nb_trainer_destroy(h)
             self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def _hparams_from_kwargs(kwargs):
@@ -304,6 +307,10 @@ class _TrainJob:
         self.done_epochs += perms.shape[1]
         return True
 
+    def release(self):
+        """Destroy the trainer (frees its XCDs and device buffers)."""
+        self.trainer.close()
+
     def result(self):
         networks = []
         with torch.cuda.stream(self.stream):
@@ -318,27 +325,49 @@ class _TrainJob:
         return networks, stats
 
 
+N_XCD = 8            # one XCD per network of a resident trainer
+
+
 def train_ensembles(jobs):
-    """Train several ensembles concurrently, one HIP stream each (the neural
-    bounds of a multi-modal NautilusBound: every Adam step is a pair of small
-    launches, so independent ensembles fill the GPU side by side).  ``jobs``:
-    list of dicts with keys xs, y, seeds and optionally hparams,
-    permutations, init, max_epochs."""
+    """Train several ensembles (the neural bounds of a multi-modal
+    NautilusBound), as many at a time as the GPU has XCDs for: the resident
+    training kernel gives every network an XCD of its own -- all 32 CUs --
+    so two ensembles of four networks train side by side and the others take
+    their turn as XCDs come free.  (An ensemble that starts while all XCDs are
+    taken would fall back to two launches per Adam step next to the resident
+    kernels: measured 80-120 us per step instead of 18.)  One HIP stream per
+    ensemble.  ``jobs``: list of dicts with keys xs, y, seeds and optionally
+    hparams, permutations, init, max_epochs."""
     main = torch.cuda.current_stream()
-    running = []
-    for k, job in enumerate(jobs):
-        stream = main if len(jobs) == 1 else torch.cuda.Stream()
-        stream.wait_stream(main)
-        running.append(_TrainJob(
-            job['xs'], job['y'], job['seeds'], job.get('hparams'),
-            job.get('permutations'), job.get('init'), job.get('max_epochs'),
-            stream))
-    active = list(running)
-    while active:
-        active = [j for j in active if j.step()]
-    out = [j.result() for j in running]
-    for j in running:
-        main.wait_stream(j.stream)
+    waiting = list(enumerate(jobs))
+    running, out = [], [None] * len(jobs)
+    free = N_XCD
+    while waiting or running:
+        while waiting:
+            k, job = waiting[0]
+            need = len(job['seeds'])
+            # (more networks than XCDs: the trainer uses two launches per
+            # step anyway; let it run alone)
+            if need > free and (running or need <= N_XCD):
+                break
+            waiting.pop(0)
+            stream = main if len(jobs) == 1 else torch.cuda.Stream()
+            stream.wait_stream(main)
+            free -= min(need, N_XCD)
+            running.append((k, min(need, N_XCD), _TrainJob(
+                job['xs'], job['y'], job['seeds'], job.get('hparams'),
+                job.get('permutations'), job.get('init'),
+                job.get('max_epochs'), stream)))
+        still = []
+        for k, need, j in running:
+            if j.step():
+                still.append((k, need, j))
+            else:
+                out[k] = j.result()
+                main.wait_stream(j.stream)
+                j.release()                  # its XCDs are free again
+                free += need
+        running = still
     return out
 
 
