@@ -511,9 +511,17 @@ def main():
         point_evals=work, dominant_by_time=dominant,
         time_share={k: v['ms'] for k, v in kernels.items()})
 
+    # emulator networks per bound (M x E) against the ranks they are dealt out
+    # over (network g trains on rank g mod world, reference neural.py:93-96)
+    nets_per_bound = max(
+        [sum(len(nbd.emulator.neural_networks) for nbd in b.neural_bounds
+             if nbd.emulator is not None) for b in sampler.bounds[1:]] or [0])
     out = dict(
         metric='effective posterior samples/sec + |dlogZ| vs analytic, '
                '50-dim Gaussian',
+        ranks_training=min(world, nets_per_bound),
+        ranks_idle_while_training=max(0, world - nets_per_bound),
+        networks_per_bound=nets_per_bound,
         value=(n_eff1 - n_eff0) / dt, unit='effective samples/s',
         value_definition='growth of the effective sample size over the K '
                          'timed sampling-phase steps / their wall time (the '

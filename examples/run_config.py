@@ -32,7 +32,13 @@ def main():
     ap.add_argument('--counters', action='store_true',
                     help='point-evaluation counters of the bound kernels and '
                          'HIP-event time per kernel family')
+    ap.add_argument('--watchdog', type=float, default=0,
+                    help='dump the Python stack and exit after this many '
+                         'seconds (debugging aid)')
     args = ap.parse_args()
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     c = baseline_config(args.name)
     t0 = time.time()
     s = Sampler(unit_prior, c['likelihood'], n_dim=c['n_dim'],

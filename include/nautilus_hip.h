@@ -206,14 +206,27 @@ int nb_live_stats(const double* log_l_dev, int64_t n, const double* thr_dev,
 
 /* Emulator training, NeuralNetworkEmulator.train -> MLPRegressor.fit
  * (neural.py:50-98; sklearn/_multilayer_perceptron.py:620-760): Adam,
- * minibatch 200, squared loss, stop after 11 stale epochs.  One workgroup per
- * network.  See nb_mlp_train.hip for the state layout.                      */
+ * minibatch 200, squared loss, stop after 11 stale epochs.  A resident kernel
+ * trains up to 16 networks at a time, every network on the 32 CUs of one XCD
+ * (two networks per XCD beyond 8).  See nb_mlp_train.hip for the state
+ * layout.                                                                    */
 typedef struct nb_trainer nb_trainer;
 int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
                       const double* x_dev, const double* y_dev,
                       const double* const* coefs_host,
                       const double* const* intercepts_host,
                       nb_trainer** out);
+/* A fleet: the networks of SEVERAL ensembles -- the neural bounds of a
+ * multi-modal NautilusBound, nautilus.py:107-114 -- in one trainer, network i
+ * with the training set (x_dev_of[i], y_dev_of[i], n_rows_of[i]) of its
+ * ensemble; all of them train in the same resident launches.               */
+int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
+                            const int64_t* n_rows_of,
+                            const double* const* x_dev_of,
+                            const double* const* y_dev_of,
+                            const double* const* coefs_host,
+                            const double* const* intercepts_host,
+                            nb_trainer** out);
 /* Optional: MLPRegressor hyper-parameters (defaults are the reference's,
  * neural.py:79-81: lr 1e-2, betas 0.9/0.999, eps 1e-8, batch 200, max_iter
  * 10000, n_iter_no_change 10, tol 0).                                       */
@@ -227,6 +240,10 @@ int nb_trainer_set_hparams(nb_trainer* t, double lr, double beta1,
  * stopped; with status_host == NULL the call only enqueues (asynchronous).   */
 int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
                    int32_t* status_host, void* stream);
+/* ... of a fleet: perm_dev_of[i] = n_epochs * n_rows_of[i] row orders of
+ * network i.                                                                 */
+int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
+                         int32_t n_epochs, int32_t* status_host, void* stream);
 /* Wait for the launches enqueued by nb_trainer_run(..., status_host = NULL)
  * and read the per-network status (same encoding).                          */
 int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream);

@@ -78,6 +78,11 @@ _SIGNATURES = {
                                     C.POINTER(c_double_p),
                                     C.POINTER(c_double_p),
                                     C.POINTER(C.c_void_p)]),
+    'nb_trainer_create_fleet': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    'nb_trainer_run_fleet': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     'nb_trainer_set_hparams': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
                                          C.c_double, C.c_double, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_double]),

@@ -63,10 +63,23 @@ struct NetState {
   nb_gd* scal;    // [0] adam t  [1] best loss  [2] stale  [3] n_iter  [4] done
 };
 
-struct TrainArgs {
-  const NetState* nets;
+// the training set of one network and its shuffles for the epochs of a launch
+struct NetData {
   const nb_gd* X;       // (n, D) standardised inputs
   const nb_gd* y;       // (n)
+  const nb_gi* perm;    // (n_epochs, n)
+  long long n;
+  int batch;            // min(batch size, n)
+};
+
+constexpr int MAX_RESIDENT = 16;   // networks of one resident launch
+struct FleetData { NetData d[MAX_RESIDENT]; };
+
+struct TrainArgs {
+  const NetState* nets;
+  // two-launch form: all networks share one training set
+  const nb_gd* X;
+  const nb_gd* y;
   const nb_gi* perm;    // (E, n_epochs, n)
   const nb_gi* jobs;    // G phase: n_jobs records of G_JOB_INTS ints
   int n_jobs;
@@ -74,6 +87,14 @@ struct TrainArgs {
   int n_dim, kt1, n_epochs, max_iter, n_iter_no_change, batch;
   double tol, lr, b1, b2, eps;
 };
+
+__device__ __forceinline__ NetData shared_data(const TrainArgs& a, int net) {
+  NetData d;
+  d.X = a.X; d.y = a.y;
+  d.perm = a.perm + (long long)net * a.n_epochs * a.n;
+  d.n = a.n; d.batch = a.batch;
+  return d;
+}
 
 // ---------------------------------------------------------------------------
 // Step = FB then G (the two-launch form runs them as two kernels, the kernel
@@ -192,33 +213,31 @@ struct FbRows {
 // row index of this lane's point in the minibatch slice starting at `start`
 // of epoch `ep` (rows past the end of the slice read entry 0 and are masked
 // later)
-__device__ __forceinline__ int fb_row_index(const TrainArgs& a, int net,
-                                            int tile, int ep, long long start,
-                                            int nb) {
+__device__ __forceinline__ int fb_row_index(const NetData& nd, int tile,
+                                            int ep, long long start, int nb) {
   int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
-  const nb_gi* perm = a.perm + ((long long)net * a.n_epochs + ep) * a.n + start;
+  const nb_gi* perm = nd.perm + (long long)ep * nd.n + start;
   const int pt = tile * 16 + (lane & 15);
   return perm[pt < nb ? pt : 0];
 }
 
 template <int KT1>
-__device__ __forceinline__ void fb_gather(const TrainArgs& a, int tile, int nb,
-                                          int row, FbRows<KT1>& in) {
+__device__ __forceinline__ void fb_gather(const NetData& nd, int D, int tile,
+                                          int nb, int row, FbRows<KT1>& in) {
   int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int D = a.n_dim;
   const bool valid = tile * 16 + li < nb;
-  const nb_gd* xr = a.X + (long long)row * D;
+  const nb_gd* xr = nd.X + (long long)row * D;
 #pragma unroll
   for (int j = 0; j < KT1; ++j) {
     const int f = 4 * (4 * j + wave) + lg;
     const double v = xr[f < D ? f : D - 1];
     in.x[j] = (f < D) ? (valid ? v : 0.0) : ((f == D) ? 1.0 : 0.0);
   }
-  const double yv = a.y[row];
+  const double yv = nd.y[row];
   in.yv = (wave == 0 && lg == 0 && valid) ? yv : 0.0;
 }
 
@@ -517,8 +536,9 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
   __syncthreads();
   FbRows<KT1> rows;
-  fb_gather<KT1>(a, tile, nb,
-                 fb_row_index(a, (int)blockIdx.y, tile, ep, start, nb), rows);
+  const NetData nd = shared_data(a, (int)blockIdx.y);
+  fb_gather<KT1>(nd, a.n_dim, tile, nb, fb_row_index(nd, tile, ep, start, nb),
+                 rows);
   fb_body<KT1, true>(a, st, (int)blockIdx.y, tile, nb, rows, lds);
 }
 
@@ -726,10 +746,10 @@ nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
 // (sklearn/_multilayer_perceptron.py:730-760, 819-822); one thread
 __device__ __forceinline__ void epoch_body(const TrainArgs& a,
-                                           const NetState& st,
+                                           const NetState& st, long long n,
                                            long long t_adam) {
   if (ld_xcd(&st.scal[4]) != 0.0) return;
-  const double loss = ld_xcd(&st.scal[5]) / (double)a.n;
+  const double loss = ld_xcd(&st.scal[5]) / (double)n;
   int n_iter = (int)ld_xcd(&st.scal[3]);
   double best = ld_xcd(&st.scal[1]);
   int stale = (int)ld_xcd(&st.scal[2]);
@@ -747,7 +767,7 @@ __device__ __forceinline__ void epoch_body(const TrainArgs& a,
 
 __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
   const NetState st = a.nets[blockIdx.x];
-  if (threadIdx.x == 0) epoch_body(a, st, t_adam);
+  if (threadIdx.x == 0) epoch_body(a, st, a.n, t_adam);
 }
 
 // ---------------------------------------------------------------------------
@@ -764,9 +784,14 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 // (s_waitcnt) and a consumer to drop its CU's L1 (buffer_inv): no L2
 // write-back, and the barrier is one atomic in that L2.
 // ---------------------------------------------------------------------------
+#ifndef NB_POLL_SLEEP
+#define NB_POLL_SLEEP 16
+#endif
 constexpr int XCD_COUNT = 8;
 constexpr int XCD_SLOTS = 32;            // workgroups per network: one per CU
-constexpr int SYNC_WORDS = 4;            // counter, error, (unused), ticket
+constexpr int SYNC_WORDS = 4;            // per network: counter, error, -, -
+// (+ one ticket counter per XCD behind the MAX_RESIDENT network records)
+constexpr int SYNC_INTS = SYNC_WORDS * 16 + XCD_COUNT;
 constexpr int SYNC_LIMIT = 1 << 23;
 
 // (split into arrive / wait so that read-only prefetches can be issued in
@@ -795,7 +820,7 @@ __device__ __forceinline__ void xcd_wait(int* counter, int* err, int& phase,
     int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(NB_POLL_SLEEP);
       if (++spins > SYNC_LIMIT) {
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -811,9 +836,10 @@ __device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
   xcd_wait(counter, err, phase, n_wg);
 }
 
+// networks of the XCDs: up to two per XCD (two workgroups per CU), -1 = none
 struct XcdMap {
   int n_nets;
-  int net[XCD_COUNT];
+  int net[XCD_COUNT][2];
 };
 
 __global__ void nb_xcc_probe_kernel(int* out) {
@@ -840,7 +866,7 @@ __device__ const int g_stamp_order[19] = {0, 11, 12, 13, 14, 15, 16, 17,
 // pass while this one is resident)
 template <int KT1>
 __global__ void __launch_bounds__(256, 2)
-nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
+nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
   // own disjoint XCDs; map.net[x] = network of XCD x or -1
   // The workgroup asks the hardware which XCD it runs on and takes a ticket
@@ -856,29 +882,45 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
   const int n_nets = map.n_nets;
   unsigned xcc_id;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-  const int net = map.net[xcc_id & (XCD_COUNT - 1)];
-  if (net < 0 || net >= n_nets) return;
-  int* counter = sync + SYNC_WORDS * net;
-  int* err = counter + 1;
-  int* ticket = counter + 3;
+  const int xcd = xcc_id & (XCD_COUNT - 1);
+  if (map.net[xcd][0] < 0) return;
+  // One ticket counter per XCD.  An XCD with one network gives it all 32
+  // arrivals (a workgroup on every CU: the shortest step); an XCD with two
+  // networks gives each of them 16 -- on 16 CUs of their own, as long as the
+  // dispatcher spreads the 32 workgroups of the grid over the 32 CUs: sharing
+  // CUs was measured at twice the step time, i.e. no gain over training one
+  // network after the other, because the phases are bound by what a CU gets
+  // out of the L2 per clock.  (The CUs keep a free workgroup slot either way.)
+  int* ticket = sync + SYNC_WORDS * MAX_RESIDENT + xcd;
   if (threadIdx.x == 0) sh_slot = atomicAdd(ticket, 1);
   __syncthreads();
-  const int slot = __builtin_amdgcn_readfirstlane(sh_slot);
-  if (slot >= XCD_SLOTS) return;
+  const int arrival = __builtin_amdgcn_readfirstlane(sh_slot);
+  if (arrival >= XCD_SLOTS) return;
+  const bool two = map.net[xcd][1] >= 0;
+  const int slots = two ? XCD_SLOTS / 2 : XCD_SLOTS;
+  const int which = two ? arrival / slots : 0;
+  const int net = map.net[xcd][which];
+  if (net < 0 || net >= n_nets) return;
+  const int slot = arrival - which * slots;
+  int* counter = sync + SYNC_WORDS * net;
+  int* err = counter + 1;
   const NetState st = a.nets[net];
+  const NetData nd = fleet.d[net];
   // this workgroup's job of the G phase (the same in every step)
   const GJob my_job = g_job_record(a, slot < a.n_jobs ? slot : 0);
   int phase = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long n = a.n;
-  const int steps = (int)((n + a.batch - 1) / a.batch);
+  const long long n = nd.n;
+  const int batch = nd.batch;
+  const int steps = (int)((n + batch - 1) / batch);
   // the zero padding of the input block (rows >= D + 1 of the last k-tile are
   // multiplied by zero weights and must not hold NaN bit patterns); every
   // step rewrites exactly the rows it fills
   for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
-  xcd_barrier(counter, err, phase, XCD_SLOTS);
-  long long t_adam = t_adam0;
+  xcd_barrier(counter, err, phase, slots);
+  // the Adam step counter lives with the network (epoch_body keeps it)
+  long long t_adam = (long long)ld_xcd(&st.scal[0]);
   FbRows<KT1> rows;
   bool have_rows = false;        // rows = the slice of the step about to run
   int row_next = 0;              // ... and the row index of the step after it
@@ -890,8 +932,8 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
     // epoch_body, which is followed by a barrier
     const bool done = ld_xcd(&st.scal[4]) != 0.0;
     for (int sidx = 0; sidx < steps; ++sidx) {
-      const long long start = (long long)sidx * a.batch;
-      const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
+      const long long start = (long long)sidx * batch;
+      const int nb = (int)((n - start < batch) ? (n - start) : batch);
       t_adam += 1;
       if (done) continue;
 #ifdef NB_TRAIN_TIMING
@@ -914,17 +956,17 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       // the last step of an epoch)
       const bool last = sidx + 1 == steps;
       const int ep2 = last ? ep + 1 : ep;
-      const long long start2 = last ? 0 : start + a.batch;
-      const int nb2 = (int)((n - start2 < a.batch) ? (n - start2) : a.batch);
+      const long long start2 = last ? 0 : start + batch;
+      const int nb2 = (int)((n - start2 < batch) ? (n - start2) : batch);
       const bool next_rows = ep2 < a.n_epochs && slot * 16 < nb2;
       if (slot * 16 < nb) {
         if (!have_rows)
-          fb_gather<KT1>(a, slot, nb, fb_row_index(a, net, slot, ep, start, nb),
-                         rows);
+          fb_gather<KT1>(nd, a.n_dim, slot, nb,
+                         fb_row_index(nd, slot, ep, start, nb), rows);
         // its row indices are fetched now and consumed after the G phase,
         // where the rows themselves are fetched behind the barrier signal:
         // neither of the two dependent loads is waited for where it is issued
-        if (next_rows) row_next = fb_row_index(a, net, slot, ep2, start2, nb2);
+        if (next_rows) row_next = fb_row_index(nd, slot, ep2, start2, nb2);
         fb_body<KT1, false>(a, st, net, slot, nb, rows, lds);
       } else if (slot < G_ROWT) {
         fb_clear_deltas(st, 16 * KT1, slot);
@@ -933,41 +975,42 @@ nb_train_xcd_kernel(TrainArgs a, XcdMap map, long long t_adam0, int* sync) {
       // (the step size -- two pow() -- is computed while waiting)
       xcd_arrive(counter);
       const double lr_t = adam_lr(a, t_adam);
-      xcd_wait(counter, err, phase, XCD_SLOTS);
+      xcd_wait(counter, err, phase, slots);
       TR_STAMP(2);
       // jobs slot, slot + 32, ... of the G phase (all 32 CUs of the XCD take
       // part, also the ones without a row tile in FB; the host's job list
       // fits one round); the last workgroup folds the loss
-      if (slot == XCD_SLOTS - 1 && wave == 3) loss_fold(st, nb, lane);
+      if (slot == slots - 1 && wave == 3) loss_fold(st, nb, lane);
       // the rows of the next step (read-only data) are fetched behind the
       // operand loads of this phase: in flight under its MFMA chains, back
       // long before the barrier
       have_rows = next_rows && slot * 16 < nb;
       {
         bool fetched = false;
-        for (int job = slot; job < a.n_jobs; job += XCD_SLOTS) {
+        for (int job = slot; job < a.n_jobs; job += slots) {
           g_job(a, st, job == slot ? my_job : g_job_record(a, job), nb, lr_t,
                 lds + FbLds<KT1>::G_RED,
                 [&]() __attribute__((always_inline)) {
                   if (have_rows && !fetched)
-                    fb_gather<KT1>(a, slot, nb2, row_next, rows);
+                    fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
                   fetched = true;
                 },
                 net == 0 && slot == 0);
-          if (job + XCD_SLOTS < a.n_jobs) lds_barrier();   // red is reused
+          if (job + slots < a.n_jobs) lds_barrier();   // red is reused
         }
-        if (have_rows && !fetched) fb_gather<KT1>(a, slot, nb2, row_next, rows);
+        if (have_rows && !fetched)
+          fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
       }
       TR_STAMP(3);
-      xcd_barrier(counter, err, phase, XCD_SLOTS);
+      xcd_barrier(counter, err, phase, slots);
       TR_STAMP(4);
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
         return;
     }
     if (done) continue;
-    if (slot == 0 && threadIdx.x == 0) epoch_body(a, st, t_adam);
-    xcd_barrier(counter, err, phase, XCD_SLOTS);
+    if (slot == 0 && threadIdx.x == 0) epoch_body(a, st, n, t_adam);
+    xcd_barrier(counter, err, phase, slots);
   }
 }
 
@@ -1035,8 +1078,13 @@ struct nb_trainer {
   int n_dim = 0, E = 0, kt1 = 0, dt = 0;
   long long n = 0;
   long long n_w = 0;
-  const double* X = nullptr;
+  const double* X = nullptr;       // network 0's set (all networks', if shared)
   const double* y = nullptr;
+  // per network: training set and rows (a fleet: the networks of several
+  // ensembles, each with the set of its ensemble)
+  std::vector<const double*> Xs, ys;
+  std::vector<long long> ns;
+  bool shared_set = true;
   std::vector<NetState> nets_host;
   NetState* nets_dev = nullptr;
   double* pool = nullptr;          // one allocation for all per-net buffers
@@ -1053,20 +1101,59 @@ struct nb_trainer {
 
 extern "C" {
 
+int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
+                            const int64_t* n_rows_of,
+                            const double* const* x_dev_of,
+                            const double* const* y_dev_of,
+                            const double* const* coefs,
+                            const double* const* icpts, nb_trainer** out);
+
 int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
                       const double* x_dev, const double* y_dev,
                       const double* const* coefs, const double* const* icpts,
                       nb_trainer** out) {
-  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT || n_networks < 1 || n_rows < 1) {
-    nb_set_error("bad trainer shape (n_dim=%d, n_networks=%d, n_rows=%lld)",
-                 n_dim, n_networks, (long long)n_rows);
+  if (n_networks < 1) {
+    nb_set_error("bad trainer shape (n_networks=%d)", n_networks);
     return NB_ERR_ARG;
   }
+  std::vector<int64_t> ns((size_t)n_networks, n_rows);
+  std::vector<const double*> xs((size_t)n_networks, x_dev),
+      ys((size_t)n_networks, y_dev);
+  return nb_trainer_create_fleet(n_dim, n_networks, ns.data(), xs.data(),
+                                 ys.data(), coefs, icpts, out);
+}
+
+int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
+                            const int64_t* n_rows_of,
+                            const double* const* x_dev_of,
+                            const double* const* y_dev_of,
+                            const double* const* coefs,
+                            const double* const* icpts, nb_trainer** out) {
+  if (n_dim < 1 || n_dim > 16 * NB_MAX_DT || n_networks < 1) {
+    nb_set_error("bad trainer shape (n_dim=%d, n_networks=%d)", n_dim,
+                 n_networks);
+    return NB_ERR_ARG;
+  }
+  for (int i = 0; i < n_networks; ++i)
+    if (n_rows_of[i] < 1) {
+      nb_set_error("bad trainer shape (network %d has %lld rows)", i,
+                   (long long)n_rows_of[i]);
+      return NB_ERR_ARG;
+    }
+  const int64_t n_rows = n_rows_of[0];
+  const double* x_dev = x_dev_of[0];
+  const double* y_dev = y_dev_of[0];
   nb_trainer* t = new nb_trainer();
   t->n_dim = n_dim; t->E = n_networks; t->n = n_rows;
   t->dt = (n_dim + 15) / 16;
   t->kt1 = (n_dim + 1 + 15) / 16;
   t->X = x_dev; t->y = y_dev;
+  for (int i = 0; i < n_networks; ++i) {
+    t->Xs.push_back(x_dev_of[i]); t->ys.push_back(y_dev_of[i]);
+    t->ns.push_back(n_rows_of[i]);
+    if (x_dev_of[i] != x_dev || y_dev_of[i] != y_dev || n_rows_of[i] != n_rows)
+      t->shared_set = false;
+  }
   t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
   const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
   const long long curve = t->max_iter;
@@ -1077,8 +1164,7 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
   if (e == hipSuccess)
     e = hipMalloc((void**)&t->nets_dev, n_networks * sizeof(NetState));
   if (e == hipSuccess)
-    e = hipMalloc((void**)&t->sync_dev,
-                  SYNC_WORDS * XCD_COUNT * sizeof(int));
+    e = hipMalloc((void**)&t->sync_dev, SYNC_INTS * sizeof(int));
   {
     const std::vector<int> jobs = g_jobs(t->kt1);
     t->n_jobs = (int)jobs.size() / G_JOB_INTS;
@@ -1088,28 +1174,43 @@ int nb_trainer_create(int32_t n_dim, int32_t n_networks, int64_t n_rows,
       e = hipMemcpy(t->jobs_dev, jobs.data(), jobs.size() * sizeof(int),
                     hipMemcpyHostToDevice);
   }
-  t->two_launch = n_networks > XCD_COUNT ||
+  t->two_launch = n_networks > MAX_RESIDENT ||
                   getenv("NB_TRAIN_TWO_LAUNCH") != nullptr ||
                   !xcd_pinning_available();
-  // A resident workgroup takes a whole CU; two resident kernels competing for
-  // the CUs of one XCD could each end up partially dispatched and wait for
-  // each other.  So every trainer owns its XCDs exclusively; a trainer that
-  // finds too few free ones trains with two launches per step instead.
+  // A resident network takes one workgroup slot on every CU of an XCD (of two
+  // per CU).  Every trainer owns its XCDs exclusively -- two resident kernels
+  // that each hold a part of an XCD could wait for each other -- and puts
+  // one network on each while they last, two beyond that (16 networks on the
+  // 8 XCDs); a trainer that finds too few free XCDs trains with two launches
+  // per step instead.
   t->xcd_map.n_nets = n_networks;
-  for (int x = 0; x < XCD_COUNT; ++x) t->xcd_map.net[x] = -1;
+  for (int x = 0; x < XCD_COUNT; ++x)
+    t->xcd_map.net[x][0] = t->xcd_map.net[x][1] = -1;
   if (!t->two_launch) {
-    int assigned = 0;
-    for (int x = 0; x < XCD_COUNT && assigned < n_networks; ++x)
-      if (!(g_xcd_in_use & (1u << x))) {
-        t->xcd_map.net[x] = assigned++;
-        t->xcd_owned |= 1u << x;
-      }
-    if (assigned < n_networks) {
-      t->xcd_owned = 0;
+    int n_free = 0;
+    for (int x = 0; x < XCD_COUNT; ++x)
+      if (!(g_xcd_in_use & (1u << x))) ++n_free;
+    if (n_networks > 2 * n_free) {
       t->two_launch = true;
     } else {
+      // as many XCDs as there are networks (up to the free ones), the
+      // networks dealt out round-robin
+      const int n_use = n_networks < n_free ? n_networks : n_free;
+      int xs_used[XCD_COUNT], k = 0;
+      for (int x = 0; x < XCD_COUNT && k < n_use; ++x)
+        if (!(g_xcd_in_use & (1u << x))) xs_used[k++] = x;
+      for (int i = 0; i < n_networks; ++i)
+        t->xcd_map.net[xs_used[i % n_use]][i / n_use] = i;
+      for (int j = 0; j < n_use; ++j) t->xcd_owned |= 1u << xs_used[j];
       g_xcd_in_use |= t->xcd_owned;
     }
+  }
+  if (t->two_launch && !t->shared_set) {
+    nb_set_error("a trainer whose networks have different training sets "
+                 "needs the resident kernel (at most %d networks, free XCDs, "
+                 "NB_TRAIN_TWO_LAUNCH unset)", MAX_RESIDENT);
+    nb_trainer_destroy(t);
+    return NB_ERR_UNSUPPORTED;
   }
   if (getenv("NB_TRAIN_DEBUG") != nullptr)
     fprintf(stderr, "[trainer] nets=%d n=%lld two_launch=%d owned=%02x in_use=%02x\n",
@@ -1196,30 +1297,55 @@ int nb_trainer_set_hparams(nb_trainer* t, double lr, double beta1,
   return NB_OK;
 }
 
+int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
+                         int32_t n_epochs, int32_t* status_host, void* stream);
+
 int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
                    int32_t* status_host, void* stream) {
+  if (!t->shared_set) {
+    nb_set_error("nb_trainer_run: the networks have different training sets; "
+                 "use nb_trainer_run_fleet");
+    return NB_ERR_ARG;
+  }
+  std::vector<const int32_t*> perms((size_t)t->E);
+  for (int i = 0; i < t->E; ++i)
+    perms[i] = perm_dev + (size_t)i * n_epochs * t->n;
+  return nb_trainer_run_fleet(t, perms.data(), n_epochs, status_host, stream);
+}
+
+int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
+                         int32_t n_epochs, int32_t* status_host,
+                         void* stream) {
   hipStream_t s = (hipStream_t)stream;
   TrainArgs a;
   a.nets = t->nets_dev; a.X = (const nb_gd*)t->X; a.y = (const nb_gd*)t->y;
-  a.perm = (const nb_gi*)perm_dev;
+  a.perm = (const nb_gi*)perm_dev_of[0];
   a.jobs = (const nb_gi*)t->jobs_dev; a.n_jobs = t->n_jobs;
   a.n = t->n; a.n_dim = t->n_dim; a.kt1 = t->kt1; a.n_epochs = n_epochs;
   a.max_iter = t->max_iter; a.n_iter_no_change = t->n_iter_no_change;
   a.batch = (int)((t->n < t->batch) ? t->n : t->batch);
   a.tol = t->tol; a.lr = t->lr; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps;
-  // Adam step counter continues across calls (host mirror of scal[0])
   const long long n = t->n;
   const int steps_per_epoch = (int)((n + a.batch - 1) / a.batch);
-  const int n_gt = nb_net_tiles(t->kt1);
   if (!t->two_launch) {
-    NB_HIP_CHECK(hipMemsetAsync(t->sync_dev, 0,
-                                SYNC_WORDS * XCD_COUNT * sizeof(int), s));
+    FleetData fleet;
+    for (int i = 0; i < MAX_RESIDENT; ++i) {
+      const int k = i < t->E ? i : 0;
+      fleet.d[i].X = (const nb_gd*)t->Xs[k];
+      fleet.d[i].y = (const nb_gd*)t->ys[k];
+      fleet.d[i].perm = (const nb_gi*)perm_dev_of[k];
+      fleet.d[i].n = t->ns[k];
+      fleet.d[i].batch = (int)((t->ns[k] < t->batch) ? t->ns[k] : t->batch);
+    }
+    NB_HIP_CHECK(hipMemsetAsync(t->sync_dev, 0, SYNC_INTS * sizeof(int), s));
+    // 32 workgroups per XCD: all of them for its network, or 16 for each of
+    // its two
     const dim3 grid(XCD_COUNT * XCD_SLOTS), blk(256);
     switch (t->kt1) {
 #define NB_CASE(KT1_)                                                      \
       case KT1_:                                                           \
         hipLaunchKernelGGL(nb_train_xcd_kernel<KT1_>, grid, blk, 0, s, a,  \
-                           t->xcd_map, t->t_adam, t->sync_dev);            \
+                           fleet, t->xcd_map, t->sync_dev);                \
         break;
       NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
       NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
@@ -1232,6 +1358,13 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
       return nb_trainer_status(t, status_host, stream);
     return NB_OK;
   }
+  // two launches per step: one training set, contiguous shuffles
+  for (int i = 1; i < t->E; ++i)
+    if (perm_dev_of[i] != perm_dev_of[0] + (size_t)i * n_epochs * t->n) {
+      nb_set_error("two-launch training needs the shuffles of all networks "
+                   "in one (E, n_epochs, n) array");
+      return NB_ERR_ARG;
+    }
   for (int ep = 0; ep < n_epochs; ++ep) {
     for (int sidx = 0; sidx < steps_per_epoch; ++sidx) {
       const long long start = (long long)sidx * a.batch;
@@ -1264,7 +1397,7 @@ int nb_trainer_run(nb_trainer* t, const int32_t* perm_dev, int32_t n_epochs,
 int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream) {
   NB_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   if (!t->two_launch) {
-    int sync[SYNC_WORDS * XCD_COUNT];
+    int sync[SYNC_INTS];
     NB_HIP_CHECK(hipMemcpy(sync, t->sync_dev, sizeof sync,
                            hipMemcpyDeviceToHost));
     for (int i = 0; i < t->E; ++i)

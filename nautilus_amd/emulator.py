@@ -66,16 +66,30 @@ class Trainer:
     """Thin object wrapper of the ``nb_trainer_*`` C ABI."""
 
     def __init__(self, x_dev, y_dev, init_nets, hparams=None):
+        """``x_dev`` / ``y_dev``: one training set for all networks, or lists
+        with the set of every network (a fleet: the networks of several
+        ensembles in one trainer, ``nb_trainer_create_fleet``)."""
         lib = _lib.load()
         self._lib = lib
-        self.x, self.y = x_dev, y_dev        # keep device buffers alive
-        self.n, self.n_dim = x_dev.shape
         self.e = len(init_nets)
+        fleet = isinstance(x_dev, (list, tuple))
+        self.xs = list(x_dev) if fleet else [x_dev] * self.e
+        self.ys = list(y_dev) if fleet else [y_dev] * self.e   # kept alive
+        self.ns = [int(x.shape[0]) for x in self.xs]
+        self.n, self.n_dim = self.xs[0].shape
         cp, ip, keep = _weight_pointers(init_nets)
         h = C.c_void_p()
-        _lib.check(lib.nb_trainer_create(
-            self.n_dim, self.e, self.n, C.c_void_p(x_dev.data_ptr()),
-            C.c_void_p(y_dev.data_ptr()), cp, ip, C.byref(h)))
+        if fleet:
+            ns = (C.c_int64 * self.e)(*self.ns)
+            xp = (C.c_void_p * self.e)(*[x.data_ptr() for x in self.xs])
+            yp = (C.c_void_p * self.e)(*[y.data_ptr() for y in self.ys])
+            _lib.check(lib.nb_trainer_create_fleet(
+                self.n_dim, self.e, ns, xp, yp, cp, ip, C.byref(h)))
+        else:
+            _lib.check(lib.nb_trainer_create(
+                self.n_dim, self.e, self.n, C.c_void_p(x_dev.data_ptr()),
+                C.c_void_p(y_dev.data_ptr()), cp, ip, C.byref(h)))
+        self.fleet = fleet
         self._h = h
         if hparams:
             hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, epsilon=1e-8,
@@ -87,15 +101,29 @@ class Trainer:
                 hp['tol']))
 
     def run(self, perms, sync=True):
-        """perms: int32 array (E, n_epochs, n).  Returns per-network status
-        (n_iter, negative once stopped) if sync else None."""
-        perms_dev = torch.from_numpy(
-            np.ascontiguousarray(perms, dtype=np.int32)).cuda()
+        """perms: int32 array (E, n_epochs, n), or for a fleet a list of
+        (n_epochs, n_i) arrays.  Returns per-network status (n_iter, negative
+        once stopped) if sync else None."""
         status = (C.c_int32 * self.e)()
-        _lib.check(self._lib.nb_trainer_run(
-            self._h, C.c_void_p(perms_dev.data_ptr()), perms.shape[1],
-            status if sync else None,
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.fleet:
+            # one upload: the shuffles of all networks back to back
+            n_epochs = perms[0].shape[0]
+            flat = np.concatenate([np.ascontiguousarray(
+                p, dtype=np.int32).reshape(-1) for p in perms])
+            perms_dev = torch.from_numpy(flat).cuda()
+            offs = np.concatenate([[0], np.cumsum(
+                [p.size for p in perms])[:-1]])
+            ptrs = (C.c_void_p * self.e)(*[
+                perms_dev.data_ptr() + 4 * int(o) for o in offs])
+            _lib.check(self._lib.nb_trainer_run_fleet(
+                self._h, ptrs, n_epochs, status if sync else None, stream))
+        else:
+            perms_dev = torch.from_numpy(
+                np.ascontiguousarray(perms, dtype=np.int32)).cuda()
+            _lib.check(self._lib.nb_trainer_run(
+                self._h, C.c_void_p(perms_dev.data_ptr()), perms.shape[1],
+                status if sync else None, stream))
         self._perms = getattr(self, '_perms', [])[-1:] + [perms_dev]
         return np.array(status[:]) if sync else None
 
@@ -243,25 +271,39 @@ class NeuralNetworkEmulator:
 
 
 class _TrainJob:
-    """One ensemble in flight: its trainer, the per-network shuffle streams
-    and the bookkeeping of the chunked epoch loop."""
+    """Networks in flight -- one ensemble, or a fleet of several ensembles
+    with a training set each -- : the trainer, the per-network shuffle
+    streams and the bookkeeping of the chunked epoch loop."""
 
-    def __init__(self, xs, y, seeds, hparams, permutations, init, max_epochs,
-                 stream):
-        self.n, d = xs.shape
-        self.e = len(seeds)
+    def __init__(self, members, hparams, max_epochs, stream):
+        """``members``: list of dicts (xs, y, seeds, permutations, init), one
+        per ensemble."""
+        self.members = members
         self.stream = stream
-        self.states = [np.random.RandomState(s) for s in seeds]
-        nets0 = [_glorot(d, rs) for rs in self.states]
-        if init is not None:
-            nets0 = init
+        d = members[0]['xs'].shape[1]
+        self.owner, self.states, self.perm_src = [], [], []
+        xs, ys, nets0 = [], [], []
+        for k, m in enumerate(members):
+            for j, seed in enumerate(m['seeds']):
+                rs = np.random.RandomState(seed)
+                init = m.get('init')
+                nets0.append(_glorot(d, rs) if init is None else init[j])
+                self.owner.append(k)
+                self.states.append(rs)
+                perms = m.get('permutations')
+                self.perm_src.append(None if perms is None else perms[j])
+                xs.append(m['xs'])
+                ys.append(m['y'])
+        self.e = len(self.owner)
+        self.ns = [int(x.shape[0]) for x in xs]
+        self.fleet = len(members) > 1
         with torch.cuda.stream(stream):
-            self.trainer = Trainer(xs, y, nets0, hparams)
-        self.permutations = permutations
+            self.trainer = (Trainer(xs, ys, nets0, hparams) if self.fleet
+                            else Trainer(xs[0], ys[0], nets0, hparams))
         self.max_iter = (hparams or {}).get('max_iter', 10000)
         if max_epochs is not None:
             self.max_iter = min(self.max_iter, max_epochs)
-        self.orders = [np.arange(self.n) for _ in range(self.e)]
+        self.orders = [np.arange(n) for n in self.ns]
         self.status = np.zeros(self.e, dtype=int)
         self.done_epochs = 0
         self.in_flight = False
@@ -273,25 +315,27 @@ class _TrainJob:
         chunk = min(EPOCH_CHUNK, self.max_iter - self.done_epochs)
         if chunk <= 0:
             return None
-        n, e = self.n, self.e
-        perms = np.zeros((e, chunk, n), dtype=np.int32)
-        for i in range(e):
+        out = []
+        for i in range(self.e):
+            n = self.ns[i]
+            perms = np.zeros((chunk, n), dtype=np.int32)
             for ep in range(chunk):
-                if self.permutations is not None:
+                if self.perm_src[i] is not None:
                     self.orders[i] = np.asarray(
-                        self.permutations[i][self.done_epochs + ep])
+                        self.perm_src[i][self.done_epochs + ep])
                 elif self.status[i] >= 0:
                     # sklearn.utils.shuffle: permutations compose
                     # (_multilayer_perceptron.py:700-704)
                     idx = np.arange(n)
                     self.states[i].shuffle(idx)
                     self.orders[i] = self.orders[i][idx]
-                perms[i, ep] = self.orders[i]
-        return perms
+                perms[ep] = self.orders[i]
+            out.append(perms)
+        return out if self.fleet else np.stack(out)
 
     def step(self):
         """Prepare the next chunk, collect the status of the chunk in flight,
-        enqueue the next one.  Returns False once the ensemble is done."""
+        enqueue the next one.  Returns False once all networks are done."""
         if self.finished:
             return False
         perms = self.next_chunk()
@@ -304,70 +348,90 @@ class _TrainJob:
                 return False
             self.trainer.run(perms, sync=False)
         self.in_flight = True
-        self.done_epochs += perms.shape[1]
+        self.done_epochs += perms[0].shape[0] if self.fleet \
+            else perms.shape[1]
         return True
 
     def release(self):
         """Destroy the trainer (frees its XCDs and device buffers)."""
         self.trainer.close()
 
-    def result(self):
-        networks = []
+    def results(self):
+        """One (networks, stats) pair per ensemble."""
+        out = [([], dict(n_iter=[], n_rows=int(m['xs'].shape[0])))
+               for m in self.members]
         with torch.cuda.stream(self.stream):
             for i in range(self.e):
                 n_iter = abs(int(self.status[i]))
                 coefs, intercepts = self.trainer.weights(i)
-                networks.append(Network(coefs, intercepts, n_iter,
-                                        self.trainer.loss_curve(i, n_iter)))
+                net = Network(coefs, intercepts, n_iter,
+                              self.trainer.loss_curve(i, n_iter))
                 # scikit-learn's sample counter (_multilayer_perceptron.py:728)
-                networks[-1].t_ = n_iter * self.n
-        stats = dict(n_iter=[abs(int(s)) for s in self.status], n_rows=self.n)
-        return networks, stats
+                net.t_ = n_iter * self.ns[i]
+                nets, stats = out[self.owner[i]]
+                nets.append(net)
+                stats['n_iter'].append(n_iter)
+        return out
 
 
-N_XCD = 8            # one XCD per network of a resident trainer
+MAX_RESIDENT = 16    # networks of one resident launch (two per XCD)
 
 
 def train_ensembles(jobs):
     """Train several ensembles (the neural bounds of a multi-modal
-    NautilusBound), as many at a time as the GPU has XCDs for: the resident
-    training kernel gives every network an XCD of its own -- all 32 CUs --
-    so two ensembles of four networks train side by side and the others take
-    their turn as XCDs come free.  (An ensemble that starts while all XCDs are
-    taken would fall back to two launches per Adam step next to the resident
-    kernels: measured 80-120 us per step instead of 18.)  One HIP stream per
-    ensemble.  ``jobs``: list of dicts with keys xs, y, seeds and optionally
-    hparams, permutations, init, max_epochs."""
+    NautilusBound).  The resident training kernel takes up to 16 networks per
+    launch -- every network on the 32 CUs of an XCD, two networks per XCD
+    beyond eight -- each with the training set of its ensemble, so the
+    ensembles are packed into fleets of at most 16 networks and the fleets
+    train one after the other.  (Separate trainers side by side would leave
+    all but the first two ensembles with two launches per Adam step next to
+    the resident kernels: measured 80-120 us per step instead of 18.)  With
+    NB_TRAIN_TWO_LAUNCH set (several processes on one GPU) every ensemble
+    gets a trainer and a stream of its own.  ``jobs``: list of dicts with
+    keys xs, y, seeds and optionally hparams, permutations, init,
+    max_epochs."""
+    import os
     main = torch.cuda.current_stream()
-    waiting = list(enumerate(jobs))
-    running, out = [], [None] * len(jobs)
-    free = N_XCD
-    while waiting or running:
-        while waiting:
-            k, job = waiting[0]
-            need = len(job['seeds'])
-            # (more networks than XCDs: the trainer uses two launches per
-            # step anyway; let it run alone)
-            if need > free and (running or need <= N_XCD):
-                break
-            waiting.pop(0)
+    out = [None] * len(jobs)
+    if len(jobs) == 0:
+        return out
+
+    def finish(job, keys):
+        while job.step():
+            pass
+        for k, res in zip(keys, job.results()):
+            out[k] = res
+        main.wait_stream(job.stream)
+        job.release()
+
+    same = all((j.get('hparams') or {}) == (jobs[0].get('hparams') or {}) and
+               j.get('max_epochs') == jobs[0].get('max_epochs') for j in jobs)
+    if os.environ.get('NB_TRAIN_TWO_LAUNCH') or not same:
+        running = []
+        for k, job in enumerate(jobs):
             stream = main if len(jobs) == 1 else torch.cuda.Stream()
             stream.wait_stream(main)
-            free -= min(need, N_XCD)
-            running.append((k, min(need, N_XCD), _TrainJob(
-                job['xs'], job['y'], job['seeds'], job.get('hparams'),
-                job.get('permutations'), job.get('init'),
-                job.get('max_epochs'), stream)))
-        still = []
-        for k, need, j in running:
-            if j.step():
-                still.append((k, need, j))
-            else:
-                out[k] = j.result()
-                main.wait_stream(j.stream)
-                j.release()                  # its XCDs are free again
-                free += need
-        running = still
+            running.append((k, _TrainJob([job], job.get('hparams'),
+                                         job.get('max_epochs'), stream)))
+        active = list(running)
+        while active:
+            active = [(k, j) for k, j in active if j.step()]
+        for k, j in running:
+            finish(j, [k])
+        return out
+    # fleets of at most MAX_RESIDENT networks, ensembles in order
+    fleets, cur, size = [], [], 0
+    for k, job in enumerate(jobs):
+        e = len(job['seeds'])
+        if cur and size + e > MAX_RESIDENT:
+            fleets.append(cur)
+            cur, size = [], 0
+        cur.append(k)
+        size += e
+    fleets.append(cur)
+    for keys in fleets:
+        finish(_TrainJob([jobs[k] for k in keys], jobs[0].get('hparams'),
+                         jobs[0].get('max_epochs'), main), keys)
     return out
 
 

@@ -33,6 +33,29 @@ def main():
     from nautilus_amd.parallel import ShardedComm
     comm = ShardedComm()
     d = 4
+    # the construction of a bound, sharded (networks dealt out over the ranks,
+    # weights exchanged) against the same construction on this rank alone:
+    # identical parameters, bit for bit (neural.py:93-96)
+    from nautilus_amd.bounds import NautilusBound
+    rng = np.random.default_rng(5)
+    cloud = 0.5 + 0.12 * rng.normal(size=(1200, d))
+    cloud_l = -np.sum((cloud - 0.5)**2, axis=1)
+
+    def build(c):
+        return NautilusBound.compute(
+            cloud, cloud_l, np.median(cloud_l), np.log(0.05), n_networks=2,
+            rng=np.random.default_rng(9), comm=c)
+    sharded, alone = build(comm), build(None)
+
+    def params(b):
+        out = []
+        for nb in b.neural_bounds:
+            out += [nb.outer_bound.c, nb.outer_bound.B, [nb.score_predict_min]]
+            for net in nb.emulator.neural_networks:
+                out += [np.ravel(w) for w in net.coefs_ + net.intercepts_]
+        return np.concatenate([np.ravel(np.asarray(v, float)) for v in out])
+    construction_identical = bool(np.array_equal(params(sharded),
+                                                 params(alone)))
     if args.host_likelihood:
         prior, like = (lambda u: u), host_like
     else:
@@ -58,7 +81,8 @@ def main():
             n_bounds=len(s.bounds),
             shell_n_sample=[int(v) for v in s.shell_n_sample],
             shell_n=[int(v) for v in s.shell_n],
-            n_networks=len(nets))), flush=True)
+            n_networks=len(nets),
+            construction_identical=construction_identical)), flush=True)
     comm.barrier()
     dist.destroy_process_group()
 

@@ -276,6 +276,9 @@ def test_whole_run_sharded_over_two_ranks(extra):
     one = _run_sharded(1, *extra)
     two = _run_sharded(2, *extra)
     assert one['ok'] and two['ok'] and two['world'] == 2
+    # a bound built with its networks dealt out over the ranks has the
+    # parameters of the same bound built on one rank, bit for bit
+    assert one['construction_identical'] and two['construction_identical']
     for res in (one, two):
         assert abs(res['log_z']) < 0.05          # analytic log Z = 0
         assert res['n_eff'] >= 3000
