@@ -280,13 +280,14 @@ def cpu_baseline(sampler, like_numpy, seconds, cores):
     return out
 
 
-def pmc_traffic(argv, kernel_substr):
-    """HBM bytes per launch of the kernels whose name contains
-    ``kernel_substr`` over the timed region of this very command: two child
+def pmc_traffic(argv):
+    """HBM bytes of the bound-evaluation kernels (nb_eval_fast_kernel,
+    nb_geom_kernel) over the timed region of this very command: two child
     runs under ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE need separate
     passes on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"; FETCH_SIZE
-    counts 64 B per 128-B request of wide loads -> x 2).  Returns a dict or
-    None if the profiler is unavailable."""
+    counts 64 B per 128-B request of wide loads -> x 2).  The timed region's
+    dispatches are the last ``roofline.kernel_dispatches`` of each kernel in
+    the child run.  Returns a dict or None if the profiler is unavailable."""
     import csv
     import glob
     import shutil
@@ -295,11 +296,9 @@ def pmc_traffic(argv, kernel_substr):
     if shutil.which('rocprofv3') is None:
         return None
     totals = {}
+    calls = None
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         tmp = tempfile.mkdtemp(prefix='nb_pmc_', dir='/tmp')
-        # counters in their own passes with the kernel trace only (the guide's
-        # recipe); the timed region's launches are the LAST `roofline.launches`
-        # dispatches of the kernel in the child run
         cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace',
                '--output-format', 'csv', '-d', tmp, '-o', 'pmc', '--',
                sys.executable, os.path.abspath(__file__)] + [
@@ -312,7 +311,8 @@ def pmc_traffic(argv, kernel_substr):
                                    text=True)
             line = [ln for ln in child.stdout.splitlines()
                     if ln.startswith('{"metric"')][-1]
-            n_timed = int(json.loads(line)['roofline']['launches'])
+            roof = json.loads(line)['roofline']
+            n_timed, calls = roof['kernel_dispatches'], roof['launches']
         except Exception:
             shutil.rmtree(tmp, ignore_errors=True)
             return None
@@ -322,23 +322,25 @@ def pmc_traffic(argv, kernel_substr):
                               recursive=True):
             with open(path) as fh:
                 rows += [r for r in csv.DictReader(fh)
-                         if kernel_substr in r.get('Kernel_Name', '') and
-                         r.get('Counter_Name') == counter]
+                         if r.get('Counter_Name') == counter]
         shutil.rmtree(tmp, ignore_errors=True)
-        rows.sort(key=lambda r: int(r['Dispatch_Id']))
-        vals = [float(r['Counter_Value']) for r in rows[-n_timed:]]
-        if not vals:
-            return None
+        total = 0.0
+        for name, count in n_timed.items():
+            mine = sorted((r for r in rows if name in r.get('Kernel_Name', '')),
+                          key=lambda r: int(r['Dispatch_Id']))
+            if count > len(mine):
+                return None
+            total += sum(float(r['Counter_Value']) for r in mine[-count:]) \
+                if count else 0.0
         # FETCH_SIZE / WRITE_SIZE are reported in kilobytes; FETCH_SIZE
         # tallies the 128-B requests of wide loads at 64 B on gfx950 (x 2)
-        totals[counter] = (sum(vals) * 1024.0 *
-                           (2.0 if counter == 'FETCH_SIZE' else 1.0),
-                           len(vals))
-    fetch, n_f = totals['FETCH_SIZE']
-    write, n_w = totals['WRITE_SIZE']
-    return dict(bytes_per_launch=fetch / n_f + write / n_w,
-                read_bytes_per_launch=fetch / n_f,
-                write_bytes_per_launch=write / n_w, launches=n_f)
+        totals[counter] = total * 1024.0 * (2.0 if counter == 'FETCH_SIZE'
+                                            else 1.0)
+    return dict(bytes_per_launch=(totals['FETCH_SIZE'] +
+                                  totals['WRITE_SIZE']) / max(1, calls),
+                read_bytes_per_launch=totals['FETCH_SIZE'] / max(1, calls),
+                write_bytes_per_launch=totals['WRITE_SIZE'] / max(1, calls),
+                launches=calls)
 
 
 def roctx_region(resume):
@@ -448,6 +450,7 @@ def main():
     n_eff0, n_like0, prop0 = sampler.n_eff, sampler.n_like, proposals()
     roctx_region(True)
     mallocs0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
+    disp0 = dict(device.DISPATCHES)
     with device.EvalCounters() as counters, device.KernelTimer() as ktimer:
         t0 = time.time()
         for _ in range(args.steps):
@@ -462,6 +465,7 @@ def main():
     n_eff1, n_like1, prop1 = sampler.n_eff, sampler.n_like, proposals()
     kernels = ktimer.totals()
     work = counters.read()
+    dispatches = {k: device.DISPATCHES[k] - disp0[k] for k in disp0}
 
     # ---- roofline of the dominant kernel ----------------------------------
     dominant = max(kernels, key=lambda k: kernels[k]['ms'])
@@ -480,7 +484,7 @@ def main():
                                   '--pmc-traffic); committed measurements: '
                                   'profiles/r02/')
     if args.pmc_traffic and rank == 0 and world == 1:
-        got = pmc_traffic(sys.argv[1:], 'nb_eval_fast')
+        got = pmc_traffic(sys.argv[1:])
         if got is not None:
             traffic = got['bytes_per_launch']
             traffic_src = ('rocprofv3 --pmc child passes of this command: '
@@ -500,7 +504,7 @@ def main():
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
         frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=traffic,
         traffic_unit='bytes/launch', traffic_source=traffic_src,
-        launches=ev['launches'],
+        launches=ev['launches'], kernel_dispatches=dispatches,
         avg_launch_ms=ev['ms'] / max(1, ev['launches']),
         algorithmic_flops_per_launch=flops / max(1, ev['launches']),
         # every proposal is read once (8 D bytes) and flagged (1 byte);

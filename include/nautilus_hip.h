@@ -364,6 +364,9 @@ int nb_loglike_funnel(const double* u_dev, int64_t n, int32_t n_dim, double mu,
                       double sigma0, double k, double c, double* out_dev,
                       void* stream);
 
+/* Debugging aid: print the native backtrace on SIGABRT / SIGSEGV.           */
+int nb_debug_install_abort_trace(void);
+
 /* Two-stage evaluation of bounds with several outer members, several neural
  * bounds, or of lists of bounds (bounds/union.py:285-289, 316-319;
  * bounds/nautilus.py:162-169, 212-222; sampler.py:797-798, 1213-1219).

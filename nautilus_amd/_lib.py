@@ -154,6 +154,7 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     'nb_comm_allreduce_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
+    'nb_debug_install_abort_trace': (C.c_int, []),
     'nb_geom_list': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
@@ -198,6 +199,8 @@ def load():
         fn.argtypes = args
     if lib.nb_abi_version() != 3:
         raise RuntimeError('nautilus_amd: ABI version mismatch')
+    if os.environ.get('NB_ABORT_TRACE'):
+        lib.nb_debug_install_abort_trace()
     _lib = lib
     return lib
 

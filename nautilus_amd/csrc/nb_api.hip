@@ -7,8 +7,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <csignal>
 #include <cstring>
+#include <execinfo.h>
 #include <limits>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -452,7 +455,14 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   b->off_stream = off_stream;
   b->off_members = off_members;
   b->off_neural = off_neural;
-  hipError_t e = hipMalloc((void**)&b->blob_dev, (size_t)total * sizeof(double));
+  // (the kernels stage parts of the blob in whole 1 KB pieces -- dma_weights,
+  // the ellipsoid block of nb_eval_fast.hip -- so the last piece of the last
+  // block may read up to 1 KB past its end: keep that inside the allocation)
+  constexpr size_t SLACK = 512;
+  hipError_t e = hipMalloc((void**)&b->blob_dev,
+                           ((size_t)total + SLACK) * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemset(b->blob_dev + total, 0, SLACK * sizeof(double));
   if (e == hipSuccess)
     e = hipMemcpy(b->blob_dev, buf.data(), (size_t)total * sizeof(double),
                   hipMemcpyHostToDevice);
@@ -569,6 +579,23 @@ int nb_neural_score(const nb_bound* b, const double* x, int64_t n, double* out,
 #endif
   return nb_launch_eval(b->dt, b->self_list_dev, 1, 4, x, n, nullptr, nullptr,
                         out, 0, 0, as_stream(stream));
+}
+
+// debugging aid: native backtrace on SIGABRT / SIGSEGV (NB_ABORT_TRACE=1)
+static void nb_abort_trace(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "[nautilus_hip] fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
+int nb_debug_install_abort_trace(void) {
+  signal(SIGABRT, nb_abort_trace);
+  signal(SIGSEGV, nb_abort_trace);
+  return NB_OK;
 }
 
 int nb_geom_list(const nb_boundlist* l, int32_t mode, const double* x,
