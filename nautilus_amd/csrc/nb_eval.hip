@@ -271,7 +271,7 @@ __device__ __forceinline__ void mlp_tiles(const double* w, int ks_n,
 typedef const void __attribute__((address_space(1))) * nb_gptr;
 typedef void __attribute__((address_space(3))) * nb_lptr;
 template <int NW>
-__device__ __forceinline__ void dma_weights(const double* __restrict__ src,
+__device__ __forceinline__ void dma_weights(const nb_gd* __restrict__ src,
                                             double* dst, int n_doubles,
                                             int wave, int lane) {
   for (int c = wave * 128; c < n_doubles; c += NW * 128)
@@ -281,10 +281,10 @@ __device__ __forceinline__ void dma_weights(const double* __restrict__ src,
 
 // cooperative global -> LDS copy by the whole workgroup (16 bytes per lane)
 template <int NW>
-__device__ __forceinline__ void stage_weights(const double* __restrict__ src,
+__device__ __forceinline__ void stage_weights(const nb_gd* __restrict__ src,
                                               double* dst, int n_doubles) {
   for (int i = 2 * threadIdx.x; i < n_doubles; i += 2 * 64 * NW) {
-    const double2 v = *(const double2*)(src + i);
+    const double2 v = *(const NB_G double2*)(src + i);
     *(double2*)(dst + i) = v;
   }
 }
@@ -324,7 +324,9 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
   const long long n_super = (a.n + 16 * NW * TPW - 1) / (16 * NW * TPW);
   unsigned long long cnt_outer = 0, cnt_ell = 0, cnt_mlp = 0;
 
-  const double* blob0 = a.blobs[0];
+  // (blob pointers typed as global memory: nb_common.h, NB_G)
+  const nb_gd* const NB_G* blobs = (const nb_gd* const NB_G*)a.blobs;
+  const double* blob0 = (const double*)blobs[0];
   const int n_dim = (int)nb_hdr(blob0, NB_H_NDIM);
   const int ks1 = (n_dim + 1 + 3) >> 2;
 
@@ -355,7 +357,8 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
     }
 
     for (int b = 0; b < a.nb; ++b) {
-      const double* blob = a.blobs[b];
+      const nb_gd* blob_g = blobs[b];
+      const double* blob = (const double*)blob_g;
       const int K = (int)nb_hdr(blob, NB_H_K);
       const int M = (int)nb_hdr(blob, NB_H_M);
       const int E = (int)nb_hdr(blob, NB_H_E);
@@ -376,7 +379,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       // outer member is staged in between, and only for n_dim <= 48 (beyond,
       // keeping the points in registers until the ellipsoid test spills:
       // measured 2 % slower at n_dim = 50).
-      const double* nblk = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
+      const nb_gd* nblk = blob_g + nb_hdr(blob, NB_H_OFF_NEURAL);
       const int kt1 = (int)nb_hdr(blob, NB_H_KT1);
       const int n_a = kt1 * NB_HT1 * NB_TILE;                   // layer 1
       constexpr int KA = (DT + 2) / 2;                  // k-tiles of chunk A
@@ -410,12 +413,12 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
         // of the workgroup passes this test the whole bound is skipped --
         // for nested bounds in high dimension all but the next few bounds.
         if (SPARSE && M > 0) {
-          const double* nblk0 = blob + nb_hdr(blob, NB_H_OFF_NEURAL);
+          const nb_gd* nblk0 = blob_g + nb_hdr(blob, NB_H_OFF_NEURAL);
           bool maybe = false;
           for (int m = 0; m < M; ++m) {
-            const double* nb_m = nblk0 + m * neural_stride;
+            const nb_gd* nb_m = nblk0 + m * neural_stride;
             const double rad2 = nb_m[1];
-            const double* cc = nb_m + 2 + 2 * DP;
+            const nb_gd* cc = nb_m + 2 + 2 * DP;
             double d2[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) d2[t] = 0.0;
@@ -459,7 +462,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
       // ---- outer union: overlap count --------------------------------
 #pragma unroll
       for (int t = 0; t < TPW; ++t) k_cnt[t] = 0;
-      const double* mblk = blob + nb_hdr(blob, NB_H_OFF_MEMBERS);
+      const nb_gd* mblk = blob_g + nb_hdr(blob, NB_H_OFF_MEMBERS);
       if (m_sample && K == 1) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) k_cnt[t] = 1;   // drawn from the only member
@@ -512,10 +515,10 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
         const long long net_stride = nb_hdr(blob, NB_H_NET_STRIDE);
         const int n_b = (NB_HT1 * NB_HT2 + NB_HT2 * NB_HT3 + NB_HT3) * NB_TILE;
         for (int m = 0; m < M; ++m) {
-          const double* nb_m = nblk + m * neural_stride;
+          const nb_gd* nb_m = nblk + m * neural_stride;
           double y[TPW][4 * DT], r2[TPW];
           bool box_bad[TPW], inside_e[TPW], need[TPW];
-          const double* nets =
+          const nb_gd* nets =
               nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
           if (ell_dma) {
             // (m == 0 of a pre-issued bound: copies in flight, points loaded)
@@ -646,7 +649,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               double* reg[2] = {wlds, tlds};
               double h1[TPW][4 * NB_HT1];
               auto issue = [&](int e, int st, int q) {
-                const double* w1 = nets + e * net_stride;
+                const nb_gd* w1 = nets + e * net_stride;
                 if (st == 0) dma_weights<NW>(w1, reg[q & 1], n_a0, wave, lane);
                 else if (TWO && st == 1)
                   dma_weights<NW>(w1 + n_a0, reg[q & 1], n_a - n_a0, wave, lane);
@@ -706,7 +709,7 @@ nb_eval_kernel(EvalArgs a, int w_doubles) {
               }
             } else {
               for (int e = 0; e < E; ++e) {
-                const double* w1 = nets + e * net_stride;
+                const nb_gd* w1 = nets + e * net_stride;
                 double h1[TPW][4 * NB_HT1];
                 __syncthreads();                       // LDS free
                 stage_weights<NW>(w1, wlds, n_a);

@@ -271,16 +271,32 @@ class DeviceBoundList:
         """mask[i] = any bound of the list contains x[i] (uint8 flags for the
         compaction kernels with ``as_flags``)."""
         x = as_device_points(x, self.n_dim)
-        st, _ = two_stage(self.bounds, self, GEOM_ANY, x)
-        inside = (st & GS_INSIDE) != 0
-        return inside.to(torch.uint8) if as_flags else inside
+        if len(self.bounds) <= TWO_STAGE_MAX_LIST:
+            st, _ = two_stage(self.bounds, self, GEOM_ANY, x)
+            inside = (st & GS_INSIDE) != 0
+            return inside.to(torch.uint8) if as_flags else inside
+        # long lists of nested bounds: a point near the edge of its shell
+        # waits for the emulators of bound after bound, one round of the two
+        # stages each; the one-kernel form walks the list inside the kernel
+        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+        _lib.check(self._lib.nb_contains_any(self._h, _ptr(x), x.shape[0],
+                                             _ptr(mask), _stream()))
+        return mask if as_flags else mask.bool()
 
     def first_containing(self, x):
         x = as_device_points(x, self.n_dim)
-        st, _, pos = two_stage(self.bounds, self, GEOM_FIRST, x,
-                               return_pos=True)
-        return torch.where((st & GS_INSIDE) != 0, pos >> 8,
-                           torch.full_like(pos, -1))
+        if len(self.bounds) <= TWO_STAGE_MAX_LIST:
+            st, _, pos = two_stage(self.bounds, self, GEOM_FIRST, x,
+                                   return_pos=True)
+            return torch.where((st & GS_INSIDE) != 0, pos >> 8,
+                               torch.full_like(pos, -1))
+        idx = torch.empty(x.shape[0], dtype=torch.int32, device='cuda')
+        _lib.check(self._lib.nb_first_containing(self._h, _ptr(x), x.shape[0],
+                                                 _ptr(idx), _stream()))
+        return idx
+
+
+TWO_STAGE_MAX_LIST = 2     # bounds in a list evaluated in two stages
 
 
 GEOM_ANY, GEOM_FIRST, GEOM_SAMPLE = 0, 1, 2
