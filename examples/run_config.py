@@ -71,7 +71,8 @@ def main():
         n_batch=args.n_batch or c['n_batch'],
         log_z=float(s.log_z), analytic_log_z=c['analytic_log_z'],
         n_eff=float(s.n_eff), n_like=int(s.n_like), n_bounds=len(s.bounds),
-        n_neural_last=len(s.bounds[-1].neural_bounds)
+        n_neural_last=len(s.bounds[-1].neural_bounds),
+        n_dead_bounds=s.n_dead_bounds
         if len(s.bounds) > 1 else 0,
         n_proposals=int(s.n_proposals), mean_first3=mean[:3].round(4).tolist(),
         n_in_bound=int(np.sum(s.shell_n_sample)),

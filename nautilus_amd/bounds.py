@@ -28,8 +28,12 @@ from scipy.stats import rankdata
 from . import device, geometry
 from .emulator import NeuralNetworkEmulator
 
+import os as _os
+_FILL_TRACE = bool(_os.environ.get('NB_FILL_TRACE'))
 MIN_DRAW = 1 << 14          # proposals per launch, lower limit
 MAX_DRAW = 1 << 22          # upper limit (bounds the scratch memory)
+DEAD_MARGIN = 5e-3          # loss within this of the constant predictor's
+MAX_BARREN = 256            # launches of MAX_DRAW without one accepted point
 
 
 def _default_rng(rng):
@@ -396,6 +400,7 @@ class _RejectionSampler(_DeviceBoundBase):
 
     def _fill(self, n_points):
         q = self._queue()
+        barren = 0
         while len(q) < n_points:
             need = n_points - len(q)
             acc = max(self._acceptance(), 1e-7)
@@ -405,6 +410,23 @@ class _RejectionSampler(_DeviceBoundBase):
             rows, counts = self.device_bound().sample_launch(
                 seed, off, n_draw, reuse=True)     # q.push copies the rows
             c = counts.cpu().numpy()
+            # the reference's loop (nautilus.py:217-240) never ends for a
+            # bound that accepts nothing; say so instead
+            barren = barren + 1 if int(c[1]) == 0 and n_draw == MAX_DRAW \
+                else 0
+            if barren >= MAX_BARREN:
+                raise RuntimeError(
+                    'the bound accepted none of %d proposals (%d inside its '
+                    'ellipsoids): its emulator rejects everything' %
+                    (barren * MAX_DRAW, int(c[0])))
+            if _FILL_TRACE:
+                import sys
+                dev = self.device_bound()
+                print('[fill] need=%d n_draw=%d outer=%d final=%d K=%d M=%d '
+                      'dense_need=%s' % (need, n_draw, c[0], c[1],
+                                         dev.n_members, dev.n_neural,
+                                         dev.dense_need), file=sys.stderr,
+                      flush=True)
             self._account(n_draw, int(c[0]), int(c[1]))
             rows = rows[:int(c[1])]
             shift = getattr(self, 'shift', None)
@@ -617,6 +639,7 @@ class NeuralBound(_DeviceBoundBase):
             self.n_dim = x.shape[1]
             self.outer_bound = ell
             bounds.append(self)
+            self.emulator_dead = False
             if n_networks == 0:
                 self.emulator = None
                 self.score_predict_min = 0
@@ -637,9 +660,37 @@ class NeuralBound(_DeviceBoundBase):
                 neural_network_kwargs=neural_network_kwargs, comm=comm)
             for (self, x_t, score, hi), emu in zip(train, emus):
                 self.emulator = emu
+                # A network whose last epoch is no better than the constant
+                # predictor has died (all units of a layer inactive, a hazard
+                # of Adam at the reference's learning rate 1e-2).  A bound
+                # whose whole ensemble died accepts nothing, and the
+                # reference's sampling loop would spin on it for ever.
+                floor = 0.5 * np.var(score) * (1.0 - DEAD_MARGIN)
+                self.emulator_dead = all(
+                    n.loss_curve_[-1] >= floor for n in emu.neural_networks)
                 pred = emu.predict_device(x_t).cpu().numpy()
                 self.score_predict_min = np.polyval(
                     np.polyfit(score, pred, 3), np.amin(score[hi]))
+                if _FILL_TRACE:
+                    import sys
+                    print('[neural] n=%d hi=%d spm=%.6f pred[min %.4f q50 %.4f'
+                          ' q99 %.4f max %.4f] pred(hi)[min %.4f q50 %.4f] '
+                          'n_iter=%s loss=%s' % (
+                              len(score), int(np.sum(hi)),
+                              self.score_predict_min, pred.min(),
+                              np.median(pred), np.quantile(pred, 0.99),
+                              pred.max(), pred[hi].min(),
+                              np.median(pred[hi]),
+                              [n.n_iter_ for n in emu.neural_networks],
+                              ['%.2e' % n.loss_curve_[-1]
+                               for n in emu.neural_networks]),
+                          file=sys.stderr, flush=True)
+                    dump = _os.environ.get('NB_DUMP_COLLAPSE')
+                    if dump and np.quantile(pred, 0.99) - np.median(pred) \
+                            < 1e-3:
+                        np.savez(dump, x_t=x_t.cpu().numpy(), score=score,
+                                 hi=hi, mean=emu.mean, scale=emu.scale)
+                        raise SystemExit('collapsed emulator dumped')
         return bounds
 
     @classmethod
@@ -792,6 +843,13 @@ class NautilusBound(_RejectionSampler):
         self.neural_bounds = list(neural_bounds)
         self._init_sampling(rng)
         return self
+
+    @property
+    def emulators_dead(self):
+        """True if the whole ensemble of one of the neural bounds died in
+        training (``NeuralBound.emulator_dead``): the bound accepts nothing."""
+        return any(getattr(nb, 'emulator_dead', False)
+                   for nb in self.neural_bounds)
 
     def _upload(self):
         u = self.outer_bound

@@ -221,7 +221,7 @@ class DeviceBound:
         fused_ok = (self.n_neural == 1 and self.n_members <= 1 and
                     self.n_networks >= 1)
         self._launches += 1
-        probe = self.dense_need is None or self._launches % 64 == 0
+        probe = self.dense_need is None or self._launches % 1024 == 0
         if fused_ok and not probe and self.dense_need > 0.5:
             flags = _buffer('accept', (x.shape[0],), torch.uint8, reuse)
             _lib.check(self._lib.nb_accept(self._h, seed, offset, _ptr(x),

@@ -155,6 +155,7 @@ class Sampler:
         self.rng = np.random.default_rng(seed)
 
         self.n_like = 0
+        self.n_dead_bounds = 0      # bounds dropped for a dead emulator
         self.explored = False
         self.bounds = []
         self._pts = []           # per shell: _Grow (n, n_dim) on the device
@@ -855,7 +856,9 @@ class Sampler:
                         n_networks=self.n_networks,
                         neural_network_kwargs=self.neural_network_kwargs,
                         pool=self.pool_s, rng=self.rng, comm=self.comm)
-                    if self.comm is None:
+                    if bound.emulators_dead:
+                        pass
+                    elif self.comm is None:
                         bound.sample(1000, return_points=False)
                     else:
                         # the pre-fill behind the first volume estimate
@@ -866,7 +869,18 @@ class Sampler:
                         self._sum_counters(bound, before)
                 for key, val in bound.timing.items():
                     self.timing[key] = self.timing.get(key, 0.0) + val
-                ok = bool(bound.log_v < self.bounds[-1].log_v)
+                if bound.emulators_dead:
+                    # Deviation: every network of an ensemble ended no
+                    # better than a constant, so the bound accepts nothing
+                    # and the reference would never return from the pre-fill
+                    # (nautilus.py:217-240).  Treated like a bound that fails
+                    # to shrink (sampler.py:1034): the last bound is filled
+                    # for another n_update points and the next attempt trains
+                    # on the larger set.
+                    self.n_dead_bounds += 1
+                    ok = False
+                else:
+                    ok = bool(bound.log_v < self.bounds[-1].log_v)
                 if ok:
                     self.bounds.append(bound)
         if not ok:

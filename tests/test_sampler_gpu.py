@@ -596,3 +596,56 @@ def test_prior_on_device():
     pts, log_w, _ = s.posterior(return_as_dict=True)
     assert isinstance(pts, dict) and abs(
         np.average(pts['a'], weights=np.exp(log_w)) - 1.0) < 0.02
+
+
+def test_dead_emulator_bound_is_dropped(monkeypatch):
+    """A bound whose whole network ensemble ended no better than a constant
+    accepts nothing (the reference would spin in nautilus.py:217-240).  It is
+    dropped like a bound that fails to shrink (sampler.py:1034-1038): the
+    likelihood threshold of the last shell moves up, the shell is filled
+    further and the run finishes with the right evidence."""
+    from nautilus_amd import GaussianLikelihood, Sampler, bounds, unit_prior
+    analytic, ref_lz = _reference_band()
+    like = GaussianLikelihood(MU, np.eye(3) * 0.01, normalised=False)
+    s = Sampler(unit_prior, like, n_dim=3, n_live=400, n_networks=1,
+                vectorized=True, seed=0, n_batch=400)
+    made = []
+    real = bounds.NeuralBound.compute_many.__func__
+
+    def compute_many(cls, *args, **kwargs):
+        out = real(cls, *args, **kwargs)
+        made.append(out)
+        if len(made) in (2, 3):             # two attempts in a row
+            for nb in out:
+                assert nb.emulator_dead is False
+                nb.emulator_dead = True
+        return out
+    monkeypatch.setattr(bounds.NeuralBound, 'compute_many',
+                        classmethod(compute_many))
+    assert s.run(n_eff=3000, discard_exploration=True) is True
+    assert s.n_dead_bounds == 2
+    assert len(s.bounds) + 2 <= len(made) + 1
+    vols = np.array([b.log_v for b in s.bounds])
+    assert np.all(np.diff(vols) < 0)
+    assert np.all(np.diff(s.shell_log_l_min) > 0)
+    assert abs(s.log_z - analytic) < max(0.03, 4 * np.std(ref_lz))
+
+
+def test_barren_bound_fails_loudly(monkeypatch):
+    """The pre-fill of a bound that accepts nothing raises instead of
+    looping for ever."""
+    from nautilus_amd import bounds
+    rng = np.random.default_rng(0)
+    pts = 0.5 + 0.05 * rng.normal(size=(4000, 3))
+    log_l = -np.sum((pts - 0.5)**2, axis=1)
+    b = bounds.NautilusBound.compute(
+        pts, log_l, np.sort(log_l)[-400], np.log(0.01), n_networks=1,
+        rng=np.random.default_rng(1))
+    assert len(b.neural_bounds) >= 1 and not b.emulators_dead
+    for nb in b.neural_bounds:
+        nb.score_predict_min = 10.0          # no score reaches it
+    b._dev = None                            # upload again
+    monkeypatch.setattr(bounds, 'MAX_BARREN', 2)
+    monkeypatch.setattr(bounds, 'MAX_DRAW', bounds.MIN_DRAW)
+    with pytest.raises(RuntimeError, match='accepted none'):
+        b.sample(10)
