@@ -482,7 +482,7 @@ def main():
     # latest committed measurement under profiles/ named for reference.
     traffic, traffic_src = None, ('not measured in this run (use '
                                   '--pmc-traffic); committed measurements: '
-                                  'profiles/r02/')
+                                  'profiles/r03/bench_pmc_traffic.json')
     if args.pmc_traffic and rank == 0 and world == 1:
         got = pmc_traffic(sys.argv[1:])
         if got is not None:
@@ -497,9 +497,12 @@ def main():
         kernel='nb_eval_fast_kernel (+ nb_geom_kernel)', kernel_note=(
             'bound evaluation of the timed steps: proposal acceptance in '
             'nb_eval_fast_kernel (fused cube test, ellipsoid, emulators); '
-            'shell exclusion = nb_geom_kernel (geometric tests of the later '
-            'bounds) + nb_eval_fast_kernel on the gathered points that reach '
-            'an emulator; calls and HIP-event time are those of all of them'),
+            'shell exclusion against one or two later bounds = nb_geom_kernel '
+            '(geometric tests) + nb_eval_fast_kernel on the gathered points '
+            'that reach an emulator, against longer lists = nb_eval_kernel '
+            '(walks the list inside the kernel); calls and HIP-event time '
+            'are those of all of them, kernel_dispatches and the PMC traffic '
+            'those of the first two'),
         bound='mfma', achieved=achieved_tf,
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
         frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=traffic,

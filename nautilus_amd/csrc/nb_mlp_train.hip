@@ -35,6 +35,8 @@
 
 namespace {
 
+typedef double nb_d2 __attribute__((ext_vector_type(2)));
+
 constexpr int MAXB = 208;        // minibatch rows padded to 16 (batch <= 200)
 constexpr int LD1 = 112, LD2 = 64, LD3 = 32, LD4 = 16;
 constexpr int G_ROWT = MAXB / 16;   // 16-row tiles of a minibatch
@@ -53,6 +55,32 @@ constexpr int WT_DOUBLES = WT4 + 1 * NB_HT3 * NB_TILE;
 // clean lines on this part -- measured: 4.6 us per step.)
 __device__ __forceinline__ double ld_xcd(const nb_gd* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Weight tiles (W: [kt][ht], contraction index c = input unit; WT: [ht][kt],
+// c = output unit) are stored so that a lane finds the operands of two
+// consecutive k-steps side by side: k-step 2 P + j of the tile row covers
+// c = 8 P + 2 lg + j (lg = lane / 16), and element (c, r) of a tile lives at
+// ((c / 8) * 64 + ((c / 2) % 4) * 16 + r) * 2 + c % 2 -- one 16-byte load per
+// lane and PAIR of k-steps, 1 KB contiguous per wavefront.  A CU's texture
+// path moves ~26 B / clk with 8-byte and ~53 B / clk with 16-byte loads per
+// lane (dev/l2_read_bench.hip), and the forward / backward phase is made of
+// waiting for exactly these operands.
+__host__ __device__ constexpr int tile_index(int c, int r) {
+  return ((c >> 3) * 64 + ((c >> 1) & 3) * 16 + r) * 2 + (c & 1);
+}
+
+// 16-byte device-scope load (buffer_load_dwordx4 ... sc1; the global-pointer
+// form of the atomic load builtin stops at 8 bytes): wave-uniform byte offset
+// `soff` + per-lane byte offset `voff` into the buffer behind `rsrc`
+__device__ __forceinline__ nb_d2 ld_xcd2(__amdgpu_buffer_rsrc_t rsrc,
+                                         unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(
+      nb_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const nb_gd* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff,
+                                           0x00020000);
 }
 
 struct NetState {
@@ -119,47 +147,69 @@ template <int NREG>
 __device__ __forceinline__ void lds_operand(const double* act, int lane,
                                             double* in) {
   const int li = lane & 15, lg = lane >> 4;
+  // k-step ks covers the units 16 (ks / 4) + 8 ((ks / 2) % 2) + 2 lg + ks % 2
+  // (tile_index)
 #pragma unroll
-  for (int ks = 0; ks < NREG; ++ks) in[ks] = act[(4 * ks + lg) * LS + li];
+  for (int ks = 0; ks < NREG; ++ks)
+    in[ks] = act[(16 * (ks >> 2) + 8 * ((ks >> 1) & 1) + 2 * lg + (ks & 1)) *
+                     LS + li];
 }
 
-// cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows)
-// (n_unit is a multiple of 16: thread -> row tid / 16, 16 consecutive units)
+// cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows,
+// 16 bytes per thread: thread -> row tid / 16, units 2 c, 2 c + 1 of every
+// block of 32; n_unit is a multiple of 16, so half the threads skip the last
+// block where it is a multiple of 16 only)
 __device__ __forceinline__ void flush_stash(const double* act, nb_gd* dst,
                                             int ld, int n_unit, int tile,
                                             int tid) {
-  const unsigned r = tid >> 4, c = tid & 15;
+  const unsigned r = tid >> 4, c = 2 * (tid & 15);
   nb_gd* row = dst + (tile * 16) * ld;               // wave-uniform
   const unsigned off = r * ld + c;
-  for (int u = 0; u < n_unit; u += 16) row[off + u] = act[(c + u) * LS + r];
+  for (int u = 0; u < n_unit; u += 32) {
+    if (u + (int)c < n_unit) {
+      const nb_d2 v = {act[(c + u) * LS + r], act[(c + 1 + u) * LS + r]};
+      *(NB_G nb_d2*)(row + off + u) = v;
+    }
+  }
 }
 
-// A operands of one 16x16 output tile, k-steps 0 .. N-1: `tile0` points at
-// the tile of k-tile 0 (wave-uniform), consecutive k-tiles are TSTRIDE tiles
-// apart; the operand of a k-step is one contiguous 512-byte row block.  The
-// same form serves the forward products (tiles [kt][ht] of W) and, through
-// the transposed copy, the backward ones (tiles [ht][kt] of WT).
+// A operands of one 16x16 output tile, k-steps 0 .. N-1 (N even): `tile0` is
+// the DOUBLE offset of the tile of k-tile 0 in the buffer behind `rsrc`
+// (wave-uniform), consecutive k-tiles are TSTRIDE tiles apart; the operands
+// of a pair of k-steps are one contiguous 1 KB block (16 bytes per lane).
+// The same form serves the forward products (tiles [kt][ht] of W) and,
+// through the transposed copy, the backward ones (tiles [ht][kt] of WT).
 template <int N, int TSTRIDE>
-__device__ __forceinline__ void load_ops(const nb_gd* __restrict__ tile0,
-                                         unsigned lane, double* wr) {
+__device__ __forceinline__ void load_ops(__amdgpu_buffer_rsrc_t rsrc,
+                                         unsigned tile0, unsigned lane,
+                                         double* wr) {
+  static_assert(N % 2 == 0, "operands come in pairs of k-steps");
 #pragma unroll
-  for (int s = 0; s < N; ++s)
-    wr[s] = ld_xcd(
-        &tile0[(unsigned)((s >> 2) * TSTRIDE * NB_TILE + (s & 3) * 64) + lane]);
+  for (int p = 0; p < N / 2; ++p) {
+    const nb_d2 v = ld_xcd2(
+        rsrc, lane * 16,
+        (tile0 + (unsigned)((p >> 1) * TSTRIDE * NB_TILE + (p & 1) * 128)) * 8);
+    wr[2 * p] = v.x;
+    wr[2 * p + 1] = v.y;
+  }
 }
 
-// ... of layer 1: only the k-steps of the last k-tile depend on n_dim
+// ... of layer 1: only the pairs of the last k-tile depend on n_dim
 template <int KT1>
-__device__ __forceinline__ void load_ops_l1(const nb_gd* __restrict__ tile0,
-                                            int ks1, unsigned lane,
-                                            double* wr) {
-  load_ops<4 * (KT1 - 1), NB_HT1>(tile0, lane, wr);
+__device__ __forceinline__ void load_ops_l1(__amdgpu_buffer_rsrc_t rsrc,
+                                            unsigned tile0, int ks1,
+                                            unsigned lane, double* wr) {
+  load_ops<4 * (KT1 - 1), NB_HT1>(rsrc, tile0, lane, wr);
 #pragma unroll
-  for (int s = 4 * (KT1 - 1); s < 4 * KT1; ++s)
-    wr[s] = (s < ks1)
-        ? ld_xcd(&tile0[(unsigned)((s >> 2) * NB_HT1 * NB_TILE + (s & 3) * 64) +
-                        lane])
-        : 0.0;
+  for (int p = 2 * (KT1 - 1); p < 2 * KT1; ++p) {
+    nb_d2 v = {0.0, 0.0};
+    if (2 * p < ks1)
+      v = ld_xcd2(rsrc, lane * 16,
+                  (tile0 + (unsigned)((p >> 1) * NB_HT1 * NB_TILE +
+                                      (p & 1) * 128)) * 8);
+    wr[2 * p] = v.x;
+    wr[2 * p + 1] = v.y;
+  }
 }
 
 template <int N>
@@ -320,15 +370,17 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   const unsigned lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int ks1 = (a.n_dim + 1 + 3) >> 2;
+  // k-steps of layer 1 in use: pairs, 8 input units (bias included) each
+  const int ks1 = 2 * ((a.n_dim + 1 + 7) >> 3);
 
-  const nb_gd* W1 = st.W;
-  const nb_gd* W2 = W1 + KT1 * NB_HT1 * NB_TILE;
-  const nb_gd* W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
-  const nb_gd* W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
-  const nb_gd* T2 = st.WT + WT2;
-  const nb_gd* T3 = st.WT + WT3;
-  const nb_gd* T4 = st.WT + WT4;
+  // tile offsets (doubles) into the weights / their transposed copies
+  const __amdgpu_buffer_rsrc_t rW = tile_rsrc(st.W);
+  const __amdgpu_buffer_rsrc_t rT = tile_rsrc(st.WT);
+  constexpr unsigned W1 = 0;
+  constexpr unsigned W2 = W1 + KT1 * NB_HT1 * NB_TILE;
+  constexpr unsigned W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
+  constexpr unsigned W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
+  constexpr unsigned T2 = WT2, T3 = WT3, T4 = WT4;
   const StashPtrs sp = stash_ptrs(st, LD0);
 
   const int pt = tile * 16 + li;
@@ -339,11 +391,12 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   // one contiguous 512-byte row block per operand), a layer or more ahead of
   // their use; nothing else sits in the memory queue in front of them -- the
   // stash stores of the step are issued at the very end. ---------------------
-  double w1r[2][KS1], w2r[26], w3r[13], w4r[6], b4r[1], b3r[5], b2r[2][13];
+  double w1r[2][KS1], w2r[26], w3r[14], w4r[6], b4r[2], b3r[6], b2r[2][14];
   const int ht1b = (wave + 4 < NB_HT1) ? wave + 4 : wave;
-  load_ops_l1<KT1>(W1 + wave * NB_TILE, ks1, lane, w1r[0]);
-  load_ops_l1<KT1>(W1 + ht1b * NB_TILE, ks1, lane, w1r[1]);
-  if constexpr (KT1 <= 4) load_ops<26, NB_HT2>(W2 + wave * NB_TILE, lane, w2r);
+  load_ops_l1<KT1>(rW, W1 + wave * NB_TILE, ks1, lane, w1r[0]);
+  load_ops_l1<KT1>(rW, W1 + ht1b * NB_TILE, ks1, lane, w1r[1]);
+  if constexpr (KT1 <= 4)
+    load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
 
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
 #pragma unroll
@@ -351,7 +404,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
     sA0[(4 * (4 * j + wave) + lg) * LS + li] = rows.x[j];
   lds_barrier();
   FB_STAMP(11);
-  if constexpr (KT1 > 4) load_ops<26, NB_HT2>(W2 + wave * NB_TILE, lane, w2r);
+  if constexpr (KT1 > 4)
+    load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
 
   // ---- layer 1: output tiles wave, wave + 4 ------------------------------
   {
@@ -375,10 +429,10 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   lds_barrier();
   FB_STAMP(12);
   // the remaining operands, in the order of use (in flight during layer 2)
-  load_ops<13, NB_HT3>(W3 + (wave & 1) * NB_TILE, lane, w3r);
-  load_ops<6, 1>(W4, lane, w4r);
-  load_ops<1, NB_HT3>(T4 + (wave & 1) * NB_TILE, lane, b4r);
-  load_ops<5, NB_HT2>(T3 + wave * NB_TILE, lane, b3r);
+  load_ops<14, NB_HT3>(rW, W3 + (wave & 1) * NB_TILE, lane, w3r);
+  load_ops<6, 1>(rW, W4, lane, w4r);
+  load_ops<2, NB_HT3>(rT, T4 + (wave & 1) * NB_TILE, lane, b4r);
+  load_ops<6, NB_HT2>(rT, T3 + wave * NB_TILE, lane, b3r);
 
   // ---- layer 2: output tile = wave ----------------------------------------
   {
@@ -397,14 +451,14 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(13);
   // (the operands of the last backward product take the registers layer 2's
   // have left; five stages until they are needed)
-  load_ops<13, NB_HT1>(T2 + wave * NB_TILE, lane, b2r[0]);
-  load_ops<13, NB_HT1>(T2 + ht1b * NB_TILE, lane, b2r[1]);
+  load_ops<14, NB_HT1>(rT, T2 + wave * NB_TILE, lane, b2r[0]);
+  load_ops<14, NB_HT1>(rT, T2 + ht1b * NB_TILE, lane, b2r[1]);
 
   // ---- layer 3: two output tiles ------------------------------------------
   if (wave < NB_HT3) {
-    double in[13];
-    lds_operand<13>(sA2, lane, in);
-    const nb_d4 acc = mma<13>(w3r, in);
+    double in[14];
+    lds_operand<14>(sA2, lane, in);
+    const nb_d4 acc = mma<14>(w3r, in);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double v = fmax(acc[r], 0.0);
@@ -438,9 +492,9 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
   if (wave < NB_HT3) {
-    double dout[1];
-    lds_operand<1>(sD4, lane, dout);
-    const nb_d4 acc = mma<1>(b4r, dout);
+    double dout[2];
+    lds_operand<2>(sD4, lane, dout);
+    const nb_d4 acc = mma<2>(b4r, dout);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int unit = 16 * wave + 4 * r + lg;
@@ -454,9 +508,9 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 
   // ---- delta 2 --------------------------------------------------------------
   {
-    double dout[5];
-    lds_operand<5>(sD3, lane, dout);
-    const nb_d4 acc = mma<5>(b3r, dout);
+    double dout[6];
+    lds_operand<6>(sD3, lane, dout);
+    const nb_d4 acc = mma<6>(b3r, dout);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int unit = 16 * wave + 4 * r + lg;
@@ -470,13 +524,13 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 
   // ---- delta 1 --------------------------------------------------------------
   {
-    double dout[13];
-    lds_operand<13>(sD2, lane, dout);
+    double dout[14];
+    lds_operand<14>(sD2, lane, dout);
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int kt = wave + 4 * rep;
       if (kt < NB_HT1) {
-        const nb_d4 acc = mma<13>(b2r[rep], dout);
+        const nb_d4 acc = mma<14>(b2r[rep], dout);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int unit = 16 * kt + 4 * r + lg;
@@ -677,7 +731,9 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   G_STAMP(30);
   after_loads();
   // this lane's element of every tile of the job: row lg + 4 wave, column li
-  const unsigned eoff = (lg + 4 * wave) * 16 + li;
+  const unsigned eoff = (lg + 4 * wave) * 16 + li;     // moments: row major
+  const unsigned woff_e = tile_index(lg + 4 * wave, li);
+  const unsigned toff_e = tile_index(li, lg + 4 * wave);
   double w_old[G_MAX_TILES], m_old[G_MAX_TILES], v_old[G_MAX_TILES];
 #pragma unroll
   for (int ia = 0; ia < 2; ++ia)
@@ -685,7 +741,7 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
     for (int ib = 0; ib < 2; ++ib)
       if (ia < nk && ib < nh) {
         const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
-        w_old[2 * ia + ib] = ld_xcd(&(st.W + woff)[eoff]);
+        w_old[2 * ia + ib] = ld_xcd(&(st.W + woff)[woff_e]);
         m_old[2 * ia + ib] = ld_xcd(&(st.M + woff)[eoff]);
         v_old[2 * ia + ib] = ld_xcd(&(st.V + woff)[eoff]);
       }
@@ -721,11 +777,11 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
         const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
         (st.M + woff)[eoff] = m;
         (st.V + woff)[eoff] = v;
-        (st.W + woff)[eoff] = w;
+        (st.W + woff)[woff_e] = w;
         if (g.tbase >= 0) {
           const int toff =
               g.tbase + ((ht0 + ib) * g.kt_n + kt0 + ia) * NB_TILE;
-          (st.WT + toff)[li * 16 + lg + 4 * wave] = w;
+          (st.WT + toff)[toff_e] = w;
         }
       }
   G_STAMP(32);
@@ -1015,12 +1071,12 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
 }
 
 void put_w(double* tiles, int ht_n, int k, int h, double v) {
-  tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
-        (h & 15)] = v;
+  tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE +
+        tile_index(k & 15, h & 15)] = v;
 }
 double get_w(const double* tiles, int ht_n, int k, int h) {
-  return tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE + (k & 15) * 16 +
-               (h & 15)];
+  return tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE +
+               tile_index(k & 15, h & 15)];
 }
 // The job list of the G phase (see g_job): blocks of up to 2 x 2 tiles per
 // layer, shaped so that a network needs at most 32 jobs -- one round of the
@@ -1046,8 +1102,8 @@ std::vector<int> g_jobs(int kt1) {
 
 // transposed copy: tiles [ht][kt], element (hh, kk)
 void put_wt(double* tiles, int kt_n, int k, int h, double v) {
-  tiles[((size_t)(h >> 4) * kt_n + (k >> 4)) * NB_TILE + (h & 15) * 16 +
-        (k & 15)] = v;
+  tiles[((size_t)(h >> 4) * kt_n + (k >> 4)) * NB_TILE +
+        tile_index(h & 15, k & 15)] = v;
 }
 
 }  // namespace
