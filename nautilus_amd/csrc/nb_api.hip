@@ -24,10 +24,10 @@ int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
                         unsigned long long seed, unsigned long long offset,
                         hipStream_t stream);
 int nb_launch_geom(int dt, const double* const* blobs_dev, int nb, int mode,
-                   const double* x, long long n_rows, const long long* idx,
-                   long long n, int* pos, unsigned char* st,
-                   unsigned long long seed, unsigned long long offset,
-                   hipStream_t stream);
+                   int n_blocks, const double* x, long long n_rows,
+                   const long long* idx, long long n, int* pos,
+                   unsigned char* st, unsigned long long seed,
+                   unsigned long long offset, hipStream_t stream);
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
                    int* out_i32, double* out_f64, unsigned long long seed,
@@ -127,6 +127,7 @@ static inline int64_t nb_hdr_host_off_members(const nb_bound* b) {
 struct nb_boundlist {
   const double** ptrs_dev = nullptr;
   int n = 0, dt = 0, n_dim = 0;
+  int blocks_single = 0;   // n == 1: ellipsoid blocks (K + M) of the bound
 };
 
 namespace {
@@ -513,6 +514,7 @@ int nb_boundlist_create(nb_bound* const* bounds, int32_t n,
   if (n > 0) {
     l->dt = bounds[0]->dt;
     l->n_dim = bounds[0]->n_dim;
+    if (n == 1) l->blocks_single = bounds[0]->K + bounds[0]->M;
     hipError_t e = hipMalloc((void**)&l->ptrs_dev, n * sizeof(double*));
     if (e == hipSuccess)
       e = hipMemcpy(l->ptrs_dev, ptrs.data(), n * sizeof(double*),
@@ -609,15 +611,17 @@ int nb_geom_list(const nb_boundlist* l, int32_t mode, const double* x,
     nb_set_error("nb_geom_list: empty list");
     return NB_ERR_ARG;
   }
-  return nb_launch_geom(l->dt, l->ptrs_dev, l->n, mode, x, n_rows,
-                        (const long long*)idx, n, pos, st, 0, 0,
+  return nb_launch_geom(l->dt, l->ptrs_dev, l->n, mode, l->blocks_single, x,
+                        n_rows, (const long long*)idx, n, pos, st, 0, 0,
                         as_stream(stream));
 }
 
 int nb_geom_sample(const nb_bound* b, uint64_t seed, uint64_t offset,
                    const double* x, int64_t n_rows, const int64_t* idx,
                    int64_t n, int32_t* pos, uint8_t* st, void* stream) {
-  return nb_launch_geom(b->dt, b->self_list_dev, 1, 2, x, n_rows,
+  // (a proposal of a one-member bound is not tested against that member)
+  return nb_launch_geom(b->dt, b->self_list_dev, 1, 2,
+                        (b->K == 1 ? 0 : b->K) + b->M, x, n_rows,
                         (const long long*)idx, n, pos, st, seed, offset,
                         as_stream(stream));
 }

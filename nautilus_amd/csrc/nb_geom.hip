@@ -16,6 +16,13 @@
 // bounds in the list; the geometric stage itself is HBM bound (8 D bytes per
 // point and pass, ellipsoid blocks from L2).
 //
+// A SINGLE bound (proposal acceptance, contains) whose ellipsoid blocks --
+// outer members and neural bounds -- fit into LDS together (7 blocks at
+// n_dim = 50) keeps them there for the whole launch: a workgroup stages them
+// once and then only streams points.  Staged per 128-point pass, the blocks
+// cost more L2 traffic than the points cost HBM traffic (22 KB per block and
+// pass against 51 KB of points at n_dim = 50).
+//
 // Workgroup = 8 wavefronts x one 16-point tile; an ellipsoid block (limits,
 // centre, lower-triangular 16x16 tiles of B_inv^T) is staged in LDS for the
 // 128 points of a pass and evaluated on v_mfma_f64_16x16x4_f64 like every
@@ -51,6 +58,7 @@ struct GeomArgs {
   unsigned char* st;            // per ROW: status
   unsigned long long seed, offset;
   unsigned long long* counters; // optional, as in nb_eval.hip
+  int resident;                 // single bound: all its blocks stay in LDS
 };
 
 // packed block in LDS: lo, hi, c (slot order), lower-triangular tiles
@@ -139,6 +147,24 @@ nb_geom_kernel(GeomArgs a) {
   const int n_dim = (int)nb_hdr((const double*)blob0, NB_H_NDIM);
   const long long n_pass = (a.n + 16 * GM_NW - 1) / (16 * GM_NW);
   unsigned long long cnt_outer = 0, cnt_ell = 0;
+  constexpr int BLK = GeomLds<DT>::TOTAL;
+  // resident blocks: [members (unless the proposals skip them)] [neural]
+  int res_members = 0;
+  if (a.resident) {
+    const double* hdr = (const double*)blob0;
+    const int K = (int)nb_hdr(hdr, NB_H_K);
+    const int M = (int)nb_hdr(hdr, NB_H_M);
+    res_members = (m_sample && K == 1) ? 0 : K;
+    const nb_gd* mblk = blob0 + nb_hdr(hdr, NB_H_OFF_MEMBERS);
+    const nb_gd* nblk = blob0 + nb_hdr(hdr, NB_H_OFF_NEURAL);
+    const long long ell_stride = nb_hdr(hdr, NB_H_ELL_STRIDE);
+    const long long neural_stride = nb_hdr(hdr, NB_H_NEURAL_STRIDE);
+    for (int j = 0; j < res_members; ++j)
+      geom_stage<DT>(mblk + j * ell_stride, lds + j * BLK);
+    for (int j = 0; j < M; ++j)
+      geom_stage<DT>(nblk + j * neural_stride, lds + (res_members + j) * BLK);
+    __syncthreads();
+  }
 
   for (long long pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
     const long long p = (pass * GM_NW + wave) * 16 + (lane & 15);
@@ -230,11 +256,16 @@ nb_geom_kernel(GeomArgs a) {
         const nb_gd* mblk = blob + nb_hdr(hdr, NB_H_OFF_MEMBERS);
         for (int m = 0; m < K; ++m) {
           const nb_gd* blk = mblk + m * ell_stride;
-          __syncthreads();
-          geom_stage<DT>(blk, lds);
-          __syncthreads();
+          const double* sblk = lds;
+          if (a.resident) {
+            sblk = lds + m * BLK;
+          } else {
+            __syncthreads();
+            geom_stage<DT>(blk, lds);
+            __syncthreads();
+          }
           const bool has_ell = ((const NB_G long long*)blk)[0] > 0;
-          k_cnt += geom_inside<DT>(lds, has_ell, n_dim, xin, lane) ? 1 : 0;
+          k_cnt += geom_inside<DT>(sblk, has_ell, n_dim, xin, lane) ? 1 : 0;
         }
         cnt_outer += (unsigned long long)K *
                      __popcll(__ballot(mine && lg == 0));
@@ -267,10 +298,15 @@ nb_geom_kernel(GeomArgs a) {
           const bool test = want && !found && m >= m_start;
           if (!__syncthreads_or(test ? 1 : 0)) continue;
           const nb_gd* nb_m = nblk0 + m * neural_stride;
-          __syncthreads();
-          geom_stage<DT>(nb_m, lds);
-          __syncthreads();
-          const bool inside = geom_inside<DT>(lds, true, n_dim, xin, lane);
+          const double* sblk = lds;
+          if (a.resident) {
+            sblk = lds + (res_members + m) * BLK;
+          } else {
+            __syncthreads();
+            geom_stage<DT>(nb_m, lds);
+            __syncthreads();
+          }
+          const bool inside = geom_inside<DT>(sblk, true, n_dim, xin, lane);
           cnt_ell += __popcll(__ballot(test && lg == 0));
           if (test && inside) {
             found = true;
@@ -309,23 +345,34 @@ nb_geom_kernel(GeomArgs a) {
   }
 }
 
+constexpr size_t GM_LDS_MAX = 160 * 1024 - 64;   // sh_min_b lives there too
+
 template <int DT>
-int launch_geom(const GeomArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)GeomLds<DT>::TOTAL * sizeof(double);
+int launch_geom(GeomArgs a, int n_blocks, hipStream_t stream) {
+  const size_t one = (size_t)GeomLds<DT>::TOTAL * sizeof(double);
   static bool configured = false;
   if (!configured) {
+    const size_t most = GM_LDS_MAX / one * one;
     const hipError_t e = hipFuncSetAttribute(
         (const void*)nb_geom_kernel<DT>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
     if (e != hipSuccess) {
-      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
+      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", most,
                    hipGetErrorString(e));
       return NB_ERR_HIP;
     }
     configured = true;
   }
   const long long n_pass = (a.n + 16 * GM_NW - 1) / (16 * GM_NW);
+  // Resident blocks pay when a workgroup sees several passes: one workgroup
+  // per CU then, staging once.  (Few passes: stage per pass, more
+  // workgroups.)
+  a.resident = (a.nb == 1 && n_blocks >= 1 &&
+                (size_t)n_blocks * one <= GM_LDS_MAX && n_pass >= 4 * 256)
+                   ? 1 : 0;
+  const size_t lds = a.resident ? (size_t)n_blocks * one : one;
   long long blocks = n_pass < 2048 ? n_pass : 2048;
+  if (a.resident) blocks = lds > 80 * 1024 ? 256 : 512;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((nb_geom_kernel<DT>), dim3((unsigned)blocks),
                      dim3(64 * GM_NW), lds, stream, a);
@@ -337,25 +384,26 @@ int launch_geom(const GeomArgs& a, hipStream_t stream) {
 unsigned long long* nb_eval_counters();
 
 int nb_launch_geom(int dt, const double* const* blobs_dev, int nb, int mode,
-                   const double* x, long long n_rows, const long long* idx,
-                   long long n, int* pos, unsigned char* st,
-                   unsigned long long seed, unsigned long long offset,
-                   hipStream_t stream) {
+                   int n_blocks, const double* x, long long n_rows,
+                   const long long* idx, long long n, int* pos,
+                   unsigned char* st, unsigned long long seed,
+                   unsigned long long offset, hipStream_t stream) {
   if (n <= 0 || nb <= 0) return NB_OK;
   GeomArgs a;
   a.blobs = blobs_dev; a.nb = nb; a.mode = mode; a.x = (const nb_gd*)x;
   a.idx = idx; a.n = n; a.n_rows = n_rows; a.pos = pos; a.st = st;
   a.seed = seed; a.offset = offset; a.counters = nb_eval_counters();
+  a.resident = 0;
   int rc = NB_OK;
   switch (dt) {
-    case 1: rc = launch_geom<1>(a, stream); break;
-    case 2: rc = launch_geom<2>(a, stream); break;
-    case 3: rc = launch_geom<3>(a, stream); break;
-    case 4: rc = launch_geom<4>(a, stream); break;
-    case 5: rc = launch_geom<5>(a, stream); break;
-    case 6: rc = launch_geom<6>(a, stream); break;
-    case 7: rc = launch_geom<7>(a, stream); break;
-    case 8: rc = launch_geom<8>(a, stream); break;
+    case 1: rc = launch_geom<1>(a, n_blocks, stream); break;
+    case 2: rc = launch_geom<2>(a, n_blocks, stream); break;
+    case 3: rc = launch_geom<3>(a, n_blocks, stream); break;
+    case 4: rc = launch_geom<4>(a, n_blocks, stream); break;
+    case 5: rc = launch_geom<5>(a, n_blocks, stream); break;
+    case 6: rc = launch_geom<6>(a, n_blocks, stream); break;
+    case 7: rc = launch_geom<7>(a, n_blocks, stream); break;
+    case 8: rc = launch_geom<8>(a, n_blocks, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;
