@@ -70,22 +70,52 @@ struct GeomLds {
   static constexpr int TOTAL = TILES + NT * NB_TILE;
 };
 
-// global ell block -> packed LDS block, whole workgroup, 16 bytes per lane
+// (row tile, k tile) of the p-th lower-triangular tile, p = ht (ht + 1) / 2 + kt
+struct TriTable {
+  unsigned char ht[36], kt[36];
+  constexpr TriTable() : ht(), kt() {
+    int p = 0;
+    for (int h = 0; h < 8; ++h)
+      for (int k = 0; k <= h; ++k) {
+        ht[p] = (unsigned char)h;
+        kt[p] = (unsigned char)k;
+        ++p;
+      }
+  }
+};
+__device__ constexpr TriTable TRI{};
+
+// global ell block -> packed LDS block, whole workgroup, 16 bytes per lane:
+// a quarter of the workgroup (128 threads) copies one 2 KB tile; all loads of
+// a round of 16 tiles are issued before the first store (the copy of a block
+// used to spend its time in index arithmetic and one load latency per tile)
 template <int DT>
 __device__ __forceinline__ void geom_stage(const nb_gd* blk, double* lds) {
   constexpr int DP = 16 * DT, NT = DT * (DT + 1) / 2;
-  for (int i = 2 * threadIdx.x; i < 3 * DP; i += 2 * 64 * GM_NW) {
-    const double2 v = *(const NB_G double2*)(blk + 2 + i);
-    *(double2*)(lds + i) = v;
+  const int tid = threadIdx.x;
+  if (2 * tid < 3 * DP) {
+    const double2 v = *(const NB_G double2*)(blk + 2 + 2 * tid);
+    *(double2*)(lds + 2 * tid) = v;
   }
-  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 2 * 64 * GM_NW) {
-    const int p = i / NB_TILE, e = i - p * NB_TILE;
-    int ht = 0;
-    while ((ht + 1) * (ht + 2) / 2 <= p) ++ht;
-    const int kt = p - ht * (ht + 1) / 2;
-    const double2 v = *(const NB_G double2*)(
-        blk + 2 + 3 * DP + (kt * DT + ht) * NB_TILE + e);
-    *(double2*)(lds + 3 * DP + i) = v;
+  const int g = tid >> 7, e = 2 * (tid & 127);
+  const nb_gd* src = blk + 2 + 3 * DP + e;
+  double* dst = lds + 3 * DP + e;
+  constexpr int ROUND = 4;                 // tiles per thread and round
+#pragma unroll
+  for (int p0 = 0; p0 < NT; p0 += 4 * ROUND) {
+    double2 v[ROUND];
+#pragma unroll
+    for (int j = 0; j < ROUND; ++j) {
+      const int p = p0 + 4 * j + g;
+      if (p < NT)
+        v[j] = *(const NB_G double2*)(
+            src + ((int)TRI.kt[p] * DT + (int)TRI.ht[p]) * NB_TILE);
+    }
+#pragma unroll
+    for (int j = 0; j < ROUND; ++j) {
+      const int p = p0 + 4 * j + g;
+      if (p < NT) *(double2*)(dst + p * NB_TILE) = v[j];
+    }
   }
 }
 
