@@ -5,6 +5,8 @@ path runs in the hand-written HIP kernels of ``libnautilus_hip.so``.
 """
 
 import ctypes as C
+import os
+import time
 
 import numpy as np
 import torch
@@ -307,6 +309,18 @@ GS_OUTER, GS_INSIDE, GS_PENDING, GS_DONE = 1, 2, 4, 8
 GS_NOT_PENDING = 0xFF ^ GS_PENDING
 
 
+TWO_STAGE_TIMES = {}      # NB_TWO_STAGE_TRACE=1: seconds per step (synchronous)
+_TS_TRACE = bool(os.environ.get('NB_TWO_STAGE_TRACE'))
+
+
+def _ts_mark(name, t0):
+    """Debugging aid: attribute GPU time to the steps of ``two_stage``."""
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    TWO_STAGE_TIMES[name] = TWO_STAGE_TIMES.get(name, 0.0) + t1 - t0
+    return t1
+
+
 def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
     """Bound evaluation in two stages (``nb_geom_*`` + ``nb_neural_score_rows``,
     include/nautilus_hip.h): the geometric tests of every point first, then
@@ -324,6 +338,8 @@ def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
     if n == 0 or len(bounds) == 0:
         return (st, 0, pos) if return_pos else (st, 0)
     idx, n_act = None, n
+    if _TS_TRACE:
+        t_mark = _ts_mark('setup', time.perf_counter())
     while True:
         if mode == GEOM_SAMPLE:
             _lib.check(lib.nb_geom_sample(
@@ -336,6 +352,8 @@ def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
                 _ptr(idx) if idx is not None else None, n_act, _ptr(pos),
                 _ptr(st), _stream()))
         DISPATCHES['nb_geom_kernel'] += 1
+        if _TS_TRACE:
+            t_mark = _ts_mark('geom', t_mark)
         sub = st if idx is None else st[idx]
         pend = torch.nonzero(sub & GS_PENDING).squeeze(1)
         if pend.numel() == 0:
@@ -355,6 +373,8 @@ def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
                          torch.float64, False)
         ok = torch.empty(pend.numel(), dtype=torch.bool, device='cuda')
         at = 0
+        if _TS_TRACE:
+            t_mark = _ts_mark('index lists', t_mark)
         for key, size in zip(groups, sizes):
             b, m = key >> 8, key & 255
             rows = pend[at:at + size]
@@ -363,6 +383,8 @@ def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
                 bounds[b]._h, m, 0 if mode == GEOM_SAMPLE else 1, _ptr(x),
                 _ptr(rows), size, _ptr(out), _stream()))
             DISPATCHES['nb_eval_fast_kernel'] += 1
+            if _TS_TRACE:
+                t_mark = _ts_mark('scores', t_mark)
             ok[at:at + size] = out[:, 1] > bounds[b].thresholds[m]
             at += size
         st[pend[ok]] = (st[pend[ok]] & GS_NOT_PENDING) | (GS_INSIDE | GS_DONE)
@@ -374,6 +396,8 @@ def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
             st[back] = (st[back] & GS_NOT_PENDING) | GS_DONE
             break
         idx, n_act = back.contiguous(), int(back.numel())
+        if _TS_TRACE:
+            t_mark = _ts_mark('flags', t_mark)
     return (st, n_need, pos) if return_pos else (st, n_need)
 
 

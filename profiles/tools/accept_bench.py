@@ -27,7 +27,7 @@ def glorot(rs, d):
     return Network(coefs, icpts)
 
 
-def build(d, k, e, seed=0):
+def build(d, k, e, seed=0, k_members=None, m_neural=None):
     rs = np.random.RandomState(seed)
     centres = 0.25 + 0.5 * rs.rand(k, d)
     members, neural = [], []
@@ -43,27 +43,48 @@ def build(d, k, e, seed=0):
             np.zeros(d), np.ones(d), [glorot(rs, d) for _ in range(e)])
         neural.append(nb.NeuralBound.from_parts(
             nb.Ellipsoid.from_params(c, B, B_inv, A), emu, 0.0))
+    members = members[:k_members or k]
+    neural = neural[:m_neural or k]
     outer = nb.Union.from_members(members, unit=True)
     outer.log_v_all = np.array([m.log_v for m in members])
     return nb.NautilusBound.from_parts(outer, neural,
                                        rng=np.random.default_rng(1))
 
 
-for d in (50, 100):
-    k = m = e = 4
-    bound = build(d, k, e)
+# arguments: D or D:K:M (default 50 100, K = M = 4); one process per
+# dimension gives the cleanest numbers (r03_kernels_prof.sh)
+CASES = [tuple(int(v) for v in a.split(':')) for a in sys.argv[1:]] or \
+    [(50,), (100,)]
+for case in CASES:
+    d = case[0]
+    k, m = (case[1], case[2]) if len(case) == 3 else (4, 4)
+    e = 4
+    bound = build(d, max(k, m), e, k_members=k, m_neural=m)
     dev = bound.device_bound()
     n = 1 << 20
     x = dev.propose(7, 0, n)
     dev.accept(7, 0, x)                      # warm-up
     reps = 5
+    device.TWO_STAGE_TIMES.clear()
     with device.EvalCounters() as counters:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        prof = None
+        if os.environ.get('NB_ACCEPT_CPROFILE'):
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         for r in range(reps):
             flags = dev.accept(7, 0, x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats('tottime').print_stats(12)
+        if device.TWO_STAGE_TIMES:
+            print({k: round(v / reps * 1e3, 3) for k, v in device.TWO_STAGE_TIMES.items()}, 'ms per call')
+            device.TWO_STAGE_TIMES.clear()
         work = counters.read()
     flops = ((work['outer_point_evals'] + work['ellipsoid_point_evals']) *
              d * (d + 1) + work['emulator_point_evals'] * 2.0 *

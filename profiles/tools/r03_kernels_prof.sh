@@ -8,12 +8,21 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 cd /tmp
-for name in stream_bench accept_bench; do
+for name in stream_bench; do
   rm -rf /tmp/p_$name
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -o p -- python $R/profiles/tools/$name.py > $OUT/$name.txt 2>&1
   find /tmp/p_$name -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/${name}_kernel_stats.csv
   grep -v amdgpu.ids $OUT/$name.txt | tail -12
 done
+# acceptance through the two stages, one process per case (D[:K:M])
+: > $OUT/accept_bench.txt
+for c in 50 100 50:2:4 50:3:3 20:4:4; do
+  rm -rf /tmp/p_acc
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_acc -o p -- python $R/profiles/tools/accept_bench.py $c > /tmp/acc.txt 2>&1
+  grep "^D=\|gathered" /tmp/acc.txt >> $OUT/accept_bench.txt
+  find /tmp/p_acc -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/accept_bench_${c//:/_}_kernel_stats.csv
+done
+cat $OUT/accept_bench.txt
 rm -rf /tmp/p_fast
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fast -o p -- python $R/profiles/tools/fast_time.py 50 64 100 128 > $OUT/fast_time.txt 2>&1
 find /tmp/p_fast -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/fast_time_kernel_stats.csv

@@ -327,6 +327,71 @@ def test_pipelined_accept_and_score(dev, d, e, k_outer):
             assert 0 < want.mean() < 1
 
 
+@pytest.mark.parametrize('d,k,m', [(20, 3, 2), (50, 2, 3)])
+def test_two_stage_large_launch(dev, d, k, m):
+    """Bounds with several outer members and several neural bounds go through
+    the two stages (nb_geom.hip + gathered scores).  A launch of more than
+    131 072 points of a single bound keeps all its ellipsoid blocks in LDS;
+    smaller ones stage them per pass: the flags of the same proposals must
+    not depend on the launch size, and both agree with the oracle
+    (union.py:305-327, nautilus.py:146-169 on the same Philox stream)."""
+    from oracle import bounds_oracle as bo
+    from oracle import mlp_oracle as mo
+    from oracle import philox
+    rng = np.random.default_rng(5 * d + k)
+    centres = 0.5 + 0.04 * rng.normal(size=(max(k, m), d))
+    members, neural = [], []
+    for j in range(max(k, m)):
+        b_mat = np.tril(rng.normal(size=(d, d)) * 0.01) + np.eye(d) * 0.2
+        ell = bo.OEllipsoid.from_params(centres[j], b_mat)
+        if j < k:
+            members.append(bo.OEllipsoid.from_params(centres[j],
+                                                     1.05 * b_mat))
+        if j < m:
+            nb = bo.ONeural()
+            nb.outer_bound, nb.n_dim = ell, d
+            nb.emulator = mo.Emulator.from_weights(
+                rng.normal(size=d) * 0.1, rng.uniform(0.5, 1.5, d),
+                [mo.glorot_init(d, 3 * j + i)[:2] for i in range(2)])
+            probe = centres[j] + (rng.normal(size=(2000, d)) @ b_mat.T) * (
+                0.7 / np.sqrt(d))
+            nb.score_predict_min = float(np.median(
+                nb.emulator.predict(ell.transform(probe))))
+            neural.append(nb)
+    outer = bo.OUnion.from_members(members, unit=True)
+    ob = bo.ONautilus.from_parts(outer, neural)
+    b = upload(ob)
+    seed, offset, n = 31 + d, 10**10 + 7, 150000
+    xd = b.propose(seed, offset, n)
+    big = b.accept(seed, offset, xd).cpu().numpy()
+    inside_big = b.contains(xd).cpu().numpy()
+    assert 0.01 < (big >> 1).mean() < 0.99
+    # the same proposals in launches below the residency threshold
+    for lo, hi in ((0, 4000), (70001, 90000), (n - 3000, n)):
+        part = b.accept(seed, offset + lo, xd[lo:hi].contiguous())
+        assert np.array_equal(part.cpu().numpy(), big[lo:hi])
+        assert np.array_equal(
+            b.contains(xd[lo:hi].contiguous()).cpu().numpy(),
+            inside_big[lo:hi])
+    # ... and the oracle on a slice
+    lo, hi = 20000, 32000
+    x, keep, _ = philox.union_propose(outer, seed, offset + lo, hi - lo)
+    assert np.allclose(xd[lo:hi].cpu().numpy(), x, rtol=0, atol=1e-12)
+    assert np.array_equal(big[lo:hi] & 1, keep.astype(np.uint8))
+    score_edge = np.zeros(hi - lo, dtype=bool)
+    for nb in neural:
+        y = nb.outer_bound.transform(x)
+        score_edge |= near_boundary(nb.emulator.predict(y),
+                                    nb.score_predict_min, 1e-9)
+        score_edge |= near_boundary(np.sum(y**2, axis=1), 1.0, 1e-12)
+    want = keep & ob.neural_contains(x)
+    assert np.array_equal((big[lo:hi] >> 1)[~score_edge],
+                          want.astype(np.uint8)[~score_edge])
+    want_in = ob.contains(x)
+    assert np.array_equal(inside_big[lo:hi][~score_edge],
+                          want_in[~score_edge])
+
+
 @pytest.fixture(scope='module')
 def nautilus_d4():
     from helpers import nautilus_from_golden
