@@ -175,25 +175,32 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
 }
 
 // Odd n_dim: rows are only 8-byte aligned, so the 16-byte row loads above are
-// not available.  A group of 32 points is still one contiguous, 16-byte
-// aligned block of 32 * D doubles: every wavefront DMAs its block into LDS
+// not available.  A group of 16 points is still one contiguous, 16-byte
+// aligned block of 16 * D doubles: every wavefront DMAs its block into LDS
 // (global_load_lds, fully coalesced, double buffered -- the next block is in
 // flight while the current one is multiplied) and gathers the B operands
 // from there; an odd row stride spreads the points over the LDS banks.
+// EIGHT wavefronts x one tile per workgroup: a wavefront has one block in
+// flight and waits for it before it computes, so the memory latency is
+// covered by the other wavefront of its SIMD (four wavefronts x two tiles:
+// 0.40 of the HBM peak at n_dim = 49).
 typedef const void __attribute__((address_space(1))) * nbs_gptr;
 typedef void __attribute__((address_space(3))) * nbs_lptr;
 
+constexpr int ODD_TPW = 1;     // tiles per wavefront
+constexpr int ODD_NW = 8;      // wavefronts per workgroup
+
 template <int DT, int KL, bool SMALL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * ODD_NW)
 nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
                          const double* __restrict__ tiles, int n_dim,
                          const double* __restrict__ x, long long n,
                          unsigned char* __restrict__ mask, int bufsz) {
-  constexpr int TPW = 2;
+  constexpr int TPW = ODD_TPW;
   constexpr int NT = DT * (DT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* wl = lds;
-  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 512)
+  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 2 * 64 * ODD_NW)
     *(double2*)(wl + i) = *(const double2*)(tiles + i);
   __syncthreads();
 
@@ -213,8 +220,8 @@ nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
   }
 
   const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
-  const long long g0 = (long long)blockIdx.x * 4 + wave;
-  const long long gstep = (long long)gridDim.x * 4;
+  const long long g0 = (long long)blockIdx.x * ODD_NW + wave;
+  const long long gstep = (long long)gridDim.x * ODD_NW;
   auto issue = [&](long long grp, int b) {
     const long long base = grp * blk;
     for (int c = 0; c < blk; c += 128) {
@@ -265,8 +272,9 @@ int launch_odd(const double* cvec, const double* tiles, int n_dim,
                const double* x, long long n, unsigned char* mask,
                hipStream_t stream) {
   constexpr int NT = DT * (DT + 1) / 2;
-  const int bufsz = (32 * n_dim + 127) & ~127;
-  const size_t lds = ((size_t)NT * NB_TILE + 8 * (size_t)bufsz) * sizeof(double);
+  const int bufsz = (16 * ODD_TPW * n_dim + 127) & ~127;
+  const size_t lds = ((size_t)NT * NB_TILE + 2 * ODD_NW * (size_t)bufsz) *
+                     sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
     if (hipFuncSetAttribute((const void*)nb_ell_stream_odd_kernel<DT, KL, SMALL>,
@@ -278,12 +286,12 @@ int launch_odd(const double* cvec, const double* tiles, int n_dim,
     allowed = lds;
   }
   (void)hipGetLastError();
-  const long long n_groups = (n + 31) / 32;
-  long long blocks = (n_groups + 3) / 4;
+  const long long n_groups = (n + 16 * ODD_TPW - 1) / (16 * ODD_TPW);
+  long long blocks = (n_groups + ODD_NW - 1) / ODD_NW;
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((nb_ell_stream_odd_kernel<DT, KL, SMALL>),
-                     dim3((unsigned)blocks), dim3(256), lds, stream, cvec,
+                     dim3((unsigned)blocks), dim3(64 * ODD_NW), lds, stream, cvec,
                      tiles, n_dim, x, n, mask, bufsz);
   return NB_OK;
 }
@@ -296,8 +304,9 @@ int launch_variant(const double* cvec, const double* tiles, int n_dim,
     if ((n_dim & 1) && n >= 64)
       return launch_odd<DT, KL, SMALL>(cvec, tiles, n_dim, x, n, mask, stream);
   }
-  // 4 tiles per wavefront while the operands fit the register file
-  constexpr int TPW = (DT <= 4) ? 4 : 2;
+  // 4 tiles per wavefront while the operands fit the register file, one
+  // beyond 96 dimensions (two tiles of 28 slots spill 26-42 registers)
+  constexpr int TPW = (DT <= 4) ? 4 : (DT <= 6 ? 2 : 1);
   const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
   long long blocks = (n_groups + 3) / 4;
   if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
