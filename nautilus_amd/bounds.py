@@ -31,7 +31,7 @@ from .emulator import NeuralNetworkEmulator
 import os as _os
 # debugging aids: NB_FILL_TRACE=1 prints one line per refill launch and per
 # trained emulator to stderr; NB_DUMP_COLLAPSE=<file.npz> saves the training
-# set of the first emulator whose whole ensemble died (dev/collapse_check.py)
+# set of the first emulator whose whole ensemble died (tests/tools/collapse_check.py)
 _FILL_TRACE = bool(_os.environ.get('NB_FILL_TRACE'))
 MIN_DRAW = 1 << 14          # proposals per launch, lower limit
 MAX_DRAW = 1 << 22          # upper limit (bounds the scratch memory)
@@ -689,7 +689,7 @@ class NeuralBound(_DeviceBoundBase):
                                for n in emu.neural_networks]),
                           file=sys.stderr, flush=True)
                     # the training set of a dead ensemble, for
-                    # dev/collapse_check.py
+                    # tests/tools/collapse_check.py
                     dump = _os.environ.get('NB_DUMP_COLLAPSE')
                     if dump and self.emulator_dead and \
                             not _os.path.exists(dump):

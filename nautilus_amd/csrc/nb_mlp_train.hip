@@ -64,7 +64,7 @@ __device__ __forceinline__ double ld_xcd(const nb_gd* p) {
 // ((c / 8) * 64 + ((c / 2) % 4) * 16 + r) * 2 + c % 2 -- one 16-byte load per
 // lane and PAIR of k-steps, 1 KB contiguous per wavefront.  A CU's texture
 // path moves ~26 B / clk with 8-byte and ~53 B / clk with 16-byte loads per
-// lane (dev/l2_read_bench.hip), and the forward / backward phase is made of
+// lane (profiles/tools/l2_read_bench.hip), and the forward / backward phase is made of
 // waiting for exactly these operands.
 __host__ __device__ constexpr int tile_index(int c, int r) {
   return ((c >> 3) * 64 + ((c >> 1) & 3) * 16 + r) * 2 + (c & 1);
