@@ -455,6 +455,9 @@ def main():
         t0 = time.time()
         for _ in range(args.steps):
             step()
+        # (sharded runs: the points of the last batches are still on their
+        # way to the other ranks -- part of the steps' work)
+        sampler.land_points()
         torch.cuda.synchronize()
         dt = time.time() - t0
     roctx_region(False)

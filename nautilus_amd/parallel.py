@@ -13,7 +13,9 @@ The MI355X version of it:
   own Philox stream (key mixed with the rank) and evaluates the likelihood
   for it;
 * ONE ``all_gather`` per batch moves the accepted points (+ their log L) to
-  every rank -- equal counts, so no padding -- and one ``all_reduce`` adds the
+  every rank -- equal counts, so no padding; in the sampling phase, where
+  nothing reads the points before the run ends, the log L travel at once and
+  the points asynchronously behind the next batches -- and one ``all_reduce`` adds the
   integer counters (``n_bound`` and the four MC-volume counters) that the
   evidence depends on (sampler.py:1133, nautilus.py:232-237).  A batch that
   pairs fresh points with transfer candidates (sampler.py:803-819) gathers
@@ -41,6 +43,20 @@ def rank_key(seed, rank):
     return (int(seed) ^ ((rank * _MIX) & (2**63 - 1))) & (2**63 - 1)
 
 
+class _Gathered:
+    """A gather in flight (input kept alive until it has landed)."""
+
+    def __init__(self, work, out, rows):
+        self.work, self.out, self.rows = work, out, rows
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.rows = None
+        return self.out
+
+
 class ShardedComm:
     """Thin wrapper of the collectives the sampler needs."""
 
@@ -65,6 +81,22 @@ class ShardedComm:
         else:
             dist.all_gather_into_tensor(out, rows, group=self.group)
         return out
+
+    def gather_rows_async(self, rows):
+        """``gather_rows`` without waiting: returns a handle whose ``wait()``
+        gives the gathered tensor (and makes the current stream wait for the
+        collective, not the host).  The sampling phase moves its points this
+        way -- 8 D bytes per point to every rank, the bulk of a batch's
+        traffic, and nothing needs them before the run ends -- while the
+        next batches are drawn (sampler.py, ``_sharded_batch``)."""
+        rows = rows.contiguous()
+        if rows.is_cuda and dist.get_backend(self.group) == 'gloo':
+            return _Gathered(None, self.gather_rows(rows), rows)
+        out = torch.empty((self.world * rows.shape[0],) + tuple(rows.shape[1:]),
+                          dtype=rows.dtype, device=rows.device)
+        work = dist.all_gather_into_tensor(out, rows, group=self.group,
+                                           async_op=True)
+        return _Gathered(work, out, rows)
 
     def sum_ints(self, values, device):
         """Element-wise sum of a short list of python ints over all ranks."""

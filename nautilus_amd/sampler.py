@@ -60,6 +60,15 @@ class _Grow:
         self.data[self.n:self.n + k] = rows
         self.n += k
 
+    def reserve(self, k):
+        """Room for ``k`` rows that land later (``Sampler.land_points``);
+        returns the index of the first.  NaN until then."""
+        start = self.n
+        self.append(torch.full((k,) + tuple(self.data.shape[1:]),
+                               float('nan'), dtype=torch.float64,
+                               device='cuda'))
+        return start
+
     def keep(self, mask):
         kept = self.data[:self.n][mask]
         self.data = kept.clone()
@@ -71,6 +80,16 @@ class _Grow:
     def __setstate__(self, state):
         self.data = torch.from_numpy(state['data']).cuda()
         self.n = state['n']
+
+
+class _RowsInFlight:
+    """Points of a sharded batch whose all-gather has not landed yet."""
+
+    def __init__(self, handle, total):
+        self.handle, self.total = handle, total
+
+
+MAX_IN_FLIGHT = 4        # gathers of points a rank keeps pending
 
 
 class Sampler:
@@ -159,6 +178,7 @@ class Sampler:
         self.explored = False
         self.bounds = []
         self._pts = []           # per shell: _Grow (n, n_dim) on the device
+        self._in_flight = []     # (shell, first row, gather handle)
         self._ll_dev = []        # per shell: _Grow (n,) on the device
         self.log_l = []          # per shell: numpy mirror of log_l
         self.blobs = None        # per shell: numpy (structured) arrays
@@ -193,10 +213,12 @@ class Sampler:
     # caches are rebuilt lazily, tensors travel as numpy arrays)
     # ------------------------------------------------------------------
     def __getstate__(self):
+        self.land_points()
         state = dict(self.__dict__)
         state['_later'] = {}
         state['_live'] = None
         state['comm'] = None
+        state['_in_flight'] = []
         state['_pts_t'] = self._pts_t.cpu().numpy()
         return state
 
@@ -210,6 +232,7 @@ class Sampler:
     @property
     def points(self):
         """Per-shell points as numpy arrays (reference attribute)."""
+        self.land_points()
         return [p.view().cpu().numpy() for p in self._pts]
 
     @property
@@ -413,6 +436,7 @@ class Sampler:
                 if self._writes_checkpoints():
                     self.write_shell_update(self.filepath, shell)
             done = finished()
+        self.land_points()
         if verbose:
             self.print_status('Finished' if done else 'Stopped')
         return done
@@ -686,7 +710,14 @@ class Sampler:
             else:
                 log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
         t2 = time()
-        self._pts[shell].append(pts)
+        if isinstance(pts, _RowsInFlight):
+            # sharded sampling phase: the rows are on their way to this rank
+            first = self._pts[shell].reserve(pts.total)
+            self._in_flight.append((shell, first, pts.handle))
+            while len(self._in_flight) > MAX_IN_FLIGHT:
+                self._land(self._in_flight.pop(0))
+        else:
+            self._pts[shell].append(pts)
         self._ll_dev[shell].append(log_l_dev)
         if self.explored:
             self._live = None      # log_v_live rebuilds it from the shells
@@ -744,10 +775,28 @@ class Sampler:
                 k += 1
         return totals[:n_extra]
 
+    def _land(self, entry):
+        shell, first, handle = entry
+        rows = handle.wait()
+        self._pts[shell].data[first:first + rows.shape[0]] = rows
+
+    def land_points(self):
+        """Wait for the points of sharded batches that are still travelling
+        (see ``_sharded_batch``); collective in effect -- every rank issued
+        the same gathers.  ``run()`` ends with it."""
+        pending = self.__dict__.get('_in_flight')
+        while pending:
+            self._land(pending.pop(0))
+
     def _sharded_batch(self, shell):
         """One batch spread over all ranks: local draw + likelihood, ONE
         all-gather of the accepted points with their log L, one all-reduce
-        of the integer counters."""
+        of the integer counters.  In the sampling phase of a run without
+        checkpoints nothing reads the points before the run ends (no bound is
+        built any more): the log L are gathered at once -- the shell
+        statistics need them -- and the points, 8 D of the 8 (D + 1) bytes per
+        row, by an asynchronous all-gather that lands behind the next batches
+        (``land_points``)."""
         from . import parallel
         comm = self.comm
         bound = self._rank_keyed(self.bounds[shell])
@@ -760,6 +809,16 @@ class Sampler:
             raise NotImplementedError(
                 'blobs are not exchanged between ranks of a sharded run')
         self.n_like = n_like0
+        if self.explored and self.filepath is None:
+            # (collectives of one communicator run in the order of issue: the
+            # small ones this batch waits for go first, the points last --
+            # they have the next batch's draw and evaluation to get through)
+            ll_dev = comm.gather_rows(ll_dev[:, None])[:, 0].contiguous()
+            n_bound, = self._sum_counters(bound, before, [n_bound])
+            handle = comm.gather_rows_async(pts)
+            self.n_like += ll_dev.shape[0]
+            return (_RowsInFlight(handle, ll_dev.shape[0]),
+                    ll_dev.cpu().numpy(), ll_dev, n_bound)
         packed = torch.cat([pts, ll_dev[:, None]], dim=1)
         gathered = comm.gather_rows(packed)
         n_bound, = self._sum_counters(bound, before, [n_bound])
@@ -952,6 +1011,7 @@ class Sampler:
         """sampler.py:541-647."""
         if return_blobs and self.blobs is None:
             raise ValueError('No blobs have been calculated.')
+        self.land_points()
         if return_as_dict is None:
             return_as_dict = bool(callable(self.prior) and self.pass_dict)
         if self._discard_exploration and self.explored:
@@ -1012,6 +1072,7 @@ class Sampler:
 
     def shell_bound_occupation(self, fractional=True):
         """sampler.py:1223-1251."""
+        self.land_points()
         m = np.zeros((len(self.bounds), len(self.bounds)), dtype=int)
         for i, p in enumerate(self._pts):
             for k, b in enumerate(self.bounds):

@@ -51,6 +51,15 @@ def _worker(rank, world, port, out_dir):
     for g in range(4):
         assert np.array_equal(total[g].numpy(),
                               np.random.default_rng(g).normal(size=5))
+    # gathers in flight land in the order they were issued (the points of
+    # the sharded sampling phase), interleaved with a synchronous collective
+    h1 = comm.gather_rows_async(rows)
+    h2 = comm.gather_rows_async(2.0 * rows)
+    again = comm.gather_rows(log_l[:, None])[:, 0]
+    assert torch.equal(again, all_ll)
+    assert torch.equal(h1.wait(), all_rows)
+    assert torch.equal(h2.wait(), 2.0 * all_rows)
+    assert torch.equal(h1.wait(), all_rows)          # idempotent
     # collective stop decision: true everywhere if true anywhere
     assert comm.any_flag(rank == 1) is True
     assert comm.any_flag(False) is False
