@@ -840,8 +840,15 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 // (s_waitcnt) and a consumer to drop its CU's L1 (buffer_inv): no L2
 // write-back, and the barrier is one atomic in that L2.
 // ---------------------------------------------------------------------------
+// s_sleep between two polls of a barrier counter, in units of 64 clocks: 16
+// when more than four networks train at once (the polls of eight busy XCDs
+// get into each other's way: 3 us per step), 6 for up to four (half a
+// microsecond less barrier latency per step)
 #ifndef NB_POLL_SLEEP
 #define NB_POLL_SLEEP 16
+#endif
+#ifndef NB_POLL_SLEEP_FEW
+#define NB_POLL_SLEEP_FEW 6
 #endif
 constexpr int XCD_COUNT = 8;
 constexpr int XCD_SLOTS = 32;            // workgroups per network: one per CU
@@ -870,13 +877,14 @@ __device__ __forceinline__ void xcd_arrive(int* counter) {
 // round trip.)  The barrier behind the poll orders LDS traffic only; no cache
 // is invalidated -- the data that crosses CUs is read with ld_xcd.
 __device__ __forceinline__ void xcd_wait(int* counter, int* err, int& phase,
-                                         int n_wg) {
+                                         int n_wg, bool few) {
   if (threadIdx.x == 0) {
     const int target = (++phase) * n_wg;
     int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(NB_POLL_SLEEP);
+      if (few) __builtin_amdgcn_s_sleep(NB_POLL_SLEEP_FEW);
+      else __builtin_amdgcn_s_sleep(NB_POLL_SLEEP);
       if (++spins > SYNC_LIMIT) {
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -887,9 +895,9 @@ __device__ __forceinline__ void xcd_wait(int* counter, int* err, int& phase,
 }
 
 __device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
-                                            int n_wg) {
+                                            int n_wg, bool few) {
   xcd_arrive(counter);
-  xcd_wait(counter, err, phase, n_wg);
+  xcd_wait(counter, err, phase, n_wg, few);
 }
 
 // networks of the XCDs: up to two per XCD (two workgroups per CU), -1 = none
@@ -953,6 +961,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   const int arrival = __builtin_amdgcn_readfirstlane(sh_slot);
   if (arrival >= XCD_SLOTS) return;
   const bool two = map.net[xcd][1] >= 0;
+  const bool few = n_nets <= 4;          // few pollers: poll more often
   const int slots = two ? XCD_SLOTS / 2 : XCD_SLOTS;
   const int which = two ? arrival / slots : 0;
   const int net = map.net[xcd][which];
@@ -974,7 +983,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // multiplied by zero weights and must not hold NaN bit patterns); every
   // step rewrites exactly the rows it fills
   for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
-  xcd_barrier(counter, err, phase, slots);
+  xcd_barrier(counter, err, phase, slots, few);
   // the Adam step counter lives with the network (epoch_body keeps it)
   long long t_adam = (long long)ld_xcd(&st.scal[0]);
   FbRows<KT1> rows;
@@ -1031,7 +1040,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
       // (the step size -- two pow() -- is computed while waiting)
       xcd_arrive(counter);
       const double lr_t = adam_lr(a, t_adam);
-      xcd_wait(counter, err, phase, slots);
+      xcd_wait(counter, err, phase, slots, few);
       TR_STAMP(2);
       // jobs slot, slot + 32, ... of the G phase (all 32 CUs of the XCD take
       // part, also the ones without a row tile in FB; the host's job list
@@ -1058,7 +1067,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
           fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
       }
       TR_STAMP(3);
-      xcd_barrier(counter, err, phase, slots);
+      xcd_barrier(counter, err, phase, slots, few);
       TR_STAMP(4);
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
@@ -1066,7 +1075,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
     }
     if (done) continue;
     if (slot == 0 && threadIdx.x == 0) epoch_body(a, st, n, t_adam);
-    xcd_barrier(counter, err, phase, slots);
+    xcd_barrier(counter, err, phase, slots, few);
   }
 }
 
