@@ -618,9 +618,10 @@ __device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) 
 // layer -- k-tiles kt0 .. kt0 + nk - 1, output tiles ht0 .. ht0 + nh - 1 --
 // whose gradients share their operand columns: the nk activation column
 // blocks and the nh delta column blocks are read once for the nk * nh tiles.
-// (A CU gets ~16 bytes per clock out of the L2 when everything misses its L1,
-// as it does behind a barrier: the bytes a workgroup pulls per step are what
-// the phase costs.  One tile per job reads two column blocks per tile, a
+// (A CU gets 26 bytes per clock out of the L2 with 8-byte loads per lane when
+// everything misses its L1, as it does behind a barrier
+// (profiles/tools/l2_read_bench.hip): the bytes a workgroup pulls per step are
+// what the phase costs.  One tile per job reads two column blocks per tile, a
 // 2 x 2 block one.)  The job list is built by the host (g_jobs) so that one
 // round of 32 workgroups covers a network for every n_dim.
 constexpr int G_JOB_INTS = 5;     // layer (0..3), kt0, nk, ht0, nh
