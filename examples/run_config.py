@@ -32,6 +32,12 @@ def main():
     ap.add_argument('--counters', action='store_true',
                     help='point-evaluation counters of the bound kernels and '
                          'HIP-event time per kernel family')
+    ap.add_argument('--keep-exploration', action='store_true',
+                    help='the reference\'s default: the points of the '
+                         'exploration phase count (discard_exploration=False)')
+    ap.add_argument('--progress', default=None,
+                    help='append one JSON line per new bound (and per 50 '
+                         'sampling batches) to this file')
     ap.add_argument('--watchdog', type=float, default=0,
                     help='dump the Python stack and exit after this many '
                          'seconds (debugging aid)')
@@ -47,11 +53,40 @@ def main():
                 n_batch=args.n_batch or c['n_batch'],
                 vectorized=True, seed=args.seed)
     extra = {}
+    discard = not args.keep_exploration
+    if args.progress:
+        calls = dict(add_samples=0)
+
+        def note(kind):
+            with open(args.progress, 'a') as f:
+                f.write(json.dumps(dict(
+                    t=round(time.time() - t0, 1), kind=kind,
+                    n_bounds=len(s.bounds), explored=bool(s.explored),
+                    log_z=float(s.log_z), n_eff=float(s.n_eff),
+                    f_live=float(s.f_live) if not s.explored else 0.0,
+                    n_like=int(s.n_like), n_dead=int(s.n_dead_bounds),
+                    train_s=round(s.timing.get('bound_neural', 0.0), 1),
+                    shell_s=round(s.timing.get('sample_shell', 0.0), 1))) +
+                    '\n')
+        add_bound, add_samples = s.add_bound, s.add_samples
+
+        def add_bound_logged(*a, **k):
+            out = add_bound(*a, **k)
+            note('bound')
+            return out
+
+        def add_samples_logged(*a, **k):
+            out = add_samples(*a, **k)
+            calls['add_samples'] += 1
+            if s.explored and calls['add_samples'] % 50 == 0:
+                note('samples')
+            return out
+        s.add_bound, s.add_samples = add_bound_logged, add_samples_logged
     if args.counters:
         from nautilus_amd import device
         with device.EvalCounters() as counters, \
                 device.KernelTimer() as timer:
-            ok = s.run(n_eff=args.n_eff, discard_exploration=True,
+            ok = s.run(n_eff=args.n_eff, discard_exploration=discard,
                        timeout=args.timeout)
             torch.cuda.synchronize()
             wall = time.time() - t0
@@ -59,16 +94,26 @@ def main():
                 k: dict(launches=v['launches'], s=round(v['ms'] / 1e3, 2))
                 for k, v in timer.totals().items()})
     else:
-        ok = s.run(n_eff=args.n_eff, discard_exploration=True,
+        ok = s.run(n_eff=args.n_eff, discard_exploration=discard,
                    timeout=args.timeout)
         torch.cuda.synchronize()
         wall = time.time() - t0
-    pts, log_w, _ = s.posterior()
-    w = np.exp(log_w)
-    mean = np.average(pts, weights=w, axis=0)
+    # posterior mean of the first three parameters, on the device (config 5
+    # holds ~10^7 points of 100 dimensions; Sampler.posterior would bring them
+    # all to the host): weights as in Sampler.posterior (sampler.py:602-608)
+    s.land_points()
+    start = (s.shell_end_exp if s._discard_exploration and s.explored
+             else np.zeros(len(s.log_l), dtype=int))
+    offset = s.shell_log_v - np.log(np.maximum(s.shell_n, 1))
+    num = torch.zeros(3, dtype=torch.float64, device='cuda')
+    for p, ll, st, o in zip(s._pts, s._ll_dev, start, offset):
+        w = torch.exp(ll.view()[st:] + float(o) - float(s.log_z))
+        num += (p.view()[st:, :3] * w[:, None]).sum(0)
+    mean = num.cpu().numpy()
     print(json.dumps(dict(
         config=args.name, finished=bool(ok), wall_s=round(wall, 2),
         n_batch=args.n_batch or c['n_batch'],
+        discard_exploration=discard, explored=bool(s.explored),
         log_z=float(s.log_z), analytic_log_z=c['analytic_log_z'],
         n_eff=float(s.n_eff), n_like=int(s.n_like), n_bounds=len(s.bounds),
         n_neural_last=len(s.bounds[-1].neural_bounds),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 3
+#define NB_ABI_VERSION 4
 
 typedef struct nb_bound nb_bound;          /* opaque bound living in HBM     */
 typedef struct nb_boundlist nb_boundlist;  /* device array of bound pointers */
@@ -247,6 +247,28 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
 /* Wait for the launches enqueued by nb_trainer_run(..., status_host = NULL)
  * and read the per-network status (same encoding).                          */
 int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream);
+/* Pipelined form of the two above: enqueue a chunk of epochs (a fleet's
+ * arguments; a plain trainer passes the same training set n_networks times)
+ * together with an asynchronous copy of its status words to pinned host
+ * memory, and collect the status of ticket k later -- while chunk k + 1 is
+ * already queued behind it, so the GPU never waits for the host between
+ * chunks.  A network that stops inside chunk k skips chunk k + 1 on the
+ * device.  At most 4 tickets may be outstanding.                             */
+int nb_trainer_run_async(nb_trainer* t, const int32_t* const* perm_dev_of,
+                         int32_t n_epochs, void* stream, int64_t* ticket);
+int nb_trainer_wait(nb_trainer* t, int64_t ticket, int32_t* status_host);
+/* Host helper (no device work): the minibatch orders scikit-learn draws
+ * before every epoch -- sklearn.utils.shuffle = numpy's legacy
+ * RandomState.shuffle on MT19937, composed epoch after epoch
+ * (_multilayer_perceptron.py:700-704; reached from neural.py:79-98) -- for
+ * n_streams independent generator states (key_of[s]: the 624 words and pos[s]
+ * the position of RandomState.get_state(), both advanced in place), one host
+ * thread per stream.  order_of[s] (n_of[s] entries, in/out) is the current
+ * order, out_of[s] receives n_epochs x n_of[s] orders; streams with a NULL
+ * out_of[s] are skipped.                                                     */
+int nb_host_shuffle_epochs(int32_t n_streams, uint32_t* const* key_of,
+                           int32_t* pos, const int64_t* n_of, int32_t n_epochs,
+                           int32_t* const* order_of, int32_t* const* out_of);
 int nb_trainer_loss_curve(nb_trainer* t, int32_t net, double* out_host,
                           int32_t max_len);
 int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs_host,
@@ -364,8 +386,6 @@ int nb_loglike_funnel(const double* u_dev, int64_t n, int32_t n_dim, double mu,
                       double sigma0, double k, double c, double* out_dev,
                       void* stream);
 
-/* Debugging aid: print the native backtrace on SIGABRT / SIGSEGV.           */
-int nb_debug_install_abort_trace(void);
 
 /* Two-stage evaluation of bounds with several outer members, several neural
  * bounds, or of lists of bounds (bounds/union.py:285-289, 316-319;

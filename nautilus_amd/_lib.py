@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NAUTILUS_HIP_LIB') or os.path.join(
     _HERE, 'lib', 'libnautilus_hip.so')
 
+# NB_ABI_VERSION of include/nautilus_hip.h this binding was written against
+ABI_VERSION = 4
+
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 
@@ -89,6 +92,12 @@ _SIGNATURES = {
     'nb_trainer_run': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
                                  c_int32_p, C.c_void_p]),
     'nb_trainer_status': (C.c_int, [C.c_void_p, c_int32_p, C.c_void_p]),
+    'nb_trainer_run_async': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.POINTER(C.c_int64)]),
+    'nb_trainer_wait': (C.c_int, [C.c_void_p, C.c_int64, c_int32_p]),
+    'nb_host_shuffle_epochs': (C.c_int, [C.c_int32, C.c_void_p, c_int32_p,
+                                         C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p]),
     'nb_trainer_loss_curve': (C.c_int, [C.c_void_p, C.c_int32, c_double_p,
                                         C.c_int32]),
     'nb_trainer_weights': (C.c_int, [C.c_void_p, C.c_int32,
@@ -154,7 +163,6 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     'nb_comm_allreduce_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
-    'nb_debug_install_abort_trace': (C.c_int, []),
     'nb_geom_list': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
@@ -197,10 +205,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.nb_abi_version() != 3:
-        raise RuntimeError('nautilus_amd: ABI version mismatch')
-    if os.environ.get('NB_ABORT_TRACE'):
-        lib.nb_debug_install_abort_trace()
+    if lib.nb_abi_version() != ABI_VERSION:
+        raise RuntimeError(
+            'nautilus_amd: %s has ABI version %d, this package binds version '
+            '%d (rebuild with `make`)' % (LIB_PATH, lib.nb_abi_version(),
+                                          ABI_VERSION))
     _lib = lib
     return lib
 

@@ -37,6 +37,17 @@ MIN_DRAW = 1 << 14          # proposals per launch, lower limit
 MAX_DRAW = 1 << 22          # upper limit (bounds the scratch memory)
 DEAD_MARGIN = 5e-3          # loss within this of the constant predictor's
 MAX_BARREN = 256            # launches of MAX_DRAW without one accepted point
+# measured guard of the pre-fill: after GUARD_LAUNCHES launches of MAX_DRAW
+# proposals in one refill with an acceptance below GUARD_ACCEPTANCE the bound
+# is reported barren (BarrenBound) -- an ensemble with one marginally alive
+# network passes the loss test of NeuralBound.compute_many and resets the
+# MAX_BARREN counter with every stray accepted point
+GUARD_LAUNCHES = 64
+GUARD_ACCEPTANCE = 1e-7
+
+
+class BarrenBound(RuntimeError):
+    """A bound whose rejection sampler accepts (next to) nothing."""
 
 
 def _default_rng(rng):
@@ -404,6 +415,7 @@ class _RejectionSampler(_DeviceBoundBase):
     def _fill(self, n_points):
         q = self._queue()
         barren = 0
+        full_launches = full_accepted = 0
         while len(q) < n_points:
             need = n_points - len(q)
             acc = max(self._acceptance(), 1e-7)
@@ -418,10 +430,19 @@ class _RejectionSampler(_DeviceBoundBase):
             barren = barren + 1 if int(c[1]) == 0 and n_draw == MAX_DRAW \
                 else 0
             if barren >= MAX_BARREN:
-                raise RuntimeError(
+                raise BarrenBound(
                     'the bound accepted none of %d proposals (%d inside its '
                     'ellipsoids): its emulator rejects everything' %
                     (barren * MAX_DRAW, int(c[0])))
+            if n_draw == MAX_DRAW:
+                full_launches += 1
+                full_accepted += int(c[1])
+                if full_launches >= GUARD_LAUNCHES and full_accepted < \
+                        GUARD_ACCEPTANCE * full_launches * MAX_DRAW:
+                    raise BarrenBound(
+                        'the bound accepted %d of %d proposals: its emulators '
+                        'reject (next to) everything' %
+                        (full_accepted, full_launches * MAX_DRAW))
             if _FILL_TRACE:
                 import sys
                 dev = self.device_bound()

@@ -594,10 +594,11 @@ static void nb_abort_trace(int sig) {
   raise(sig);
 }
 
-int nb_debug_install_abort_trace(void) {
+// (not an export: installed when the library is loaded with NB_ABORT_TRACE set)
+__attribute__((constructor)) static void nb_install_abort_trace(void) {
+  if (getenv("NB_ABORT_TRACE") == nullptr) return;
   signal(SIGABRT, nb_abort_trace);
   signal(SIGSEGV, nb_abort_trace);
-  return NB_OK;
 }
 
 int nb_geom_list(const nb_boundlist* l, int32_t mode, const double* x,

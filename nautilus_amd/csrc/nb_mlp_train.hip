@@ -1163,6 +1163,15 @@ struct nb_trainer {
   bool two_launch = false;         // fall back to two launches per step
   XcdMap xcd_map;                  // XCDs owned by this trainer's networks
   unsigned xcd_owned = 0;
+  // nb_trainer_run_async / nb_trainer_wait: the status words of a chunk of
+  // epochs travel to pinned host memory behind that chunk, so that the next
+  // chunk can be enqueued before the host has seen them
+  static constexpr int RING = 4;
+  long long per_net = 0;
+  double* pin_scal = nullptr;      // RING x E x 8
+  int* pin_sync = nullptr;         // RING x SYNC_INTS
+  hipEvent_t ring_event[RING] = {};
+  long long n_tickets = 0;
 };
 
 extern "C" {
@@ -1224,6 +1233,7 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
   const long long curve = t->max_iter;
   const long long per_net = 3 * t->n_w + WT_DOUBLES + stash + curve + 32;
+  t->per_net = per_net;
   const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
   hipError_t e = hipMalloc((void**)&t->pool, bytes);
   if (e == hipSuccess) e = hipMemset(t->pool, 0, bytes);
@@ -1240,8 +1250,11 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
       e = hipMemcpy(t->jobs_dev, jobs.data(), jobs.size() * sizeof(int),
                     hipMemcpyHostToDevice);
   }
+  // (NB_TRAIN_NO_RESIDENT: the library-side switch only, for the test of the
+  // host's fallback when the resident kernel is not to be had)
   t->two_launch = n_networks > MAX_RESIDENT ||
                   getenv("NB_TRAIN_TWO_LAUNCH") != nullptr ||
+                  getenv("NB_TRAIN_NO_RESIDENT") != nullptr ||
                   !xcd_pinning_available();
   // A resident network takes one workgroup slot on every CU of an XCD (of two
   // per CU).  Every trainer owns its XCDs exclusively -- two resident kernels
@@ -1487,6 +1500,68 @@ int nb_trainer_status(nb_trainer* t, int32_t* status_host, void* stream) {
   return NB_OK;
 }
 
+int nb_trainer_run_async(nb_trainer* t, const int32_t* const* perm_dev_of,
+                         int32_t n_epochs, void* stream, int64_t* ticket) {
+  hipStream_t s = (hipStream_t)stream;
+  if (t->pin_scal == nullptr) {
+    NB_HIP_CHECK(hipHostMalloc((void**)&t->pin_scal,
+                               (size_t)nb_trainer::RING * t->E * 8 *
+                                   sizeof(double), hipHostMallocDefault));
+    NB_HIP_CHECK(hipHostMalloc((void**)&t->pin_sync,
+                               (size_t)nb_trainer::RING * SYNC_INTS *
+                                   sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < nb_trainer::RING; ++i)
+      NB_HIP_CHECK(hipEventCreateWithFlags(&t->ring_event[i],
+                                           hipEventDisableTiming));
+  }
+  const int rc = nb_trainer_run_fleet(t, perm_dev_of, n_epochs, nullptr, stream);
+  if (rc != NB_OK) return rc;
+  const int slot = (int)(t->n_tickets % nb_trainer::RING);
+  // the scal blocks of all networks sit per_net doubles apart in the pool
+  NB_HIP_CHECK(hipMemcpy2DAsync(
+      t->pin_scal + (size_t)slot * t->E * 8, 8 * sizeof(double),
+      (const void*)t->nets_host[0].scal, (size_t)t->per_net * sizeof(double),
+      8 * sizeof(double), (size_t)t->E, hipMemcpyDeviceToHost, s));
+  NB_HIP_CHECK(hipMemcpyAsync(t->pin_sync + (size_t)slot * SYNC_INTS,
+                              t->sync_dev, SYNC_INTS * sizeof(int),
+                              hipMemcpyDeviceToHost, s));
+  NB_HIP_CHECK(hipEventRecord(t->ring_event[slot], s));
+  *ticket = t->n_tickets++;
+  return NB_OK;
+}
+
+int nb_trainer_wait(nb_trainer* t, int64_t ticket, int32_t* status_host) {
+  // (a slot is reused RING tickets later)
+  if (ticket < 0 || ticket >= t->n_tickets ||
+      t->n_tickets > ticket + nb_trainer::RING) {
+    nb_set_error("nb_trainer_wait: ticket %lld is not in flight (next %lld, "
+                 "ring of %d)", (long long)ticket, (long long)t->n_tickets,
+                 nb_trainer::RING);
+    return NB_ERR_ARG;
+  }
+  const int slot = (int)(ticket % nb_trainer::RING);
+  NB_HIP_CHECK(hipEventSynchronize(t->ring_event[slot]));
+  if (!t->two_launch) {
+    const int* sync = t->pin_sync + (size_t)slot * SYNC_INTS;
+    for (int i = 0; i < t->E; ++i)
+      if (sync[SYNC_WORDS * i + 1] != 0) {
+        nb_set_error("resident training kernel failed for network %d (%s); "
+                     "set NB_TRAIN_TWO_LAUNCH=1 to train with two launches "
+                     "per step", i,
+                     sync[SYNC_WORDS * i + 1] == 2
+                         ? "its workgroups do not share an XCD"
+                         : "barrier timeout");
+        return NB_ERR_HIP;
+      }
+  }
+  const double* scal = t->pin_scal + (size_t)slot * t->E * 8;
+  for (int i = 0; i < t->E; ++i) {
+    const int n_iter = (int)scal[8 * i + 3];
+    status_host[i] = (scal[8 * i + 4] != 0.0) ? -n_iter : n_iter;
+  }
+  return NB_OK;
+}
+
 int nb_trainer_loss_curve(nb_trainer* t, int32_t net, double* out_host,
                           int32_t max_len) {
   if (net < 0 || net >= t->E) { nb_set_error("bad net index"); return NB_ERR_ARG; }
@@ -1537,6 +1612,10 @@ int nb_trainer_destroy(nb_trainer* t) {
   if (t->nets_dev) (void)hipFree(t->nets_dev);
   if (t->sync_dev) (void)hipFree(t->sync_dev);
   if (t->jobs_dev) (void)hipFree(t->jobs_dev);
+  if (t->pin_scal) (void)hipHostFree(t->pin_scal);
+  if (t->pin_sync) (void)hipHostFree(t->pin_sync);
+  for (int i = 0; i < nb_trainer::RING; ++i)
+    if (t->ring_event[i]) (void)hipEventDestroy(t->ring_event[i]);
   delete t;
   return NB_OK;
 }

@@ -23,6 +23,7 @@ from . import _lib, device
 HIDDEN = (100, 50, 20)
 EPOCH_CHUNK = 16     # epochs per kernel launch (host prepares the next chunk
                      # of shuffles while the GPU trains)
+CHUNK_BYTES = 32 << 20   # ... fewer where a chunk's orders would exceed this
 
 
 class Network:
@@ -126,6 +127,26 @@ class Trainer:
                 status if sync else None, stream))
         self._perms = getattr(self, '_perms', [])[-1:] + [perms_dev]
         return np.array(status[:]) if sync else None
+
+    def run_async(self, perms_dev, offsets, n_epochs):
+        """Enqueue ``n_epochs`` epochs whose orders sit in the int32 cuda
+        tensor ``perms_dev`` (network i from element offsets[i]); returns the
+        ticket for ``wait`` (``nb_trainer_run_async``)."""
+        ptrs = (C.c_void_p * self.e)(*[
+            perms_dev.data_ptr() + 4 * int(o) for o in offsets])
+        ticket = C.c_int64()
+        _lib.check(self._lib.nb_trainer_run_async(
+            self._h, ptrs, n_epochs,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream),
+            C.byref(ticket)))
+        return ticket.value
+
+    def wait(self, ticket):
+        """Per-network status behind the chunk of ``ticket`` (n_iter, negative
+        once stopped); later chunks may still be queued."""
+        status = (C.c_int32 * self.e)()
+        _lib.check(self._lib.nb_trainer_wait(self._h, ticket, status))
+        return np.array(status[:])
 
     def status(self):
         """Wait for the enqueued epochs; per-network n_iter (negative once
@@ -270,10 +291,58 @@ class NeuralNetworkEmulator:
         return state
 
 
+class _ShuffleStreams:
+    """The per-network minibatch orders of scikit-learn's fit loop
+    (_multilayer_perceptron.py:700-704: ``sample_idx = shuffle(sample_idx,
+    random_state=self._random_state)`` before every epoch): numpy's legacy
+    MT19937 ``RandomState.shuffle``, composed epoch after epoch.  The states
+    are taken over from the ``RandomState`` objects that drew the initial
+    weights and advanced by ``nb_host_shuffle_epochs`` (one native thread per
+    network; bit for bit numpy's stream, tests/test_host_logic.py)."""
+
+    def __init__(self, states, ns):
+        self._lib = _lib.load()
+        self.e = len(states)
+        self.ns = [int(n) for n in ns]
+        self.keys, self.pos = [], (C.c_int32 * self.e)()
+        for i, rs in enumerate(states):
+            kind, key, pos = rs.get_state()[:3]
+            assert kind == 'MT19937'
+            self.keys.append(np.ascontiguousarray(key, dtype=np.uint32).copy())
+            self.pos[i] = int(pos)
+        self.orders = [np.arange(n, dtype=np.int32) for n in self.ns]
+        self.offsets = np.concatenate([[0], np.cumsum(self.ns)[:-1]])
+
+    def fill(self, out, n_epochs, active):
+        """Write the next ``n_epochs`` orders of every active network into the
+        flat int32 array ``out`` (network i at offsets[i] * n_epochs); inactive
+        networks keep their generator where it is and repeat their order."""
+        e = self.e
+        key_p = (C.c_void_p * e)(*[k.ctypes.data for k in self.keys])
+        ord_p = (C.c_void_p * e)(*[o.ctypes.data for o in self.orders])
+        n_of = (C.c_int64 * e)(*self.ns)
+        out_p = (C.c_void_p * e)()
+        base = out.ctypes.data
+        for i in range(e):
+            at = int(self.offsets[i]) * n_epochs
+            if active[i]:
+                out_p[i] = base + 4 * at
+            else:
+                out_p[i] = None
+                out[at:at + n_epochs * self.ns[i]].reshape(
+                    n_epochs, self.ns[i])[:] = self.orders[i]
+        _lib.check(self._lib.nb_host_shuffle_epochs(
+            e, key_p, self.pos, n_of, n_epochs, ord_p, out_p))
+
+
 class _TrainJob:
     """Networks in flight -- one ensemble, or a fleet of several ensembles
     with a training set each -- : the trainer, the per-network shuffle
-    streams and the bookkeeping of the chunked epoch loop."""
+    streams and the bookkeeping of the chunked epoch loop.  Two chunks of
+    epochs are kept in flight: chunk k + 1 is enqueued (its orders drawn and
+    uploaded) before the status of chunk k is read, so the GPU does not wait
+    for the host between chunks; a network that stops inside chunk k skips
+    chunk k + 1 on the device."""
 
     def __init__(self, members, hparams, max_epochs, stream):
         """``members``: list of dicts (xs, y, seeds, permutations, init), one
@@ -281,15 +350,18 @@ class _TrainJob:
         self.members = members
         self.stream = stream
         d = members[0]['xs'].shape[1]
-        self.owner, self.states, self.perm_src = [], [], []
+        self.owner, states, self.perm_src = [], [], []
         xs, ys, nets0 = [], [], []
         for k, m in enumerate(members):
             for j, seed in enumerate(m['seeds']):
                 rs = np.random.RandomState(seed)
                 init = m.get('init')
-                nets0.append(_glorot(d, rs) if init is None else init[j])
+                # (the Glorot draw always advances the stream, as in
+                # scikit-learn, also when the weights are then replaced)
+                drawn = _glorot(d, rs)
+                nets0.append(drawn if init is None else init[j])
                 self.owner.append(k)
-                self.states.append(rs)
+                states.append(rs)
                 perms = m.get('permutations')
                 self.perm_src.append(None if perms is None else perms[j])
                 xs.append(m['xs'])
@@ -303,58 +375,86 @@ class _TrainJob:
         self.max_iter = (hparams or {}).get('max_iter', 10000)
         if max_epochs is not None:
             self.max_iter = min(self.max_iter, max_epochs)
-        self.orders = [np.arange(n) for n in self.ns]
+        self.shuffles = _ShuffleStreams(states, self.ns)
+        # epochs per launch: EPOCH_CHUNK, fewer where the orders of a chunk
+        # would exceed CHUNK_BYTES (config 5: 8 networks x 2 x 10^5 rows)
+        per_epoch = 4 * sum(self.ns)
+        self.chunk = int(max(2, min(EPOCH_CHUNK, CHUNK_BYTES // per_epoch)))
         self.status = np.zeros(self.e, dtype=int)
         self.done_epochs = 0
-        self.in_flight = False
+        self.tickets = []            # chunks in flight (oldest first)
         self.finished = False
+        self._ring = []              # (pinned host orders, device orders)
+
+    def _buffers(self, n_items):
+        """Pinned host / device buffers of a chunk; a slot is reused once its
+        chunk has been waited for (at most three are alive)."""
+        if len(self._ring) < 3:
+            pin = torch.empty(n_items, dtype=torch.int32,
+                              pin_memory=torch.cuda.is_available())
+            dev = torch.empty(n_items, dtype=torch.int32, device='cuda')
+            self._ring.append((pin, dev))
+            return pin, dev
+        slot = self._ring.pop(0)
+        self._ring.append(slot)
+        if slot[0].numel() < n_items:
+            raise RuntimeError('chunk larger than the first one')
+        return slot
 
     def next_chunk(self):
-        """Shuffles of the next chunk of epochs (host work that overlaps with
-        the GPU training the previous chunk), or None."""
-        chunk = min(EPOCH_CHUNK, self.max_iter - self.done_epochs)
+        """Orders of the next chunk of epochs as (pinned flat int32 tensor,
+        device tensor, epochs), or None.  Host work that overlaps with the GPU
+        training the chunks in flight."""
+        chunk = min(self.chunk, self.max_iter - self.done_epochs)
         if chunk <= 0:
             return None
-        out = []
+        pin, dev = self._buffers(self.chunk * sum(self.ns))
+        out = pin.numpy()
+        active = [self.status[i] >= 0 and self.perm_src[i] is None
+                  for i in range(self.e)]
+        self.shuffles.fill(out, chunk, active)
         for i in range(self.e):
-            n = self.ns[i]
-            perms = np.zeros((chunk, n), dtype=np.int32)
-            for ep in range(chunk):
-                if self.perm_src[i] is not None:
-                    self.orders[i] = np.asarray(
+            if self.perm_src[i] is not None:         # orders given (tests)
+                at = int(self.shuffles.offsets[i]) * chunk
+                rows = out[at:at + chunk * self.ns[i]].reshape(chunk,
+                                                               self.ns[i])
+                for ep in range(chunk):
+                    rows[ep] = np.asarray(
                         self.perm_src[i][self.done_epochs + ep])
-                elif self.status[i] >= 0:
-                    # sklearn.utils.shuffle: permutations compose
-                    # (_multilayer_perceptron.py:700-704)
-                    idx = np.arange(n)
-                    self.states[i].shuffle(idx)
-                    self.orders[i] = self.orders[i][idx]
-                perms[ep] = self.orders[i]
-            out.append(perms)
-        return out if self.fleet else np.stack(out)
+        return pin, dev, chunk
 
     def step(self):
-        """Prepare the next chunk, collect the status of the chunk in flight,
-        enqueue the next one.  Returns False once all networks are done."""
+        """Enqueue the next chunk behind the one in flight, then collect the
+        status of the oldest.  Returns False once all networks are done."""
         if self.finished:
             return False
-        perms = self.next_chunk()
+        nxt = self.next_chunk() if np.any(self.status >= 0) else None
         with torch.cuda.stream(self.stream):
-            if self.in_flight:
-                self.status = self.trainer.status()
-                self.in_flight = False
-            if perms is None or not np.any(self.status >= 0):
-                self.finished = True
-                return False
-            self.trainer.run(perms, sync=False)
-        self.in_flight = True
-        self.done_epochs += perms[0].shape[0] if self.fleet \
-            else perms.shape[1]
+            if nxt is not None:
+                pin, dev, chunk = nxt
+                n_items = chunk * sum(self.ns)
+                dev[:n_items].copy_(pin[:n_items], non_blocking=True)
+                self.tickets.append(self.trainer.run_async(
+                    dev, self.shuffles.offsets * chunk, chunk))
+                self.done_epochs += chunk
+            # the chunk just enqueued stays queued behind the one whose
+            # status is read now; with nothing new, everything is collected
+            keep = 1 if nxt is not None else 0
+            while len(self.tickets) > keep:
+                self.status = self.trainer.wait(self.tickets.pop(0))
+            if not np.any(self.status >= 0):
+                # all stopped: the queued chunk exits at once on the device
+                while self.tickets:
+                    self.status = self.trainer.wait(self.tickets.pop(0))
+        if not self.tickets:
+            self.finished = True
+            return False
         return True
 
     def release(self):
         """Destroy the trainer (frees its XCDs and device buffers)."""
         self.trainer.close()
+        self._ring = []
 
     def results(self):
         """One (networks, stats) pair per ensemble."""
@@ -430,8 +530,22 @@ def train_ensembles(jobs):
         size += e
     fleets.append(cur)
     for keys in fleets:
-        finish(_TrainJob([jobs[k] for k in keys], jobs[0].get('hparams'),
-                         jobs[0].get('max_epochs'), main), keys)
+        try:
+            job = _TrainJob([jobs[k] for k in keys], jobs[0].get('hparams'),
+                            jobs[0].get('max_epochs'), main)
+        except RuntimeError as err:
+            # A fleet (several training sets in one trainer) needs the
+            # resident kernel; where that is not to be had -- the XCD
+            # placement probe fails on this GPU / partition mode, or other
+            # live trainers hold the XCDs -- every ensemble gets a trainer of
+            # its own, which can fall back to two launches per step.
+            if len(keys) == 1 or 'different training sets' not in str(err):
+                raise
+            for k in keys:
+                finish(_TrainJob([jobs[k]], jobs[k].get('hparams'),
+                                 jobs[k].get('max_epochs'), main), [k])
+            continue
+        finish(job, keys)
     return out
 
 

@@ -33,7 +33,7 @@ import torch
 from scipy.special import logsumexp
 
 from . import device, geometry
-from .bounds import NautilusBound, UnitCube
+from .bounds import BarrenBound, NautilusBound, UnitCube
 from .pool import NautilusPool, likelihood_worker
 
 
@@ -915,27 +915,43 @@ class Sampler:
                         n_networks=self.n_networks,
                         neural_network_kwargs=self.neural_network_kwargs,
                         pool=self.pool_s, rng=self.rng, comm=self.comm)
-                    if bound.emulators_dead:
+                    barren = bound.emulators_dead
+                    if barren:
                         pass
                     elif self.comm is None:
-                        bound.sample(1000, return_points=False)
+                        try:
+                            bound.sample(1000, return_points=False)
+                        except BarrenBound:
+                            # measured: the pre-fill accepted next to nothing
+                            barren = True
                     else:
                         # the pre-fill behind the first volume estimate
-                        # (sampler.py:1032), a share per rank
+                        # (sampler.py:1032), a share per rank; every rank
+                        # takes part in both collectives whatever it measured
                         before = self._counters(self._rank_keyed(bound))
-                        bound.sample(-(-1000 // self.comm.world),
-                                     return_points=False)
+                        try:
+                            bound.sample(-(-1000 // self.comm.world),
+                                         return_points=False)
+                        except BarrenBound:
+                            barren = True
                         self._sum_counters(bound, before)
+                        barren = bool(self.comm.any_flag(barren))
                 for key, val in bound.timing.items():
                     self.timing[key] = self.timing.get(key, 0.0) + val
-                if bound.emulators_dead:
+                if barren:
                     # Deviation: every network of an ensemble ended no
-                    # better than a constant, so the bound accepts nothing
-                    # and the reference would never return from the pre-fill
-                    # (nautilus.py:217-240).  Treated like a bound that fails
-                    # to shrink (sampler.py:1034): the last bound is filled
-                    # for another n_update points and the next attempt trains
-                    # on the larger set.
+                    # better than a constant (or the pre-fill measured an
+                    # acceptance below 1e-7 over 2.7 x 10^8 proposals): the
+                    # bound accepts next to nothing, and the reference's
+                    # pre-fill (nautilus.py:217-240) would take from hours
+                    # to for ever.  (With an exactly constant emulator the
+                    # reference's threshold, bounds/neural.py:121-126, falls
+                    # 1e-9 below the prediction and the bound degenerates to
+                    # its ellipsoid instead -- a behaviour change, not only a
+                    # hang fix.)  Treated like a bound that fails to shrink
+                    # (sampler.py:1034): the last bound is filled for another
+                    # n_update points and the next attempt trains on the
+                    # larger set.
                     self.n_dead_bounds += 1
                     ok = False
                 else:

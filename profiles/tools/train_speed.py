@@ -1,31 +1,42 @@
-"""Wall time per Adam step of the resident training kernel, host overhead of
-the first chunk (shuffles, upload, launch) removed by differencing a long and
-a short run of the same networks."""
-import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
-from nautilus_amd import emulator
+"""Emulator training speed (nb_mlp_train.hip + the host's shuffle streams):
+microseconds per Adam step of the slowest network of an ensemble, (a)
+differenced (a long minus a short run: the kernel alone) and (b) over a whole
+fit as the sampler sees it (host start-up, shuffles, uploads, status reads
+included).  python profiles/tools/train_speed.py [--big]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))))
+import torch  # noqa: E402
+from nautilus_amd import emulator  # noqa: E402
+
+CASES = [(50, 24000, 4), (20, 8000, 4), (100, 24000, 8), (30, 30000, 4),
+         (50, 2000, 4)]
+if '--big' in sys.argv:
+    # config-5 size: 8 networks x 2 x 10^5 rows (the host's shuffles used to
+    # take longer than the GPU's epochs there)
+    CASES = [(100, 200000, 8), (50, 180000, 4)]
 
 
-def run(X, y, e, ne):
+def fit(x, y, e, n_epochs):
     torch.cuda.synchronize()
     t = time.perf_counter()
-    emulator.train_networks(X, y, list(range(e)), max_epochs=ne,
+    emulator.train_networks(x, y, list(range(e)), max_epochs=n_epochs,
                             hparams=dict(n_iter_no_change=100000))
     torch.cuda.synchronize()
     return time.perf_counter() - t
 
 
-for d, nrow, e in [(50, 24000, 4), (20, 8000, 4), (100, 24000, 8),
-                   (30, 30000, 4), (50, 2000, 4)]:
-    X = torch.randn((nrow, d), dtype=torch.float64, device='cuda')
-    y = torch.rand(nrow, dtype=torch.float64, device='cuda')
-    run(X, y, e, 2)
-    short, long_ = 32, 160
-    t0 = min(run(X, y, e, short) for _ in range(2))
-    t1 = min(run(X, y, e, long_) for _ in range(2))
-    per_epoch = (nrow + 199) // 200
-    print('D=%d E=%d n=%d: %.2f us/step (differenced), %.2f us/step incl. '
-          'host start-up over %d epochs' % (
-              d, e, nrow, (t1 - t0) / ((long_ - short) * per_epoch) * 1e6,
-              t1 / (long_ * per_epoch) * 1e6, long_), flush=True)
+for d, n_row, e in CASES:
+    x = torch.randn((n_row, d), dtype=torch.float64, device='cuda')
+    y = torch.rand(n_row, dtype=torch.float64, device='cuda')
+    fit(x, y, e, 2)
+    steps = (n_row + 199) // 200
+    short, long_ = (16, 64) if n_row >= 100000 else (32, 160)
+    t_s, t_l = fit(x, y, e, short), fit(x, y, e, long_)
+    print('D=%d E=%d n=%d: %.2f us/step (differenced), %.2f us/step over a '
+          'whole fit of %d epochs' % (
+              d, e, n_row, (t_l - t_s) / ((long_ - short) * steps) * 1e6,
+              t_l / (long_ * steps) * 1e6, long_), flush=True)

@@ -894,6 +894,34 @@ def test_emulator_full_fit_equals_sklearn(dev, name, e):
                        atol=1e-11)
 
 
+def test_fleet_falls_back_without_the_resident_kernel(dev, monkeypatch):
+    """Two ensembles with a training set each are packed into one fleet
+    trainer, which needs the resident kernel.  Where the library cannot
+    provide it (XCD placement probe fails, XCDs held by another trainer --
+    forced here with the library-side switch NB_TRAIN_NO_RESIDENT, which the
+    Python side does not know) every ensemble falls back to a trainer of its
+    own with two launches per step, and the networks are the same."""
+    from nautilus_amd import emulator
+    rng = np.random.default_rng(4)
+    jobs = []
+    for n, d in [(700, 6), (450, 6)]:
+        x = rng.normal(size=(n, d))
+        y = rng.random(n)
+        jobs.append(dict(xs=torch.from_numpy(x).cuda(),
+                         y=torch.from_numpy(y).cuda(), seeds=[0, 1],
+                         max_epochs=4))
+    fleet = emulator.train_ensembles([dict(j) for j in jobs])
+    monkeypatch.setenv('NB_TRAIN_NO_RESIDENT', '1')
+    alone = emulator.train_ensembles([dict(j) for j in jobs])
+    for (nets_a, st_a), (nets_b, st_b) in zip(fleet, alone):
+        assert st_a['n_iter'] == st_b['n_iter'] == [4, 4]
+        for a, b in zip(nets_a, nets_b):
+            assert np.allclose(a.loss_curve_, b.loss_curve_, rtol=1e-9)
+            for k in range(4):
+                assert np.allclose(a.coefs_[k], b.coefs_[k], rtol=0,
+                                   atol=1e-9)
+
+
 def test_emulator_full_training_quality(dev):
     """Reference tests/test_neural.py:6-15: RMSE < 0.3 std on the 5-D radial
     rank target; stopping epoch in the reference's range."""

@@ -249,3 +249,36 @@ def test_rosenbrock_exact_evidence_helper():
                                     (1 - x[..., 0])**2))))
     assert abs(rosenbrock_log_z_exact(2, 1000) - brute) < 1e-10
     assert abs(rosenbrock_log_z_exact(30, 1000) - (-137.4875)) < 1e-4
+
+
+def test_native_shuffle_streams_equal_numpy():
+    """``nb_host_shuffle_epochs`` (the minibatch orders of the emulator fits,
+    one native thread per network) against the calls it replaces: numpy's
+    legacy ``RandomState.shuffle`` composed epoch after epoch, as
+    sklearn.utils.shuffle does inside MLPRegressor.fit
+    (_multilayer_perceptron.py:700-704) -- bit for bit, across chunks, with
+    an inactive stream left where it is."""
+    from nautilus_amd.emulator import _ShuffleStreams
+    ns = [1000, 37, 70001, 1, 2]
+    states = [np.random.RandomState(i) for i in range(len(ns))]
+    ref = [np.random.RandomState(i) for i in range(len(ns))]
+    for rs in states + ref:
+        rs.uniform(-1, 1, (50, 100))         # the Glorot draw comes first
+    orders = [np.arange(n) for n in ns]
+    sh = _ShuffleStreams(states, ns)
+    n_ep = 3
+    for rnd in range(3):
+        active = [True] * len(ns)
+        if rnd == 1:
+            active[2] = False                # stopped network
+        out = np.full(n_ep * sum(ns), -1, dtype=np.int32)
+        sh.fill(out, n_ep, active)
+        for i, n in enumerate(ns):
+            at = int(sh.offsets[i]) * n_ep
+            rows = out[at:at + n_ep * n].reshape(n_ep, n)
+            for ep in range(n_ep):
+                if active[i]:
+                    idx = np.arange(n)
+                    ref[i].shuffle(idx)
+                    orders[i] = orders[i][idx]
+                assert np.array_equal(rows[ep], orders[i]), (rnd, i, ep)

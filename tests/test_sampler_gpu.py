@@ -647,5 +647,53 @@ def test_barren_bound_fails_loudly(monkeypatch):
     b._dev = None                            # upload again
     monkeypatch.setattr(bounds, 'MAX_BARREN', 2)
     monkeypatch.setattr(bounds, 'MAX_DRAW', bounds.MIN_DRAW)
-    with pytest.raises(RuntimeError, match='accepted none'):
+    with pytest.raises(bounds.BarrenBound, match='accepted none'):
         b.sample(10)
+
+
+def test_measured_barren_bound_is_dropped(monkeypatch):
+    """An ensemble that is only marginally alive passes the loss test of
+    NeuralBound.compute_many and accepts a stray point now and then (seen: 1
+    in 4 x 10^6), which resets the MAX_BARREN counter.  The measured guard --
+    acceptance below GUARD_ACCEPTANCE after GUARD_LAUNCHES full launches of one
+    refill -- raises BarrenBound, and the sampler drops such a bound like a
+    dead one."""
+    from nautilus_amd import GaussianLikelihood, Sampler, bounds, unit_prior
+    rng = np.random.default_rng(0)
+    pts = 0.5 + 0.05 * rng.normal(size=(4000, 3))
+    log_l = -np.sum((pts - 0.5)**2, axis=1)
+    b = bounds.NautilusBound.compute(
+        pts, log_l, np.sort(log_l)[-400], np.log(0.01), n_networks=1,
+        rng=np.random.default_rng(1))
+    # a threshold that lets a few proposals in 10^5 through
+    x = b.outer_bound.sample(200000)
+    score = b.neural_bounds[0].emulator.predict(
+        b.neural_bounds[0].outer_bound.transform(x))
+    for nb in b.neural_bounds:
+        nb.score_predict_min = float(np.sort(score)[-4])
+    b._dev = None
+    monkeypatch.setattr(bounds, 'MAX_DRAW', bounds.MIN_DRAW)
+    monkeypatch.setattr(bounds, 'GUARD_LAUNCHES', 8)
+    monkeypatch.setattr(bounds, 'GUARD_ACCEPTANCE', 1e-3)
+    with pytest.raises(bounds.BarrenBound, match='next to'):
+        b.sample(1000)
+    # ... and inside a run: the bound is dropped, the run goes on
+    analytic, ref_lz = _reference_band()
+    like = GaussianLikelihood(MU, np.eye(3) * 0.01, normalised=False)
+    s = Sampler(unit_prior, like, n_dim=3, n_live=400, n_networks=1,
+                vectorized=True, seed=0, n_batch=400)
+    made = []
+    real = bounds.NeuralBound.compute_many.__func__
+
+    def compute_many(cls, *args, **kwargs):
+        out = real(cls, *args, **kwargs)
+        made.append(out)
+        if len(made) == 2:
+            for nb in out:
+                nb.score_predict_min = 10.0      # alive by its loss, barren
+        return out
+    monkeypatch.setattr(bounds.NeuralBound, 'compute_many',
+                        classmethod(compute_many))
+    assert s.run(n_eff=2000, discard_exploration=True) is True
+    assert s.n_dead_bounds == 1
+    assert abs(s.log_z - analytic) < max(0.03, 4 * np.std(ref_lz))
