@@ -57,13 +57,24 @@ def main():
     if args.progress:
         calls = dict(add_samples=0)
 
+        def train_stats(bound):
+            nbs = getattr(bound, 'neural_bounds', [])
+            emu = nbs[0].emulator if nbs else None
+            st = getattr(emu, 'trainer_stats', None) or {}
+            return dict(n_train=st.get('n_rows'), n_iter=st.get('n_iter'),
+                        n_neural=len(nbs))
+
         def note(kind):
             with open(args.progress, 'a') as f:
                 f.write(json.dumps(dict(
                     t=round(time.time() - t0, 1), kind=kind,
                     n_bounds=len(s.bounds), explored=bool(s.explored),
-                    log_z=float(s.log_z), n_eff=float(s.n_eff),
-                    f_live=float(s.f_live) if not s.explored else 0.0,
+                    log_z=None if s.log_z is None else float(s.log_z),
+                    n_eff=float(s.n_eff or 0.0),
+                    f_live=float(s.f_live) if not s.explored and
+                    s.log_z is not None else None,
+                    log_v=float(s.bounds[-1].log_v),
+                    **train_stats(s.bounds[-1]),
                     n_like=int(s.n_like), n_dead=int(s.n_dead_bounds),
                     train_s=round(s.timing.get('bound_neural', 0.0), 1),
                     shell_s=round(s.timing.get('sample_shell', 0.0), 1))) +
