@@ -282,7 +282,7 @@ def cpu_baseline(sampler, like_numpy, seconds, cores):
 
 def pmc_traffic(argv):
     """HBM bytes of the bound-evaluation kernels (nb_eval_fast_kernel,
-    nb_geom_kernel) over the timed region of this very command: two child
+    nb_cand_kernel) over the timed region of this very command: two child
     runs under ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE need separate
     passes on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"; FETCH_SIZE
     counts 64 B per 128-B request of wide loads -> x 2).  The timed region's
@@ -502,15 +502,15 @@ def main():
                                got['write_bytes_per_launch'],
                                got['launches']))
     roofline = dict(
-        kernel='nb_eval_fast_kernel (+ nb_geom_kernel)', kernel_note=(
+        kernel='nb_eval_fast_kernel (+ nb_cand_kernel)', kernel_note=(
             'bound evaluation of the timed steps: proposal acceptance in '
             'nb_eval_fast_kernel (fused cube test, ellipsoid, emulators); '
-            'shell exclusion against one or two later bounds = nb_geom_kernel '
-            '(geometric tests) + nb_eval_fast_kernel on the gathered points '
-            'that reach an emulator, against longer lists = nb_eval_kernel '
-            '(walks the list inside the kernel); calls and HIP-event time '
-            'are those of all of them, kernel_dispatches and the PMC traffic '
-            'those of the first two'),
+            'shell exclusion against the later bounds (any number) = '
+            'nb_cand_kernel (geometric tests of every point against the whole '
+            'list, candidate lists per (bound, neural bound)) + ONE batched '
+            'nb_eval_fast_kernel launch over all candidates; calls and '
+            'HIP-event time are those of whole queries, kernel_dispatches '
+            'counts the launches of each kernel'),
         bound='mfma', achieved=achieved_tf,
         peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
         frac=achieved_tf / FP64_MFMA_PEAK_TF, traffic=traffic,

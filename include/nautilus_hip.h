@@ -389,34 +389,45 @@ int nb_loglike_funnel(const double* u_dev, int64_t n, int32_t n_dim, double mu,
 
 /* Two-stage evaluation of bounds with several outer members, several neural
  * bounds, or of lists of bounds (bounds/union.py:285-289, 316-319;
- * bounds/nautilus.py:162-169, 212-222; sampler.py:797-798, 1213-1219).
+ * bounds/nautilus.py:162-169, 212-222; sampler.py:797-798, 1213-1219),
+ * entirely on the device -- no host round trip between the stages:
  *
- * Stage 1, nb_geom_*: everything that needs no emulator -- periodic
+ * Stage 1 (nb_cand.hip): everything that needs no emulator -- periodic
  * recentring, unit-cube clip, overlap count of the outer members, acceptance
- * draw, the ellipsoids of the neural bounds.  Per ROW of x two arrays (zeroed
- * by the caller before the first call) hold the state:
- *   st[row]  bit 0 kept by the outer union's acceptance draw (sample),
- *            bit 1 inside / finally accepted, bit 2 PENDING on an emulator,
- *            bit 3 decided;
- *   pos[row] = 256 * b + m: the bound of the list (and, for pending rows, the
- *            neural bound of it) the row is at; for decided-inside rows of a
- *            list b is the first bound that contains the row.
- * idx_dev (optional) lists the rows to process (n of them) -- the rows an
- * emulator turned down come back with their PENDING bit still set and resume
- * their walk behind (b, m).
- * Stage 2, nb_neural_score_rows: (r2, score) of neural bound m of `bound` for
- * the rows idx_dev[0..n) of x, densely packed (out_dev[2 i], [2 i + 1]) --
- * the pipelined emulator kernel on full tiles.  recentre != 0: the rows are
- * in the sampler's frame and the bound's periodic shift is applied first, as
- * contains() does (nautilus.py:162-163); 0 for proposals, which live in the
- * bound's frame.  A row is inside if score > score_predict_min - 1e-9
- * (bounds/neural.py:125).                                                    */
-int nb_geom_list(const nb_boundlist* list, int32_t mode /* 0 any, 1 first */,
-                 const double* x_dev, int64_t n_rows, const int64_t* idx_dev,
-                 int64_t n, int32_t* pos_dev, uint8_t* st_dev, void* stream);
-int nb_geom_sample(const nb_bound* bound, uint64_t seed, uint64_t offset,
-                   const double* x_dev, int64_t n_rows, const int64_t* idx_dev,
-                   int64_t n, int32_t* pos_dev, uint8_t* st_dev, void* stream);
+ * draw, the ellipsoids of the neural bounds -- for every point against every
+ * bound of the list; a point becomes a CANDIDATE of every (bound, neural
+ * bound) whose ellipsoid contains it (the reference's contains / sample are
+ * disjunctions over the neural bounds, so nothing waits for anything).
+ * Stage 2 (nb_eval_fast.hip): the emulators of ALL groups on their candidate
+ * rows in ONE launch of the pipelined kernel (dense 128-point passes, row
+ * counts read from device memory); a candidate whose score exceeds
+ * score_predict_min - 1e-9 (bounds/neural.py:125) sets its row's result.
+ *
+ * nb_list_eval, mode 0 (shell exclusion, sampler.py:797-798): st_dev[i] = 2
+ * if any bound of the list contains point i, else 0.  mode 1 (shell
+ * association, sampler.py:1213-1219): additionally first_dev[i] = position
+ * of the first bound that contains point i, INT32_MAX if none.  Points are in
+ * the sampler's frame (periodic bounds recentre them, nautilus.py:162-163).
+ * nb_accept_staged: the flags of nb_accept (bit 0: kept by the outer union's
+ * acceptance draw, bit 1: accepted) for proposals x_dev of stream position
+ * `offset`, for any number of outer members and neural bounds.  If
+ * totals_offset is not NULL it receives the byte offset inside work_dev of
+ * the int32 candidate counts per neural bound (valid in stream order).
+ * work_dev: device scratch of at least nb_*_work_bytes(.., n) bytes.        */
+int64_t nb_list_eval_work_bytes(const nb_boundlist* list, int64_t n);
+int nb_list_eval(const nb_boundlist* list, int32_t mode, const double* x_dev,
+                 int64_t n, uint8_t* st_dev, int32_t* first_dev, void* work_dev,
+                 int64_t work_bytes, void* stream);
+int64_t nb_accept_staged_work_bytes(const nb_bound* bound, int64_t n);
+int nb_accept_staged(const nb_bound* bound, uint64_t seed, uint64_t offset,
+                     const double* x_dev, int64_t n, uint8_t* flags_dev,
+                     void* work_dev, int64_t work_bytes, int64_t* totals_offset,
+                     void* stream);
+/* (r2, score) of neural bound m of `bound` for the rows idx_dev[0..n) of x,
+ * densely packed (out_dev[2 i], [2 i + 1]) -- the pipelined emulator kernel
+ * on full tiles.  recentre != 0: the rows are in the sampler's frame and the
+ * bound's periodic shift is applied first, as contains() does
+ * (nautilus.py:162-163); 0 for proposals, which live in the bound's frame.  */
 int nb_neural_score_rows(const nb_bound* bound, int32_t m, int32_t recentre,
                          const double* x_dev, const int64_t* idx_dev,
                          int64_t n, double* out_dev, void* stream);

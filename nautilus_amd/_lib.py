@@ -163,12 +163,15 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     'nb_comm_allreduce_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
-    'nb_geom_list': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
-                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+    'nb_list_eval_work_bytes': (C.c_int64, [C.c_void_p, C.c_int64]),
+    'nb_list_eval': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p]),
-    'nb_geom_sample': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64,
-                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nb_accept_staged_work_bytes': (C.c_int64, [C.c_void_p, C.c_int64]),
+    'nb_accept_staged': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64,
+                                   C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_int64), C.c_void_p]),
     'nb_neural_score_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p]),

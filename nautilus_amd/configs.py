@@ -54,6 +54,19 @@ def baseline_config(name):
             n_networks=8, n_batch=8192,
             analytic_log_z=funnel_log_z(100),
             description='100-dim Neal funnel, n_live=10000, n_networks=8')
+    if name.startswith('C5-D'):
+        # the config-5 problem at a smaller dimension (same likelihood family,
+        # networks and live points): the sizes at which a run FINISHES -- the
+        # exploration has to walk down the funnel to x_0 ~ 0.27 (1 % of the
+        # mass below), where the iso-likelihood region has shrunk by ~7.8 nats
+        # per dimension; at ~0.7 nats per bound that is ~100 bounds at D = 10,
+        # ~210 at D = 20 and > 1000 at D = 100
+        d = int(name[4:])
+        return dict(
+            likelihood=FunnelLikelihood(d), n_dim=d, n_live=10000,
+            n_networks=8, n_batch=8192, analytic_log_z=funnel_log_z(d),
+            description='%d-dim Neal funnel, n_live=10000, n_networks=8 '
+                        '(config 5 at a dimension that finishes)' % d)
     raise ValueError('unknown BASELINE configuration %r' % (name,))
 
 

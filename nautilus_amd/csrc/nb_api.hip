@@ -28,6 +28,21 @@ int nb_launch_geom(int dt, const double* const* blobs_dev, int nb, int mode,
                    const long long* idx, long long n, int* pos,
                    unsigned char* st, unsigned long long seed,
                    unsigned long long offset, hipStream_t stream);
+int nb_launch_cand(int dt, const double* const* blobs_dev,
+                   const int* group_base_dev, int nb, int n_groups, int b_off,
+                   int g_off, int accumulate, int mode, const double* x,
+                   long long n, unsigned char* st, int* first, int* work,
+                   unsigned long long seed, unsigned long long offset,
+                   int** dense_out, int** totals_out, long long* n_pad_out,
+                   hipStream_t stream);
+long long nb_cand_work_bytes(int dt, long long n, int n_groups);
+int nb_launch_eval_fast_batch(const double* blob0_dev, int n_dim, int recentre,
+                              const double* x, const void* groups_dev,
+                              int n_groups, const int* totals_dev,
+                              const int* dense_dev, long long n_pad,
+                              long long n_upper, int out_mode,
+                              unsigned char* st, int* first,
+                              hipStream_t stream);
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
                    int* out_i32, double* out_f64, unsigned long long seed,
@@ -113,6 +128,11 @@ void nb_set_error(const char* fmt, ...) {
 struct nb_bound {
   double* blob_dev = nullptr;
   const double** self_list_dev = nullptr;   // device array {blob_dev}
+  // two-stage queries: the bound's (neural bound) groups, {0} as group base
+  FastGroup* groups_dev = nullptr;
+  int* group_base_dev = nullptr;
+  int n_groups = 0;
+  int64_t off_shift = 0, neural_stride = 0;
   int64_t n_doubles = 0;
   int n_dim = 0, dt = 0, K = 0, M = 0, E = 0;
   bool single_full_ellipsoid = false;
@@ -128,7 +148,28 @@ struct nb_boundlist {
   const double** ptrs_dev = nullptr;
   int n = 0, dt = 0, n_dim = 0;
   int blocks_single = 0;   // n == 1: ellipsoid blocks (K + M) of the bound
+  // two-stage queries: groups of all bounds in list order, first group of
+  // every bound (n + 1 entries; host copy for splitting long lists)
+  FastGroup* groups_dev = nullptr;
+  int* group_base_dev = nullptr;
+  std::vector<int> group_base;
+  int n_groups = 0;
+  const double* blob0 = nullptr;   // any blob of the list (n_dim, strides)
 };
+
+// groups of one bound, appended to `out`
+static void nb_append_groups(const nb_bound* b, int pos,
+                             std::vector<FastGroup>& out) {
+  if (b->E < 1) return;
+  for (int m = 0; m < b->M; ++m) {
+    FastGroup g;
+    g.nb = b->blob_dev + b->off_neural + (int64_t)m * b->neural_stride;
+    g.shift = b->off_shift != 0 ? b->blob_dev + b->off_shift : nullptr;
+    g.E = b->E;
+    g.b = pos;
+    out.push_back(g);
+  }
+}
 
 namespace {
 
@@ -169,13 +210,18 @@ bool fill_ell_block(std::vector<double>& buf, size_t at, int n_dim, int dt,
     }
     is_ell[idx[i]] = 1;
   }
+  bool any_box = false;
   for (int f = 0; f < dp; ++f) {
     const bool boxed = f < n_dim && !is_ell[f] && !m.free_dims && !is_neural;
     const int sl = slot_of_feature(f);
     lo[sl] = boxed ? 0.0 : -INF;
     hi[sl] = boxed ? 1.0 : INF;
     c[sl] = 0.0;
+    any_box |= boxed;
   }
+  // [1]: members: "has finite box limits" (nb_cand.hip skips the box test
+  // otherwise); neural blocks: the squared bounding radius, set by the caller
+  put_i64(buf, at + 1, any_box ? 1 : 0);
   for (int i = 0; i < m.n_ell; ++i) c[slot_of_feature(idx[i])] = m.c[i];
   for (int i = 0; i < m.n_ell; ++i) {
     for (int j = 0; j < m.n_ell; ++j) {
@@ -456,6 +502,8 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   b->off_stream = off_stream;
   b->off_members = off_members;
   b->off_neural = off_neural;
+  b->off_shift = nb_hdr(buf.data(), NB_H_OFF_SHIFT);
+  b->neural_stride = nb_hdr(buf.data(), NB_H_NEURAL_STRIDE);
   // (the kernels stage parts of the blob in whole 1 KB pieces -- dma_weights,
   // the ellipsoid block of nb_eval_fast.hip -- so the last piece of the last
   // block may read up to 1 KB past its end: keep that inside the allocation)
@@ -471,11 +519,25 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   if (e == hipSuccess)
     e = hipMemcpy(b->self_list_dev, &b->blob_dev, sizeof(double*),
                   hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    std::vector<FastGroup> groups;
+    nb_append_groups(b, 0, groups);
+    b->n_groups = (int)groups.size();
+    const int base[2] = {0, b->n_groups};
+    e = hipMalloc((void**)&b->group_base_dev, sizeof base);
+    if (e == hipSuccess)
+      e = hipMemcpy(b->group_base_dev, base, sizeof base,
+                    hipMemcpyHostToDevice);
+    if (e == hipSuccess && b->n_groups > 0) {
+      e = hipMalloc((void**)&b->groups_dev, groups.size() * sizeof(FastGroup));
+      if (e == hipSuccess)
+        e = hipMemcpy(b->groups_dev, groups.data(),
+                      groups.size() * sizeof(FastGroup), hipMemcpyHostToDevice);
+    }
+  }
   if (e != hipSuccess) {
     nb_set_error("bound upload failed: %s", hipGetErrorString(e));
-    if (b->blob_dev) (void)hipFree(b->blob_dev);
-    if (b->self_list_dev) (void)hipFree(b->self_list_dev);
-    delete b;
+    nb_bound_destroy(b);
     return NB_ERR_HIP;
   }
   *out = b;
@@ -486,6 +548,8 @@ int nb_bound_destroy(nb_bound* b) {
   if (b == nullptr) return NB_OK;
   if (b->blob_dev) (void)hipFree(b->blob_dev);
   if (b->self_list_dev) (void)hipFree(b->self_list_dev);
+  if (b->groups_dev) (void)hipFree(b->groups_dev);
+  if (b->group_base_dev) (void)hipFree(b->group_base_dev);
   delete b;
   return NB_OK;
 }
@@ -514,14 +578,33 @@ int nb_boundlist_create(nb_bound* const* bounds, int32_t n,
   if (n > 0) {
     l->dt = bounds[0]->dt;
     l->n_dim = bounds[0]->n_dim;
+    l->blob0 = bounds[0]->blob_dev;
     if (n == 1) l->blocks_single = bounds[0]->K + bounds[0]->M;
     hipError_t e = hipMalloc((void**)&l->ptrs_dev, n * sizeof(double*));
     if (e == hipSuccess)
       e = hipMemcpy(l->ptrs_dev, ptrs.data(), n * sizeof(double*),
                     hipMemcpyHostToDevice);
+    std::vector<FastGroup> groups;
+    l->group_base.assign(1, 0);
+    for (int i = 0; i < n; ++i) {
+      nb_append_groups(bounds[i], i, groups);
+      l->group_base.push_back((int)groups.size());
+    }
+    l->n_groups = (int)groups.size();
+    if (e == hipSuccess)
+      e = hipMalloc((void**)&l->group_base_dev, (n + 1) * sizeof(int));
+    if (e == hipSuccess)
+      e = hipMemcpy(l->group_base_dev, l->group_base.data(),
+                    (n + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && l->n_groups > 0) {
+      e = hipMalloc((void**)&l->groups_dev, groups.size() * sizeof(FastGroup));
+      if (e == hipSuccess)
+        e = hipMemcpy(l->groups_dev, groups.data(),
+                      groups.size() * sizeof(FastGroup), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
       nb_set_error("bound list upload failed: %s", hipGetErrorString(e));
-      delete l;
+      nb_boundlist_destroy(l);
       return NB_ERR_HIP;
     }
   }
@@ -532,6 +615,8 @@ int nb_boundlist_create(nb_bound* const* bounds, int32_t n,
 int nb_boundlist_destroy(nb_boundlist* l) {
   if (l == nullptr) return NB_OK;
   if (l->ptrs_dev) (void)hipFree(l->ptrs_dev);
+  if (l->groups_dev) (void)hipFree(l->groups_dev);
+  if (l->group_base_dev) (void)hipFree(l->group_base_dev);
   delete l;
   return NB_OK;
 }
@@ -601,30 +686,108 @@ __attribute__((constructor)) static void nb_install_abort_trace(void) {
   signal(SIGSEGV, nb_abort_trace);
 }
 
-int nb_geom_list(const nb_boundlist* l, int32_t mode, const double* x,
-                 int64_t n_rows, const int64_t* idx, int64_t n, int32_t* pos,
-                 uint8_t* st, void* stream) {
-  if (mode != 0 && mode != 1) {
-    nb_set_error("nb_geom_list: mode must be 0 (any) or 1 (first)");
-    return NB_ERR_ARG;
+// ---- two-stage queries (nb_cand.hip + nb_eval_fast.hip BATCH) --------------
+// groups per slice of a long list: the second stage's pass table holds 1024
+constexpr int NB_SLICE_GROUPS = 1024;
+
+int64_t nb_list_eval_work_bytes(const nb_boundlist* l, int64_t n) {
+  const int g = l->n_groups < NB_SLICE_GROUPS ? l->n_groups : NB_SLICE_GROUPS;
+  // (a slice never splits a bound: allow for the largest bound's groups)
+  int most = 0;
+  for (int i = 0; i < l->n; ++i) {
+    const int k = l->group_base[i + 1] - l->group_base[i];
+    most = k > most ? k : most;
   }
-  if (l->n == 0) {
-    nb_set_error("nb_geom_list: empty list");
-    return NB_ERR_ARG;
-  }
-  return nb_launch_geom(l->dt, l->ptrs_dev, l->n, mode, l->blocks_single, x,
-                        n_rows, (const long long*)idx, n, pos, st, 0, 0,
-                        as_stream(stream));
+  return nb_cand_work_bytes(l->dt, n, (g > most ? g : most) + 1);
 }
 
-int nb_geom_sample(const nb_bound* b, uint64_t seed, uint64_t offset,
-                   const double* x, int64_t n_rows, const int64_t* idx,
-                   int64_t n, int32_t* pos, uint8_t* st, void* stream) {
-  // (a proposal of a one-member bound is not tested against that member)
-  return nb_launch_geom(b->dt, b->self_list_dev, 1, 2,
-                        (b->K == 1 ? 0 : b->K) + b->M, x, n_rows,
-                        (const long long*)idx, n, pos, st, seed, offset,
-                        as_stream(stream));
+int64_t nb_accept_staged_work_bytes(const nb_bound* b, int64_t n) {
+  return nb_cand_work_bytes(b->dt, n, b->n_groups + 1);
+}
+
+static int nb_stage_two(const double* blob0, int n_dim, int recentre,
+                        const double* x, const FastGroup* groups, int n_groups,
+                        int* totals, int* dense, long long n_pad, long long n,
+                        int mode, uint8_t* st, int32_t* first,
+                        hipStream_t stream) {
+  if (n_groups == 0) return NB_OK;
+  // every row is a candidate of every group at most once
+  return nb_launch_eval_fast_batch(blob0, n_dim, recentre, x, groups, n_groups,
+                                   totals, dense, n_pad,
+                                   (long long)n * (n_groups < 8 ? n_groups : 8),
+                                   mode, st, first, stream);
+}
+
+int nb_list_eval(const nb_boundlist* l, int32_t mode, const double* x,
+                 int64_t n, uint8_t* st, int32_t* first, void* work,
+                 int64_t work_bytes, void* stream) {
+  if (mode != 0 && mode != 1) {
+    nb_set_error("nb_list_eval: mode must be 0 (any) or 1 (first)");
+    return NB_ERR_ARG;
+  }
+  if (mode == 1 && first == nullptr) {
+    nb_set_error("nb_list_eval: mode 1 needs the `first` output");
+    return NB_ERR_ARG;
+  }
+  if (n <= 0) return NB_OK;
+  if (l->n == 0) {
+    NB_HIP_CHECK(hipMemsetAsync(st, 0, (size_t)n, as_stream(stream)));
+    if (first != nullptr)
+      NB_HIP_CHECK(hipMemsetAsync(first, 0x7f, (size_t)n * 4,
+                                  as_stream(stream)));
+    return NB_OK;
+  }
+  if (work_bytes < nb_list_eval_work_bytes(l, n)) {
+    nb_set_error("nb_list_eval: work space of %lld bytes, need %lld",
+                 (long long)work_bytes,
+                 (long long)nb_list_eval_work_bytes(l, n));
+    return NB_ERR_ARG;
+  }
+  // slices of the list with at most NB_SLICE_GROUPS groups each
+  int b0 = 0;
+  while (b0 < l->n) {
+    int b1 = b0 + 1;
+    while (b1 < l->n && l->group_base[b1 + 1] - l->group_base[b0] <=
+                            NB_SLICE_GROUPS)
+      ++b1;
+    const int g0 = l->group_base[b0], ng = l->group_base[b1] - g0;
+    int *dense = nullptr, *totals = nullptr;
+    long long n_pad = 0;
+    int rc = nb_launch_cand(l->dt, l->ptrs_dev + b0, l->group_base_dev + b0,
+                            b1 - b0, ng, b0, g0, b0 > 0 ? 1 : 0, mode, x, n,
+                            st, first, (int*)work, 0, 0, &dense, &totals,
+                            &n_pad, as_stream(stream));
+    if (rc != NB_OK) return rc;
+    rc = nb_stage_two(l->blob0, l->n_dim, 1, x, l->groups_dev + g0, ng, totals,
+                      dense, n_pad, n, mode, st, first, as_stream(stream));
+    if (rc != NB_OK) return rc;
+    b0 = b1;
+  }
+  return NB_OK;
+}
+
+int nb_accept_staged(const nb_bound* b, uint64_t seed, uint64_t offset,
+                     const double* x, int64_t n, uint8_t* flags, void* work,
+                     int64_t work_bytes, int64_t* totals_offset, void* stream) {
+  if (n <= 0) return NB_OK;
+  if (work_bytes < nb_accept_staged_work_bytes(b, n)) {
+    nb_set_error("nb_accept_staged: work space of %lld bytes, need %lld",
+                 (long long)work_bytes,
+                 (long long)nb_accept_staged_work_bytes(b, n));
+    return NB_ERR_ARG;
+  }
+  int *dense = nullptr, *totals = nullptr;
+  long long n_pad = 0;
+  int rc = nb_launch_cand(b->dt, b->self_list_dev, b->group_base_dev, 1,
+                          b->n_groups, 0, 0, 0, 2, x, n, flags, nullptr,
+                          (int*)work, seed, offset, &dense, &totals, &n_pad,
+                          as_stream(stream));
+  if (rc != NB_OK) return rc;
+  if (totals_offset != nullptr)
+    *totals_offset = (int64_t)((char*)totals - (char*)work);
+  return nb_stage_two(b->blob_dev, b->n_dim, 0, x, b->groups_dev, b->n_groups,
+                      totals, dense, n_pad, n, 2, flags, nullptr,
+                      as_stream(stream));
 }
 
 int nb_neural_score_rows(const nb_bound* b, int32_t m, int32_t recentre,

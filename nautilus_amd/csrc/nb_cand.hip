@@ -1,0 +1,582 @@
+// First stage of the two-stage bound evaluation, entirely on the device:
+// everything contains() / sample() decide WITHOUT an emulator -- periodic
+// recentring, unit-cube clip, the ellipsoids of the outer union's members
+// (overlap count, union.py:285-289, 316-319), the acceptance draw, the
+// ellipsoids of the neural bounds (bounds/neural.py:115-120) -- for single
+// bounds and for lists of bounds (shell exclusion, sampler.py:797-798; shell
+// association, 1213-1219), and the CANDIDATE LISTS for the second stage.
+//
+// The reference evaluates `outer.contains(x) & any(nb.contains(x) for nb in
+// neural_bounds)` (nautilus.py:162-169, 212-216): a disjunction over the
+// neural bounds, and for a list of bounds a disjunction (exclusion) or the
+// first hit (association) over the bounds.  So a point needs the emulator of
+// EVERY (bound b, neural bound m) whose ellipsoid contains it, and nothing
+// has to wait for anything: this kernel walks the whole list once per point
+// and appends the row to the candidate list of each such group (b, m); the
+// second stage (nb_eval_fast.hip, BATCH) scores all lists in ONE launch on
+// dense 128-point passes and ORs the verdicts into the status bytes.  No
+// rounds, no host round trip, no index sorting: three launches per query
+// (candidates, list compaction, scores) with all counts read on the device.
+//
+// Candidate lists without atomics: wavefront w of the grid owns the points
+// [w * chunk, (w + 1) * chunk) and, in every group's list, the segment of the
+// same range; its fill counts live in LDS (one int per group and wavefront)
+// and go to counts[g][w] at the end.  nb_cand_compact_kernel turns the
+// segments into dense lists (prefix sums over the wavefronts, binary search
+// per destination slot) -- rows stay in ascending order, so the lists, the
+// passes built from them and every result are reproducible run to run.
+//
+// The geometric tests run on the matrix cores like every ellipsoid test of
+// this library (nb_tile.h layout), but per WAVEFRONT: T tiles of 16 points
+// share each A operand, which is read straight from the bound's blob (L2 /
+// L1; the blocks of a list are far too many for LDS, and a workgroup-wide
+// staging step would tie eight wavefronts to the slowest point), `PD` k-steps
+// ahead of the MFMAs.  Bounds are skipped per wavefront (bounding-sphere
+// pre-test, cube clip, nothing left to decide).
+#include <limits.h>
+#include <stdlib.h>
+
+#include "nb_common.h"
+
+#include "nb_tile.h"
+
+namespace {
+
+constexpr int CD_WPB = 4;              // wavefronts per workgroup
+constexpr int CD_MAX_WAVES = 4096;     // segments per group (compaction: LDS)
+
+enum { CM_ANY = 0, CM_FIRST = 1, CM_SAMPLE = 2 };
+// status byte of a row (SAMPLE: the flags of nb_accept)
+enum : unsigned char { CS_OUTER = 1, CS_INSIDE = 2 };
+
+struct CandArgs {
+  const double* const* blobs;   // device array of nb blob pointers
+  const int* group_base;        // device: first group of bound b
+  int nb, n_groups, mode;
+  int b_off, g_off;             // a slice of a longer list: its first bound /
+                                // group (positions and groups are the list's)
+  int accumulate;               // ... after earlier slices: rows already
+                                // inside stay as they are
+  const nb_gd* x;               // (n, n_dim)
+  long long n;
+  unsigned char* st;            // per row: status
+  int* first;                   // CM_FIRST: bound index or INT_MAX
+  int* seg;                     // [n_groups][n_pad] candidate rows
+  int* counts;                  // [n_groups][n_waves]
+  long long n_pad;
+  int chunk, n_waves;
+  unsigned long long seed, offset;
+  unsigned long long* counters; // optional, as in nb_eval.hip
+};
+
+// the k-steps of a lower-triangular ellipsoid transform in execution order
+template <int DT>
+struct StepTable {
+  static constexpr int N = 2 * DT * (DT + 1);
+  unsigned char ht[N], ks[N];
+  constexpr StepTable() : ht(), ks() {
+    int i = 0;
+    for (int h = 0; h < DT; ++h)
+      for (int k = 0; k < 4 * (h + 1); ++k) {
+        ht[i] = (unsigned char)h;
+        ks[i] = (unsigned char)k;
+        ++i;
+      }
+  }
+};
+
+// inside[t] = point of tile t passes the block's box limits and lies inside
+// its ellipsoid.  X(t, ks) = coordinate slot ks of tile t (lane layout of
+// nb_tile.h).  Operands (A tile rows, centre) come from global memory PD
+// k-steps ahead; same summation order as ell_eval / ell_eval_centre, so r2
+// is bit-identical to the other kernels'.
+template <int DT, int T, int PD, class XF>
+__device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
+                                            bool has_box, XF&& X, int lane,
+                                            bool (&inside)[T]) {
+  constexpr int DP = 16 * DT;
+  constexpr StepTable<DT> TAB{};
+  constexpr int N = StepTable<DT>::N;
+  const nb_gd* lo = blk + 2;
+  const nb_gd* hi = lo + DP;
+  const nb_gd* c = hi + DP;
+  const nb_gd* tiles = c + DP;
+  const int lg = lane >> 4;
+  bool bad[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) bad[t] = false;
+  if (has_box) {
+#pragma unroll
+    for (int ks = 0; ks < 4 * DT; ++ks) {
+      const double lov = lo[4 * ks + lg], hiv = hi[4 * ks + lg];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const double xv = X(t, ks);
+        bad[t] |= !(xv >= lov && xv < hiv);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) bad[t] = point_any(bad[t], lane);
+  }
+  double part[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) part[t] = 0.0;
+  if (has_ell) {
+    double a[PD], cv[PD];
+    auto fetch = [&](int i, int slot) __attribute__((always_inline)) {
+      const int ht = TAB.ht[i], ks = TAB.ks[i];
+      a[slot] = tiles[((ks >> 2) * DT + ht) * NB_TILE + (ks & 3) * 64 + lane];
+      cv[slot] = c[4 * ks + lg];
+    };
+#pragma unroll
+    for (int i = 0; i < PD && i < N; ++i) fetch(i, i);
+    nb_d4 acc[T];
+    // (the order is pinned: left alone, the scheduler hoists the loads of all
+    // k-steps to the top and spills)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int ht = TAB.ht[i], ks = TAB.ks[i];
+      if (ks == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+      }
+      const double av = a[i % PD];
+      double cc = cv[i % PD];
+      // the wait lands here; and the centre stays opaque: recognised as the
+      // value of an earlier k-step it would keep every x - c of the block
+      // alive next to x (twice the registers)
+      asm volatile("" : "+v"(cc) : "v"(av));
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + PD < N) fetch(i + PD, i % PD);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = MFMA(av, X(t, ks) - cc, acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 4 * (ht + 1) - 1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[t] += acc[t][r] * acc[t][r];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    inside[t] = !bad[t] && lane_group_sum(part[t]) < 1.0;
+}
+
+// (register budget: OCC wavefronts per SIMD -- the operands come from L2, so
+// the other wavefronts of a SIMD are what hides their latency; without the
+// limit the scheduler hoists every load of the unrolled k-steps and takes all
+// 512 registers)
+template <int DT, int T, int OCC>
+__global__ void __launch_bounds__(64 * CD_WPB)
+__attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
+  constexpr int DP = 16 * DT;
+  constexpr int PD = OCC >= 4 ? 6 : 10;   // k-steps the operands run ahead
+  extern __shared__ int cur[];           // [n_groups][CD_WPB] fill counts
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lg = lane >> 4;
+  for (int i = threadIdx.x; i < a.n_groups * CD_WPB; i += 64 * CD_WPB)
+    cur[i] = 0;
+  __syncthreads();
+  const bool m_sample = a.mode == CM_SAMPLE;
+  const nb_gd* const NB_G* blobs = (const nb_gd* const NB_G*)a.blobs;
+  const NB_G int* group_base = (const NB_G int*)a.group_base;
+  const int n_dim = (int)nb_hdr((const double*)blobs[0], NB_H_NDIM);
+  const long long w = (long long)blockIdx.x * CD_WPB + wave;
+  const long long p_begin = w * a.chunk;
+  const long long p_end = p_begin + a.chunk < a.n ? p_begin + a.chunk : a.n;
+  unsigned long long cnt_outer = 0, cnt_ell = 0;
+
+  // append the rows with `hit` to the wavefront's segment of group g
+  auto emit = [&](int g, bool hit, long long row) __attribute__((always_inline)) {
+    const unsigned long long bal = __ballot(hit && lg == 0);
+    if (bal == 0ull) return;
+    int base = 0;
+    if (lane == 0) {
+      base = cur[g * CD_WPB + wave];
+      cur[g * CD_WPB + wave] = base + __popcll(bal);
+    }
+    base = __shfl(base, 0);
+    if (hit && lg == 0)
+      a.seg[(long long)g * a.n_pad + p_begin + base +
+            __popcll(bal & ((1ull << lane) - 1ull))] = (int)row;
+  };
+
+  for (long long p0 = p_begin; p0 < p_end; p0 += 16 * T) {
+    long long row[T];
+    bool valid[T], active[T];
+    unsigned char st[T];
+    int first[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      row[t] = p0 + 16 * t + (lane & 15);
+      valid[t] = row[t] < p_end;
+      active[t] = valid[t];
+      st[t] = 0;
+      first[t] = INT_MAX;
+      if (a.accumulate && valid[t]) {
+        st[t] = a.st[row[t]];
+        if (a.mode == CM_FIRST) first[t] = a.first[row[t]];
+        active[t] = !(st[t] & CS_INSIDE);
+      }
+    }
+    double xin[T][4 * DT];
+    load_points<DT, T>(a.x, row, valid, n_dim, a.n, lane, xin);
+
+    bool reload = false;
+    for (int b = 0; b < a.nb; ++b) {
+      if (reload) {
+        load_points<DT, T>(a.x, row, valid, n_dim, a.n, lane, xin);
+        reload = false;
+      }
+      bool any_active = false;
+#pragma unroll
+      for (int t = 0; t < T; ++t) any_active |= active[t];
+      if (!__any(any_active)) break;
+      const nb_gd* blob = blobs[b];
+      const double* hdr = (const double*)blob;
+      const int K = (int)nb_hdr(hdr, NB_H_K);
+      const int M = (int)nb_hdr(hdr, NB_H_M);
+      const int E = (int)nb_hdr(hdr, NB_H_E);
+      const bool use_cube = nb_hdr(hdr, NB_H_USECUBE) != 0;
+      const long long ell_stride = nb_hdr(hdr, NB_H_ELL_STRIDE);
+      const long long neural_stride = nb_hdr(hdr, NB_H_NEURAL_STRIDE);
+      const long long off_shift = nb_hdr(hdr, NB_H_OFF_SHIFT);
+      const nb_gd* nblk0 = blob + nb_hdr(hdr, NB_H_OFF_NEURAL);
+      // contains() of a bound with periodic dimensions sees recentred points
+      // (nautilus.py:162-163, periodic.py:69-71: x <- (x + 0.5 - centre) mod
+      // 1); proposals already live in the shifted frame.  Rare: the shift is
+      // applied in place and the points are read again behind the bound.
+      const bool shifted = off_shift != 0 && !m_sample;
+      if (shifted) {
+        reload = true;
+        const nb_gd* shift = blob + off_shift;
+#pragma unroll
+        for (int ks = 0; ks < 4 * DT; ++ks) {
+          const double sv = shift[4 * ks + lg];
+          const bool on = shift[DP + 4 * ks + lg] != 0.0;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const double u = xin[t][ks] + sv;
+            xin[t][ks] = on ? u - floor(u) : xin[t][ks];
+          }
+        }
+      }
+      auto X = [&](int t, int ks) __attribute__((always_inline)) {
+        return xin[t][ks];
+      };
+
+      // Bounding-sphere pre-test (bound lists): a point of a bound with
+      // neural bounds lies inside one of their ellipsoids, hence within
+      // sqrt(radius2) of that centre -- for nested bounds in high dimension
+      // all but the next few bounds end here.
+      bool maybe[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) maybe[t] = active[t];
+      if (!m_sample && M > 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) maybe[t] = false;
+        for (int m = 0; m < M; ++m) {
+          const nb_gd* nb_m = nblk0 + m * neural_stride;
+          const double rad2 = nb_m[1];
+          const nb_gd* cc = nb_m + 2 + 2 * DP;
+          double d2[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) d2[t] = 0.0;
+#pragma unroll
+          for (int ks = 0; ks < 4 * DT; ++ks) {
+            const double cv = cc[4 * ks + lg];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const double dv = X(t, ks) - cv;
+              d2[t] = fma(dv, dv, d2[t]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            maybe[t] |= active[t] && lane_group_sum(d2[t]) <= rad2;
+        }
+        bool any_maybe = false;
+#pragma unroll
+        for (int t = 0; t < T; ++t) any_maybe |= maybe[t];
+        if (!__any(any_maybe)) continue;
+      }
+
+      // unit-cube clip of the union (union.py:287-288 / 313-314)
+      bool in_cube[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        bool cbad = false;
+#pragma unroll
+        for (int ks = 0; ks < 4 * DT; ++ks) {
+          const int f = 8 * (ks >> 1) + 2 * lg + (ks & 1);
+          const double xv = X(t, ks);
+          cbad |= use_cube && f < n_dim && !(xv >= 0.0 && xv < 1.0);
+        }
+        in_cube[t] = !point_any(cbad, lane);
+      }
+
+      // ---- outer union: overlap count ------------------------------------
+      int k_cnt[T];
+      bool outer_need = false;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        k_cnt[t] = 0;
+        outer_need |= maybe[t] && in_cube[t];
+      }
+      if (m_sample && K == 1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) k_cnt[t] = 1;   // drawn from the only member
+      } else if (K > 0 && __any(outer_need)) {
+        const nb_gd* mblk = blob + nb_hdr(hdr, NB_H_OFF_MEMBERS);
+        for (int m = 0; m < K; ++m) {
+          const nb_gd* blk = mblk + m * ell_stride;
+          const bool has_ell = ((const NB_G long long*)blk)[0] > 0;
+          const bool has_box = ((const NB_G long long*)blk)[1] != 0;
+          bool ins[T];
+          cand_inside<DT, T, PD>(blk, has_ell, has_box, X, lane, ins);
+#pragma unroll
+          for (int t = 0; t < T; ++t) k_cnt[t] += ins[t] ? 1 : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          cnt_outer += (unsigned long long)K *
+                       __popcll(__ballot(maybe[t] && in_cube[t] && lg == 0));
+      }
+      bool want[T];
+      if (m_sample) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (valid[t]) {
+            double u0, u_acc;
+            nb_uniform_pair(a.seed, a.offset + (unsigned long long)row[t], 0u,
+                            NB_TAG_CTRL, u0, u_acc);
+            // (no member contains it: 1 - 1 / 0 = -inf, kept -- as in the
+            // reference, union.py:318-319)
+            if (in_cube[t] && (u_acc > 1.0 - 1.0 / (double)k_cnt[t]))
+              st[t] |= CS_OUTER;
+          }
+          want[t] = valid[t] && (st[t] & CS_OUTER);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          want[t] = maybe[t] && in_cube[t] && (K == 0 || k_cnt[t] > 0);
+      }
+
+      // ---- neural bounds: every one whose ellipsoid contains the point ----
+      bool decided[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) decided[t] = (M == 0) && want[t];
+      const int g0 = group_base[b] - a.g_off;
+      for (int m = 0; m < M; ++m) {
+        bool any_want = false;
+#pragma unroll
+        for (int t = 0; t < T; ++t) any_want |= want[t] && !decided[t];
+        if (!__any(any_want)) break;
+        const nb_gd* nb_m = nblk0 + m * neural_stride;
+        bool ins[T];
+        cand_inside<DT, T, PD>(nb_m, true, false, X, lane, ins);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const bool test = want[t] && !decided[t];
+          cnt_ell += __popcll(__ballot(test && lg == 0));
+          const bool hit = test && ins[t];
+          if (E == 0) decided[t] |= hit;   // no emulator: the ellipsoid decides
+          else emit(g0 + m, hit, row[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (decided[t]) {
+          st[t] |= CS_INSIDE;
+          first[t] = a.b_off + b;
+          active[t] = false;               // nothing later can change it
+        }
+      if (m_sample) break;                 // a single bound
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (valid[t] && lg == 0) {
+        a.st[row[t]] = st[t];
+        if (a.mode == CM_FIRST) a.first[row[t]] = first[t];
+      }
+  }
+  __syncthreads();
+  if (w < a.n_waves)
+    for (int g = lane; g < a.n_groups; g += 64)
+      a.counts[(long long)g * a.n_waves + w] = cur[g * CD_WPB + wave];
+  if (a.counters != nullptr && lane == 0) {
+    atomicAdd(&a.counters[0], cnt_outer);
+    atomicAdd(&a.counters[1], cnt_ell);
+  }
+}
+
+// segments -> dense lists.  grid = (blocks over the destination slots, groups)
+__global__ void __launch_bounds__(256)
+nb_cand_compact_kernel(const int* __restrict__ counts,
+                       const int* __restrict__ seg, int* __restrict__ dense,
+                       int* __restrict__ totals, int n_waves, int chunk,
+                       long long n_pad, int per_block) {
+  __shared__ int pre[CD_MAX_WAVES + 1];
+  __shared__ int part[256];
+  const int g = blockIdx.y, t = threadIdx.x;
+  const int* cg = counts + (long long)g * n_waves;
+  const int per = (n_waves + 255) / 256;
+  const int w_lo = t * per;
+  int sum = 0;
+  for (int i = 0; i < per; ++i)
+    if (w_lo + i < n_waves) sum += cg[w_lo + i];
+  part[t] = sum;
+  __syncthreads();
+  // exclusive scan of the 256 partial sums (one wavefront)
+  if (t < 64) {
+    int v[4], run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = part[4 * t + j]; run += v[j]; }
+    int incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(incl, d);
+      if (t >= d) incl += u;
+    }
+    int excl = incl - run;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { part[4 * t + j] = excl; excl += v[j]; }
+  }
+  __syncthreads();
+  int run = part[t];
+  for (int i = 0; i < per; ++i)
+    if (w_lo + i < n_waves) { pre[w_lo + i] = run; run += cg[w_lo + i]; }
+  if (t == 255) pre[n_waves] = run;
+  __syncthreads();
+  const int total = pre[n_waves];
+  if (blockIdx.x == 0 && t == 0) totals[g] = total;
+  const long long j0 = (long long)blockIdx.x * per_block;
+  const long long j1 = j0 + per_block < total ? j0 + per_block : total;
+  for (long long j = j0 + t; j < j1; j += 256) {
+    int lo = 0, hi = n_waves;            // largest w with pre[w] <= j
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= (int)j) lo = mid; else hi = mid;
+    }
+    dense[(long long)g * n_pad + j] =
+        seg[(long long)g * n_pad + (long long)lo * chunk + ((int)j - pre[lo])];
+  }
+}
+
+template <int DT, int T, int OCC>
+int launch_cand_t(const CandArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)a.n_groups * CD_WPB * sizeof(int);
+  const int blocks = (a.n_waves + CD_WPB - 1) / CD_WPB;
+  hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC>), dim3((unsigned)blocks),
+                     dim3(64 * CD_WPB), lds, stream, a);
+  return NB_OK;
+}
+
+}  // namespace
+
+unsigned long long* nb_eval_counters();
+
+// Geometry of the candidate lists for n points: points per wavefront, number
+// of wavefronts, padded list length (all multiples the kernels rely on).
+void nb_cand_shape(int dt, long long n, int* chunk, int* n_waves,
+                   long long* n_pad) {
+  const int tile = 16 * 2;               // T = 2 tiles per wavefront
+  const long long passes = (n + tile - 1) / tile;
+  const long long per_wave = (passes + CD_MAX_WAVES - 1) / CD_MAX_WAVES;
+  *chunk = (int)((per_wave < 1 ? 1 : per_wave) * tile);
+  long long w = (n + *chunk - 1) / *chunk;
+  w = (w + CD_WPB - 1) / CD_WPB * CD_WPB;
+  *n_waves = (int)(w < CD_WPB ? CD_WPB : w);
+  *n_pad = (long long)*n_waves * *chunk;
+}
+
+// work space (bytes) of one query over n points and n_groups groups:
+// [seg][dense] int32 (n_groups x n_pad each), [counts] (n_groups x n_waves),
+// [totals] (n_groups)
+long long nb_cand_work_bytes(int dt, long long n, int n_groups) {
+  int chunk, n_waves;
+  long long n_pad;
+  nb_cand_shape(dt, n, &chunk, &n_waves, &n_pad);
+  return ((long long)n_groups * (2 * n_pad + n_waves + 1) + 64) *
+         (long long)sizeof(int);
+}
+
+// candidates + compaction.  On return (in stream order) totals[g] and
+// dense[g * n_pad ...] describe the second stage's work.
+int nb_launch_cand(int dt, const double* const* blobs_dev,
+                   const int* group_base_dev, int nb, int n_groups, int b_off,
+                   int g_off, int accumulate, int mode, const double* x, long long n, unsigned char* st, int* first,
+                   int* work, unsigned long long seed,
+                   unsigned long long offset, int** dense_out,
+                   int** totals_out, long long* n_pad_out,
+                   hipStream_t stream) {
+  if (n <= 0 || nb <= 0) return NB_OK;
+  if (n > 0x7fffffffll) {
+    nb_set_error("nb_launch_cand: %lld rows (limit 2^31 - 1)", n);
+    return NB_ERR_ARG;
+  }
+  if ((size_t)n_groups * CD_WPB * sizeof(int) > 60 * 1024) {
+    nb_set_error("nb_launch_cand: %d groups exceed the fill-count table",
+                 n_groups);
+    return NB_ERR_ARG;
+  }
+  CandArgs a;
+  a.blobs = blobs_dev; a.group_base = group_base_dev; a.nb = nb;
+  a.n_groups = n_groups; a.mode = mode; a.x = (const nb_gd*)x; a.n = n;
+  a.b_off = b_off; a.g_off = g_off; a.accumulate = accumulate;
+  a.st = st; a.first = first; a.seed = seed; a.offset = offset;
+  a.counters = nb_eval_counters();
+  nb_cand_shape(dt, n, &a.chunk, &a.n_waves, &a.n_pad);
+  const long long gp = (long long)n_groups * a.n_pad;
+  a.seg = work;
+  int* dense = work + gp;
+  a.counts = dense + gp;
+  int* totals = a.counts + (long long)n_groups * a.n_waves;
+  int rc = NB_OK;
+  // (tuning aid: NB_CAND_OCC=2 selects the two-wavefront register budget for
+  // n_dim 33-64 as well)
+  static const bool occ2 = getenv("NB_CAND_OCC") != nullptr &&
+                           atoi(getenv("NB_CAND_OCC")) == 2;
+  if (occ2 && (dt == 3 || dt == 4)) {
+    rc = dt == 3 ? launch_cand_t<3, 2, 2>(a, stream)
+                 : launch_cand_t<4, 2, 2>(a, stream);
+    if (rc != NB_OK) return rc;
+    NB_HIP_CHECK(hipGetLastError());
+    dt = 0;
+  }
+  switch (dt) {
+    case 0: break;
+    case 1: rc = launch_cand_t<1, 2, 4>(a, stream); break;
+    case 2: rc = launch_cand_t<2, 2, 4>(a, stream); break;
+    case 3: rc = launch_cand_t<3, 2, 3>(a, stream); break;
+    case 4: rc = launch_cand_t<4, 2, 3>(a, stream); break;
+    case 5: rc = launch_cand_t<5, 2, 2>(a, stream); break;
+    case 6: rc = launch_cand_t<6, 2, 2>(a, stream); break;
+    case 7: rc = launch_cand_t<7, 2, 2>(a, stream); break;
+    case 8: rc = launch_cand_t<8, 2, 2>(a, stream); break;
+    default:
+      nb_set_error("n_dim > 128 is not supported by the device kernels");
+      return NB_ERR_UNSUPPORTED;
+  }
+  if (rc != NB_OK) return rc;
+  NB_HIP_CHECK(hipGetLastError());
+  if (n_groups > 0) {
+    const int per_block = 4096;
+    const dim3 grid((unsigned)((a.n_pad + per_block - 1) / per_block),
+                    (unsigned)n_groups);
+    hipLaunchKernelGGL(nb_cand_compact_kernel, grid, dim3(256), 0, stream,
+                       a.counts, a.seg, dense, totals, a.n_waves, a.chunk,
+                       a.n_pad, per_block);
+    NB_HIP_CHECK(hipGetLastError());
+  }
+  *dense_out = dense;
+  *totals_out = totals;
+  *n_pad_out = a.n_pad;
+  return NB_OK;
+}

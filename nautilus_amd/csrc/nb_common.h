@@ -93,6 +93,16 @@ __host__ __device__ inline int nb_net_tiles(int kt1) {
   return kt1 * NB_HT1 + NB_HT1 * NB_HT2 + NB_HT2 * NB_HT3 + NB_HT3 * 1;
 }
 
+// One (bound, neural bound) group of a two-stage query (nb_cand.hip ->
+// nb_eval_fast.hip, BATCH): built on the host when a bound / a bound list is
+// created, read by the second stage per 128-point pass.
+struct FastGroup {
+  const double* nb;               // neural block inside the bound's blob
+  const double* shift;            // the bound's periodic shift block or null
+  int E;                          // networks
+  int b;                          // position of the bound in its list
+};
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  Stream layout: DESIGN.md "RNG
 // contract" / oracle/philox.py.

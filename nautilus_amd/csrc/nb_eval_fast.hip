@@ -40,6 +40,8 @@
 
 namespace {
 
+constexpr int FAST_MAX_GROUPS = 1024;     // pass table in LDS: 4 KB
+
 struct FastArgs {
   const double* blob;
   int sample;                     // 1: flags of nb_accept, 0: (r2, score)
@@ -54,6 +56,17 @@ struct FastArgs {
   unsigned long long seed;
   unsigned long long offset;
   unsigned long long* counters;   // optional, as in nb_eval.hip
+  // BATCH (second stage of nb_cand.hip): the candidates of ALL (bound, neural
+  // bound) groups of a query in one launch.  Group g owns the rows
+  // dense[g * n_pad ... + totals[g]); a 128-point pass belongs to one group.
+  const FastGroup* groups;
+  const int* totals;
+  const int* dense;
+  long long n_pad;
+  int n_groups;
+  int out_mode;                   // 0: any, 1: first, 2: sample (nb_cand.hip)
+  unsigned char* st;              // per row: status written for candidates
+  int* first;                     //          whose score passes the threshold
 };
 
 constexpr int FAST_B_DOUBLES =
@@ -162,7 +175,7 @@ __device__ __forceinline__ void points_from_raw(
 
 constexpr int FAST_REGION = 38 * NB_TILE;            // doubles per region
 
-template <int DT, int KT1>
+template <int DT, int KT1, bool BATCH>
 __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   constexpr int T = 1, NW = 8, DP = 16 * DT;
   constexpr int KS1 = 4 * KT1;
@@ -196,18 +209,78 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   const int n_dim = (int)nb_hdr(blob, NB_H_NDIM);
   const int K = (int)nb_hdr(blob, NB_H_K);
   const bool use_cube = nb_hdr(blob, NB_H_USECUBE) != 0;
-  const int E = (int)nb_hdr(blob, NB_H_E);
   const int ks1 = (n_dim + 1 + 3) >> 2;
-  const double* shift =
-      (a.recentre != 0 && nb_hdr(blob, NB_H_OFF_SHIFT) != 0)
-          ? blob + nb_hdr(blob, NB_H_OFF_SHIFT) : nullptr;
-  const double* nb_m = blob + nb_hdr(blob, NB_H_OFF_NEURAL) +
-                       a.m * nb_hdr(blob, NB_H_NEURAL_STRIDE);
   const long long net_stride = nb_hdr(blob, NB_H_NET_STRIDE);
-  const double* nets = nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
-  const long long n_super = (a.n + 16 * NW * T - 1) / (16 * NW * T);
   unsigned long long cnt_ell = 0, cnt_mlp = 0;
   long long sup = blockIdx.x;
+
+  // ---- what a pass works on ------------------------------------------------
+  // plain launches: one neural bound for all passes; BATCH: the group of the
+  // pass, found in the table of pass offsets (LDS, behind the two regions)
+  struct Pass {
+    const double* nb;             // neural block
+    const double* shift;
+    int E, b;
+    long long base;               // BATCH: first slot of the pass in `dense`
+    int n_valid;                  // BATCH: slots of the pass that hold rows
+  };
+  int* pp = (int*)(lds + 2 * FAST_REGION);
+  long long n_super;
+  if constexpr (BATCH) {
+    // pp[g] = passes of the groups before g (every workgroup, redundantly)
+    if (wave == 0) {
+      int run = 0;
+      for (int g0 = 0; g0 < a.n_groups; g0 += 64) {
+        const int g = g0 + lane;
+        int v = g < a.n_groups ? (a.totals[g] + 127) >> 7 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int u = __shfl_up(v, d);
+          if (lane >= d) v += u;
+        }
+        if (g < a.n_groups) pp[g + 1] = run + v;
+        run += __shfl(v, 63);
+      }
+      if (lane == 0) pp[0] = 0;
+    }
+    __syncthreads();
+    n_super = pp[a.n_groups];
+    if (sup >= n_super) return;
+  } else {
+    n_super = (a.n + 16 * NW * T - 1) / (16 * NW * T);
+  }
+  auto pass_of = [&](long long P) __attribute__((always_inline)) {
+    Pass ps;
+    if constexpr (BATCH) {
+      const long long Pc = P < n_super ? P : n_super - 1;
+      int lo = 0, hi = a.n_groups;          // largest g with pp[g] <= Pc
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pp[mid] <= (int)Pc) lo = mid; else hi = mid;
+      }
+      const int g = __builtin_amdgcn_readfirstlane(lo);
+      const FastGroup gd = a.groups[g];
+      ps.nb = gd.nb;
+      ps.shift = a.recentre != 0 ? gd.shift : nullptr;
+      ps.E = gd.E;
+      ps.b = gd.b;
+      const int s0 = ((int)Pc - __builtin_amdgcn_readfirstlane(pp[g])) << 7;
+      ps.base = (long long)g * a.n_pad + s0;
+      const int left = a.totals[g] - s0;
+      ps.n_valid = P < n_super ? (left < 128 ? left : 128) : 0;
+    } else {
+      ps.nb = blob + nb_hdr(blob, NB_H_OFF_NEURAL) +
+              a.m * nb_hdr(blob, NB_H_NEURAL_STRIDE);
+      ps.shift = (a.recentre != 0 && nb_hdr(blob, NB_H_OFF_SHIFT) != 0)
+                     ? blob + nb_hdr(blob, NB_H_OFF_SHIFT) : nullptr;
+      ps.E = (int)nb_hdr(blob, NB_H_E);
+      ps.b = 0;
+      ps.base = 0;
+      ps.n_valid = 0;
+    }
+    return ps;
+  };
+  Pass cur_p = pass_of(sup);
 
   // ---- DMA: a linear run of 1 KB pieces, or the packed ellipsoid block ---
   const double* dma_src = nullptr;
@@ -219,8 +292,9 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
     dma_src = src; dma_dst = dst; dma_c = wave; dma_n = n_doubles >> 7;
     dma_ell = false;
   };
-  auto dma_begin_ell = [&](double* dst) __attribute__((always_inline)) {
-    dma_src = nb_m; dma_dst = dst; dma_c = wave; dma_n = ELL_CHUNKS;
+  auto dma_begin_ell = [&](const double* nb_blk, double* dst)
+      __attribute__((always_inline)) {
+    dma_src = nb_blk; dma_dst = dst; dma_c = wave; dma_n = ELL_CHUNKS;
     dma_ell = true;
   };
   auto dma_one = [&]() __attribute__((always_inline)) {
@@ -255,7 +329,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   };
 
   int q = 0;                         // reg(q): ellipsoid block of this pass
-  dma_begin_ell(reg(0));
+  dma_begin_ell(cur_p.nb, reg(0));
   dma_flush();
   long long pt[T];
   bool valid[T];
@@ -265,16 +339,29 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   auto row_of = [&](long long p) __attribute__((always_inline)) {
     return p < a.n ? (a.idx != nullptr ? a.idx[p] : p) : 0ll;
   };
+  // BATCH: row behind slot (wave, t, lane) of a pass
+  auto row_in = [&](const Pass& ps, int t) __attribute__((always_inline)) {
+    const int slot = (wave * T + t) * 16 + (lane & 15);
+    return (long long)a.dense[ps.base + (slot < ps.n_valid ? slot : 0)];
+  };
   long long nrow[T];             // rows of the pass after the current one
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     pt[t] = ((sup * NW + wave) * T + t) * 16 + (lane & 15);
     valid[t] = pt[t] < a.n;
-    nrow[t] = row_of(pt[t]);
+    if constexpr (BATCH) nrow[t] = row_in(cur_p, t);
+    else nrow[t] = row_of(pt[t]);
   }
   load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
 
   for (; sup < n_super; sup += gridDim.x) {
+    const double* nb_m = cur_p.nb;
+    const double* shift = cur_p.shift;
+    const int E = cur_p.E;
+    const double* nets = nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
+    // (BATCH: the group of the next pass, a pass ahead of its block and rows)
+    const Pass next_p = pass_of(sup + gridDim.x);
+    long long crow[T];             // BATCH: the rows this pass evaluates
     // layer 1 (chunk a) of the first network -> the other region, under the
     // prologue; the ellipsoid block and the points are waited for here
     dma_begin(nets, reg(q ^ 1), NA_D);
@@ -290,11 +377,17 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       pt[t] = ((sup * NW + wave) * T + t) * 16 + (lane & 15);
-      valid[t] = pt[t] < a.n;
       in_cube[t] = true;
-      // (the index of the next pass's row, a pass ahead of its loads)
-      nrow[t] = row_of((((sup + gridDim.x) * NW + wave) * T + t) * 16 +
-                       (lane & 15));
+      if constexpr (BATCH) {
+        valid[t] = (wave * T + t) * 16 + (lane & 15) < cur_p.n_valid;
+        crow[t] = nrow[t];
+        nrow[t] = row_in(next_p, t);
+      } else {
+        valid[t] = pt[t] < a.n;
+        // (the index of the next pass's row, a pass ahead of its loads)
+        nrow[t] = row_of((((sup + gridDim.x) * NW + wave) * T + t) * 16 +
+                         (lane & 15));
+      }
     }
     points_from_raw<DT, T>(xraw, valid, n_dim, lane, xin);
     if (shift != nullptr) {
@@ -420,7 +513,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       // next pass, -> other region
       if constexpr (LAST) {
         load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
-        dma_begin_ell(reg(cur ^ 1));
+        dma_begin_ell(next_p.nb, reg(cur ^ 1));
       } else {
         dma_begin(nets + (e + 1) * net_stride, reg(cur ^ 1), NA_D);
       }
@@ -461,7 +554,15 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const double score = __shfl(total[t], lane & 15) / (double)E;
-      if (m_sample) {
+      if constexpr (BATCH) {
+        // the geometric stage found the point inside this neural bound's
+        // ellipsoid; the emulator decides (bounds/neural.py:121-126).  Several
+        // groups may say yes to the same row: they store the same byte.
+        if (valid[t] && lg == 0 && score > thr) {
+          a.st[crow[t]] = a.out_mode == 2 ? (unsigned char)3 : (unsigned char)2;
+          if (a.out_mode == 1) atomicMin(&a.first[crow[t]], cur_p.b);
+        }
+      } else if (m_sample) {
         bool ok = inside_e[t];
         if (need[t]) ok = inside_e[t] && (score > thr);
         const unsigned char flags =
@@ -472,6 +573,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
         a.out_f64[2 * pt[t] + 1] = score;
       }
     }
+    cur_p = next_p;
   }
   if (a.counters != nullptr && lane == 0) {
     atomicAdd(&a.counters[1], cnt_ell);
@@ -479,13 +581,14 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   }
 }
 
-template <int DT, int KT1>
-int launch_fast(const FastArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)2 * FAST_REGION * sizeof(double);
+template <int DT, int KT1, bool BATCH>
+int launch_fast_impl(const FastArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)2 * FAST_REGION * sizeof(double) +
+                     (BATCH ? (FAST_MAX_GROUPS + 1) * sizeof(int) : 0);
   static bool configured = false;
   if (!configured) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_fast_kernel<DT, KT1>,
+        (const void*)nb_eval_fast_kernel<DT, KT1, BATCH>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -494,11 +597,19 @@ int launch_fast(const FastArgs& a, hipStream_t stream) {
     }
     configured = true;
   }
+  // BATCH: the number of passes is only known on the device; workgroups
+  // without a pass leave at once
   const long long n_super = (a.n + 127) / 128;
   long long blocks = n_super < 256 ? n_super : 256;
-  hipLaunchKernelGGL((nb_eval_fast_kernel<DT, KT1>), dim3((unsigned)blocks),
-                     dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((nb_eval_fast_kernel<DT, KT1, BATCH>),
+                     dim3((unsigned)blocks), dim3(512), lds, stream, a);
   return NB_OK;
+}
+
+template <int DT, int KT1>
+int launch_fast(const FastArgs& a, hipStream_t stream) {
+  return a.groups != nullptr ? launch_fast_impl<DT, KT1, true>(a, stream)
+                             : launch_fast_impl<DT, KT1, false>(a, stream);
 }
 
 }  // namespace
@@ -514,18 +625,7 @@ bool nb_eval_fast_eligible(int n_dim, int K, int M, int E, bool sample) {
   return !sample || (K <= 1 && M == 1);
 }
 
-int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
-                        int recentre, const double* x, const long long* idx,
-                        long long n,
-                        unsigned char* out_u8, double* out_f64,
-                        unsigned long long seed, unsigned long long offset,
-                        hipStream_t stream) {
-  if (n <= 0) return NB_OK;
-  FastArgs a;
-  a.blob = blob_dev; a.sample = sample ? 1 : 0; a.x = (const nb_gd*)x; a.n = n;
-  a.idx = idx; a.m = m; a.recentre = recentre;
-  a.out_u8 = out_u8; a.out_f64 = out_f64; a.seed = seed; a.offset = offset;
-  a.counters = nb_eval_counters();
+static int dispatch_fast(const FastArgs& a, int n_dim, hipStream_t stream) {
   const int dt = (n_dim + 15) / 16, kt1 = (n_dim + 1 + 15) / 16;
   int rc = NB_ERR_UNSUPPORTED;
   switch (4 * dt + (kt1 - dt)) {
@@ -552,4 +652,49 @@ int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
   if (rc != NB_OK) return rc;
   NB_HIP_CHECK(hipGetLastError());
   return NB_OK;
+}
+
+int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
+                        int recentre, const double* x, const long long* idx,
+                        long long n,
+                        unsigned char* out_u8, double* out_f64,
+                        unsigned long long seed, unsigned long long offset,
+                        hipStream_t stream) {
+  if (n <= 0) return NB_OK;
+  FastArgs a = {};
+  a.blob = blob_dev; a.sample = sample ? 1 : 0; a.x = (const nb_gd*)x; a.n = n;
+  a.idx = idx; a.m = m; a.recentre = recentre;
+  a.out_u8 = out_u8; a.out_f64 = out_f64; a.seed = seed; a.offset = offset;
+  a.counters = nb_eval_counters();
+  return dispatch_fast(a, n_dim, stream);
+}
+
+// Second stage of the two-stage bound evaluation (nb_cand.hip): the emulators
+// of every (bound, neural bound) group on the candidate rows the geometric
+// stage left for it -- ONE launch for all groups, the row counts read from
+// device memory (totals_dev), the grid sized for n_upper candidates.
+// `groups_dev`: FastGroup records (struct layout shared with nb_api.hip).
+int nb_launch_eval_fast_batch(const double* blob0_dev, int n_dim, int recentre,
+                              const double* x, const void* groups_dev,
+                              int n_groups, const int* totals_dev,
+                              const int* dense_dev, long long n_pad,
+                              long long n_upper, int out_mode,
+                              unsigned char* st, int* first,
+                              hipStream_t stream) {
+  if (n_upper <= 0 || n_groups <= 0) return NB_OK;
+  if (n_groups > FAST_MAX_GROUPS) {
+    nb_set_error("nb_launch_eval_fast_batch: %d groups (limit %d)", n_groups,
+                 FAST_MAX_GROUPS);
+    return NB_ERR_ARG;
+  }
+  FastArgs a = {};
+  a.blob = blob0_dev; a.sample = 0; a.x = (const nb_gd*)x;
+  // (grid: every group may end in a partial pass)
+  a.n = n_upper + 128ll * n_groups;
+  a.recentre = recentre;
+  a.counters = nb_eval_counters();
+  a.groups = (const FastGroup*)groups_dev; a.n_groups = n_groups;
+  a.totals = totals_dev; a.dense = dense_dev; a.n_pad = n_pad;
+  a.out_mode = out_mode; a.st = st; a.first = first;
+  return dispatch_fast(a, n_dim, stream);
 }

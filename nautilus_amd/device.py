@@ -98,7 +98,6 @@ class DeviceBound:
         self.thresholds = [float(src.get('score_predict_min', 0.0)) - 1e-9
                            for src in neural]
         self.dense_need = None     # share of proposals that reach an emulator
-        self._launches = 0
         for nd, src in zip(n_arr, neural):
             fill_member(nd.ellipsoid, src['ellipsoid'])
             nd.score_predict_min = float(src.get('score_predict_min', 0.0))
@@ -164,8 +163,7 @@ class DeviceBound:
     # -- queries ---------------------------------------------------------
     def contains(self, x):
         x = as_device_points(x, self.n_dim)
-        st, _ = two_stage([self], self._self_list(), GEOM_ANY, x)
-        return (st & GS_INSIDE) != 0
+        return (self._self_list().eval(x, GEOM_ANY)[0] & GS_INSIDE) != 0
 
     def _self_list(self):
         lst = self.__dict__.get('_list')
@@ -215,25 +213,40 @@ class DeviceBound:
         draw, bit 1: accepted) for the proposals ``x`` of stream position
         ``offset``.  Two routes, same decisions: the fused kernel (cube test,
         acceptance draw, ellipsoid and emulators of ONE neural bound in one
-        pass over dense tiles) where most proposals reach the emulator, the
-        two-stage route (``two_stage``) for several outer members or neural
-        bounds -- and for bounds whose proposals mostly die in the geometric
-        tests (a funnel's envelope sticks far out of the unit cube): there
-        the emulators only see the survivors."""
+        pass over dense tiles) where most proposals reach the emulator, and
+        the staged route (``nb_accept_staged``: geometric stage, candidate
+        lists and ONE batched emulator launch, all counts on the device) for
+        several outer members or neural bounds -- and for bounds whose
+        proposals mostly die in the geometric tests (a funnel's envelope
+        sticks far out of the unit cube): there the emulators only see the
+        survivors.  The route of a bound is chosen ONCE, from the share of
+        its first launch's proposals that reached an emulator."""
         fused_ok = (self.n_neural == 1 and self.n_members <= 1 and
                     self.n_networks >= 1)
-        self._launches += 1
-        probe = self.dense_need is None or self._launches % 1024 == 0
-        if fused_ok and not probe and self.dense_need > 0.5:
+        if fused_ok and self.dense_need is not None and self.dense_need > 0.5:
             flags = _buffer('accept', (x.shape[0],), torch.uint8, reuse)
             _lib.check(self._lib.nb_accept(self._h, seed, offset, _ptr(x),
                                            x.shape[0], _ptr(flags),
                                            _stream()))
             DISPATCHES['nb_eval_fast_kernel'] += 1
             return flags
-        st, n_need = two_stage([self], self, GEOM_SAMPLE, x, seed, offset)
-        self.dense_need = n_need / max(1, x.shape[0])
-        return st & 3
+        n = x.shape[0]
+        flags = _buffer('accept', (n,), torch.uint8, reuse)
+        need = self._lib.nb_accept_staged_work_bytes(self._h, n)
+        work = _buffer('staged_work', (need,), torch.uint8, True)
+        off = C.c_int64(0)
+        _lib.check(self._lib.nb_accept_staged(
+            self._h, seed, offset, _ptr(x), n, _ptr(flags), _ptr(work), need,
+            C.byref(off), _stream()))
+        DISPATCHES['nb_cand_kernel'] += 1
+        DISPATCHES['nb_eval_fast_kernel'] += 1 if self.n_networks else 0
+        if fused_ok and self.dense_need is None:
+            # (the one host read of this route: the first launch of a bound
+            # that could also take the fused kernel)
+            totals = work[off.value:off.value + 4 * self.n_neural].view(
+                torch.int32)
+            self.dense_need = float(totals.sum()) / max(1, n)
+        return flags
 
     def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False):
         """One launch of the device ``sample`` pipeline: draw, accept,
@@ -269,136 +282,63 @@ class DeviceBoundList:
             self._lib.nb_boundlist_destroy(h)
             self._h = None
 
+    def eval(self, x, mode):
+        """(status bytes, first containing bound or None) of the rows of the
+        cuda tensor ``x`` against the list -- ``nb_list_eval``: geometric
+        stage, candidate lists, ONE batched emulator launch; nothing returns
+        to the host in between.  Rows are processed in slabs whose work space
+        stays below WORK_BYTES."""
+        n = x.shape[0]
+        st = torch.empty(n, dtype=torch.uint8, device='cuda')
+        first = (torch.empty(n, dtype=torch.int32, device='cuda')
+                 if mode == GEOM_FIRST else None)
+        if n == 0:
+            return st, first
+        if len(self.bounds) == 0:
+            st.zero_()
+            if first is not None:
+                first.fill_(NO_BOUND)
+            return st, first
+        slab = n
+        while slab > 4096 and self._lib.nb_list_eval_work_bytes(
+                self._h, slab) > WORK_BYTES:
+            slab = (slab + 1) // 2
+        need = self._lib.nb_list_eval_work_bytes(self._h, slab)
+        work = _buffer('staged_work', (need,), torch.uint8, True)
+        for lo in range(0, n, slab):
+            k = min(slab, n - lo)
+            _lib.check(self._lib.nb_list_eval(
+                self._h, mode, _ptr(x[lo:]), k, _ptr(st[lo:]),
+                _ptr(first[lo:]) if first is not None else None, _ptr(work),
+                need, _stream()))
+            DISPATCHES['nb_cand_kernel'] += 1
+            DISPATCHES['nb_eval_fast_kernel'] += 1
+        return st, first
+
     def contains_any(self, x, as_flags=False):
         """mask[i] = any bound of the list contains x[i] (uint8 flags for the
         compaction kernels with ``as_flags``)."""
         x = as_device_points(x, self.n_dim)
-        if len(self.bounds) <= TWO_STAGE_MAX_LIST:
-            st, _ = two_stage(self.bounds, self, GEOM_ANY, x)
-            inside = (st & GS_INSIDE) != 0
-            return inside.to(torch.uint8) if as_flags else inside
-        # long lists of nested bounds: a point near the edge of its shell
-        # waits for the emulators of bound after bound, one round of the two
-        # stages each; the one-kernel form walks the list inside the kernel
-        mask = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
-        _lib.check(self._lib.nb_contains_any(self._h, _ptr(x), x.shape[0],
-                                             _ptr(mask), _stream()))
-        return mask if as_flags else mask.bool()
+        st, _ = self.eval(x, GEOM_ANY)
+        inside = (st & GS_INSIDE) != 0
+        return inside.to(torch.uint8) if as_flags else inside
 
     def first_containing(self, x):
+        """Position of the first bound of the list that contains x[i], -1 if
+        none does."""
         x = as_device_points(x, self.n_dim)
-        if len(self.bounds) <= TWO_STAGE_MAX_LIST:
-            st, _, pos = two_stage(self.bounds, self, GEOM_FIRST, x,
-                                   return_pos=True)
-            return torch.where((st & GS_INSIDE) != 0, pos >> 8,
-                               torch.full_like(pos, -1))
-        idx = torch.empty(x.shape[0], dtype=torch.int32, device='cuda')
-        _lib.check(self._lib.nb_first_containing(self._h, _ptr(x), x.shape[0],
-                                                 _ptr(idx), _stream()))
-        return idx
-
-
-TWO_STAGE_MAX_LIST = 2     # bounds in a list evaluated in two stages
+        _, first = self.eval(x, GEOM_FIRST)
+        return torch.where(first == NO_BOUND, torch.full_like(first, -1),
+                           first)
 
 
 GEOM_ANY, GEOM_FIRST, GEOM_SAMPLE = 0, 1, 2
+NO_BOUND = 2**31 - 1       # nb_list_eval: no bound of the list contains the row
+WORK_BYTES = 256 << 20     # candidate lists of one slab of rows
 # kernel dispatches of the bound evaluation since import (bench.py: which
 # dispatches of a profiled run belong to the timed region)
-DISPATCHES = dict(nb_eval_fast_kernel=0, nb_geom_kernel=0)
-GS_OUTER, GS_INSIDE, GS_PENDING, GS_DONE = 1, 2, 4, 8
-GS_NOT_PENDING = 0xFF ^ GS_PENDING
-
-
-TWO_STAGE_TIMES = {}      # NB_TWO_STAGE_TRACE=1: seconds per step (synchronous)
-_TS_TRACE = bool(os.environ.get('NB_TWO_STAGE_TRACE'))
-
-
-def _ts_mark(name, t0):
-    """Debugging aid: attribute GPU time to the steps of ``two_stage``."""
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    TWO_STAGE_TIMES[name] = TWO_STAGE_TIMES.get(name, 0.0) + t1 - t0
-    return t1
-
-
-def two_stage(bounds, target, mode, x, seed=0, offset=0, return_pos=False):
-    """Bound evaluation in two stages (``nb_geom_*`` + ``nb_neural_score_rows``,
-    include/nautilus_hip.h): the geometric tests of every point first, then
-    the emulators on dense gathers of exactly the points that wait for them,
-    one gather per (bound, neural bound); points an emulator turns down go
-    back to the geometric stage and walk on.  ``bounds``: the DeviceBound
-    objects behind ``target`` (a DeviceBoundList, or the DeviceBound itself
-    for ``GEOM_SAMPLE``).  Returns (status bytes per point, number of points
-    that reached an emulator[, positions])."""
-    lib = _lib.load()
-    n = x.shape[0]
-    st = torch.zeros(n, dtype=torch.uint8, device='cuda')
-    pos = torch.zeros(n, dtype=torch.int32, device='cuda')
-    n_need = 0
-    if n == 0 or len(bounds) == 0:
-        return (st, 0, pos) if return_pos else (st, 0)
-    idx, n_act = None, n
-    if _TS_TRACE:
-        t_mark = _ts_mark('setup', time.perf_counter())
-    while True:
-        if mode == GEOM_SAMPLE:
-            _lib.check(lib.nb_geom_sample(
-                target._h, seed, offset, _ptr(x), n,
-                _ptr(idx) if idx is not None else None, n_act, _ptr(pos),
-                _ptr(st), _stream()))
-        else:
-            _lib.check(lib.nb_geom_list(
-                target._h, mode, _ptr(x), n,
-                _ptr(idx) if idx is not None else None, n_act, _ptr(pos),
-                _ptr(st), _stream()))
-        DISPATCHES['nb_geom_kernel'] += 1
-        if _TS_TRACE:
-            t_mark = _ts_mark('geom', t_mark)
-        sub = st if idx is None else st[idx]
-        pend = torch.nonzero(sub & GS_PENDING).squeeze(1)
-        if pend.numel() == 0:
-            break
-        if idx is not None:
-            pend = idx[pend]
-        n_need += int(pend.numel())
-        keys = pos[pend]
-        if len(bounds) > 1 or bounds[0].n_neural > 1:
-            order = torch.argsort(keys, stable=True)
-            pend, keys = pend[order], keys[order]
-            groups, sizes = torch.unique_consecutive(keys, return_counts=True)
-            groups, sizes = groups.tolist(), sizes.tolist()
-        else:
-            groups, sizes = [0], [int(pend.numel())]
-        scores = _buffer('two_stage_scores', (pend.numel(), 2),
-                         torch.float64, False)
-        ok = torch.empty(pend.numel(), dtype=torch.bool, device='cuda')
-        at = 0
-        if _TS_TRACE:
-            t_mark = _ts_mark('index lists', t_mark)
-        for key, size in zip(groups, sizes):
-            b, m = key >> 8, key & 255
-            rows = pend[at:at + size]
-            out = scores[at:at + size]
-            _lib.check(lib.nb_neural_score_rows(
-                bounds[b]._h, m, 0 if mode == GEOM_SAMPLE else 1, _ptr(x),
-                _ptr(rows), size, _ptr(out), _stream()))
-            DISPATCHES['nb_eval_fast_kernel'] += 1
-            if _TS_TRACE:
-                t_mark = _ts_mark('scores', t_mark)
-            ok[at:at + size] = out[:, 1] > bounds[b].thresholds[m]
-            at += size
-        st[pend[ok]] = (st[pend[ok]] & GS_NOT_PENDING) | (GS_INSIDE | GS_DONE)
-        back = pend[~ok]
-        if back.numel() == 0:
-            break
-        if mode == GEOM_SAMPLE and bounds[0].n_neural == 1:
-            # no other neural bound could take them
-            st[back] = (st[back] & GS_NOT_PENDING) | GS_DONE
-            break
-        idx, n_act = back.contiguous(), int(back.numel())
-        if _TS_TRACE:
-            t_mark = _ts_mark('flags', t_mark)
-    return (st, n_need, pos) if return_pos else (st, n_need)
+DISPATCHES = dict(nb_eval_fast_kernel=0, nb_cand_kernel=0)
+GS_OUTER, GS_INSIDE = 1, 2
 
 
 MAX_DIM = 128          # n_dim limit of the device kernels
@@ -850,7 +790,7 @@ def _timed(name):
 
 # HIP-event time per kernel family (bench.py).  'bound_eval' = everything that
 # evaluates bounds on the matrix cores -- the fused acceptance kernel
-# (nb_eval_fast_kernel), the geometric stage (nb_geom_kernel) and the gathered
+# (nb_eval_fast_kernel), the geometric stage (nb_cand_kernel) and the gathered
 # emulator scores behind it.
 DeviceBound.contains = _timed('bound_eval')(DeviceBound.contains)
 DeviceBound.accept = _timed('bound_eval')(DeviceBound.accept)

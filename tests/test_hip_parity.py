@@ -330,11 +330,12 @@ def test_pipelined_accept_and_score(dev, d, e, k_outer):
 @pytest.mark.parametrize('d,k,m', [(20, 3, 2), (50, 2, 3)])
 def test_two_stage_large_launch(dev, d, k, m):
     """Bounds with several outer members and several neural bounds go through
-    the two stages (nb_geom.hip + gathered scores).  A launch of more than
-    131 072 points of a single bound keeps all its ellipsoid blocks in LDS;
-    smaller ones stage them per pass: the flags of the same proposals must
-    not depend on the launch size, and both agree with the oracle
-    (union.py:305-327, nautilus.py:146-169 on the same Philox stream)."""
+    the two device-side stages (nb_cand.hip: geometric tests + candidate
+    lists, then ONE batched emulator launch of nb_eval_fast.hip).  The launch
+    size decides how the points are dealt out over the wavefronts and how the
+    candidate lists are laid out: the flags of the same proposals must not
+    depend on it, and both agree with the oracle (union.py:305-327,
+    nautilus.py:146-169 on the same Philox stream)."""
     from oracle import bounds_oracle as bo
     from oracle import mlp_oracle as mo
     from oracle import philox
@@ -390,6 +391,73 @@ def test_two_stage_large_launch(dev, d, k, m):
     want_in = ob.contains(x)
     assert np.array_equal(inside_big[lo:hi][~score_edge],
                           want_in[~score_edge])
+
+
+def test_accept_routes_agree(dev):
+    """A bound with one neural bound and at most one outer member may take
+    the fused acceptance kernel or the staged route (chosen once per bound
+    from its first launch).  Same arithmetic in the same order: the flags of
+    the same proposals are identical, bit for bit, on both."""
+    from helpers import nautilus_from_golden
+    g = load_golden('nautilusbound_D4')
+    b = upload(nautilus_from_golden(g))
+    assert b.n_neural == 1 and b.n_members <= 1 and b.n_networks >= 1
+    seed, offset, n = 77, 123456789, 200000
+    x = b.propose(seed, offset, n)
+    b.dense_need = 1.0                       # fused kernel
+    fused = b.accept(seed, offset, x).cpu().numpy()
+    b.dense_need = 0.0                       # staged route
+    staged = b.accept(seed, offset, x).cpu().numpy()
+    assert 0.001 < (fused >> 1).mean() < 0.999
+    assert np.array_equal(fused, staged)
+    b.dense_need = None                      # first launch: staged + probe
+    first = b.accept(seed, offset, x).cpu().numpy()
+    assert np.array_equal(first, fused)
+    assert 0.0 <= b.dense_need <= 1.0
+
+
+def test_list_eval_matches_the_one_kernel_form(dev):
+    """nb_list_eval (candidate lists + one batched emulator launch; exclusion
+    = any bound, association = first bound) against the one-kernel form that
+    walks the list inside the kernel (nb_contains_any / nb_first_containing),
+    on a list of nested bounds longer than anything the golden fixtures hold,
+    in slabs (small work space) and at once."""
+    import ctypes as C
+    from nautilus_amd import _lib, device
+    from helpers import nautilus_from_golden
+    g = load_golden('nautilusbound_D4')
+    base = nautilus_from_golden(g)
+    bounds = [upload(base)]
+    # nested copies: the same bound with rising emulator thresholds
+    for k in range(1, 7):
+        nb = nautilus_from_golden(g)
+        for n_b in nb.neural_bounds:
+            n_b.score_predict_min = n_b.score_predict_min + 0.03 * k
+        bounds.append(upload(nb))
+    lst = device.DeviceBoundList(bounds[1:])
+    x = bounds[0].propose(5, 0, 100000)
+    lib = _lib.load()
+    ref_any = torch.empty(x.shape[0], dtype=torch.uint8, device='cuda')
+    ref_first = torch.empty(x.shape[0], dtype=torch.int32, device='cuda')
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.nb_contains_any(lst._h, C.c_void_p(x.data_ptr()),
+                                   x.shape[0], C.c_void_p(ref_any.data_ptr()),
+                                   stream))
+    _lib.check(lib.nb_first_containing(
+        lst._h, C.c_void_p(x.data_ptr()), x.shape[0],
+        C.c_void_p(ref_first.data_ptr()), stream))
+    got_any = lst.contains_any(x, as_flags=True)
+    got_first = lst.first_containing(x)
+    assert 0.01 < float(ref_any.float().mean()) < 0.99
+    assert torch.equal(got_any, ref_any)
+    assert torch.equal(got_first, ref_first)
+    old = device.WORK_BYTES
+    device.WORK_BYTES = 1 << 20
+    try:
+        assert torch.equal(lst.contains_any(x, as_flags=True), ref_any)
+        assert torch.equal(lst.first_containing(x), ref_first)
+    finally:
+        device.WORK_BYTES = old
 
 
 @pytest.fixture(scope='module')
