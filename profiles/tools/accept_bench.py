@@ -82,9 +82,7 @@ for case in CASES:
             import pstats
             prof.disable()
             pstats.Stats(prof).sort_stats('tottime').print_stats(12)
-        if device.TWO_STAGE_TIMES:
-            print({k: round(v / reps * 1e3, 3) for k, v in device.TWO_STAGE_TIMES.items()}, 'ms per call')
-                work = counters.read()
+        work = counters.read()
     flops = ((work['outer_point_evals'] + work['ellipsoid_point_evals']) *
              d * (d + 1) + work['emulator_point_evals'] * 2.0 *
              (100 * d + 6020)) / reps
