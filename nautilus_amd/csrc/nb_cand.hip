@@ -34,7 +34,6 @@
 // ahead of the MFMAs.  Bounds are skipped per wavefront (bounding-sphere
 // pre-test, cube clip, nothing left to decide).
 #include <limits.h>
-#include <stdlib.h>
 
 #include "nb_common.h"
 
@@ -166,10 +165,11 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
     inside[t] = !bad[t] && lane_group_sum(part[t]) < 1.0;
 }
 
-// (register budget: OCC wavefronts per SIMD -- the operands come from L2, so
-// the other wavefronts of a SIMD are what hides their latency; without the
-// limit the scheduler hoists every load of the unrolled k-steps and takes all
-// 512 registers)
+// (register budget: OCC wavefronts per SIMD.  Without a limit the scheduler
+// hoists every load of the unrolled k-steps and takes all 512 registers, one
+// wavefront per SIMD; two per SIMD run without spills up to n_dim = 64 and
+// were faster than three with spills: 2.81 against 3.10 ms per 2^20 proposals
+// at n_dim = 50, K = M = 4)
 template <int DT, int T, int OCC>
 __global__ void __launch_bounds__(64 * CD_WPB)
 __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
@@ -539,23 +539,11 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
   a.counts = dense + gp;
   int* totals = a.counts + (long long)n_groups * a.n_waves;
   int rc = NB_OK;
-  // (tuning aid: NB_CAND_OCC=2 selects the two-wavefront register budget for
-  // n_dim 33-64 as well)
-  static const bool occ2 = getenv("NB_CAND_OCC") != nullptr &&
-                           atoi(getenv("NB_CAND_OCC")) == 2;
-  if (occ2 && (dt == 3 || dt == 4)) {
-    rc = dt == 3 ? launch_cand_t<3, 2, 2>(a, stream)
-                 : launch_cand_t<4, 2, 2>(a, stream);
-    if (rc != NB_OK) return rc;
-    NB_HIP_CHECK(hipGetLastError());
-    dt = 0;
-  }
   switch (dt) {
-    case 0: break;
     case 1: rc = launch_cand_t<1, 2, 4>(a, stream); break;
-    case 2: rc = launch_cand_t<2, 2, 4>(a, stream); break;
-    case 3: rc = launch_cand_t<3, 2, 3>(a, stream); break;
-    case 4: rc = launch_cand_t<4, 2, 3>(a, stream); break;
+    case 2: rc = launch_cand_t<2, 2, 3>(a, stream); break;
+    case 3: rc = launch_cand_t<3, 2, 2>(a, stream); break;
+    case 4: rc = launch_cand_t<4, 2, 2>(a, stream); break;
     case 5: rc = launch_cand_t<5, 2, 2>(a, stream); break;
     case 6: rc = launch_cand_t<6, 2, 2>(a, stream); break;
     case 7: rc = launch_cand_t<7, 2, 2>(a, stream); break;
