@@ -384,6 +384,10 @@ def main():
             dist.init_process_group(args.backend, timeout=wait)
         from nautilus_amd.parallel import ShardedComm
         comm = ShardedComm()
+        comm_info = comm.describe()
+        if comm_info['ranks_seen'] != world:
+            raise SystemExit('the communicator counts %d ranks, WORLD_SIZE=%d'
+                             % (comm_info['ranks_seen'], world))
 
     from nautilus_amd import GaussianLikelihood, Sampler, device, unit_prior
     from nautilus_amd.bounds import Ellipsoid
@@ -419,6 +423,26 @@ def main():
                                len(sampler.bounds)], 'cuda',
                               'exploration state')
     setup_s = time.time() - t_setup
+
+    # per-rank wall time by phase (host clocks): what each rank spent in
+    # emulator training, the rest of the bound construction, drawing /
+    # evaluating shell points, likelihoods and inside the collectives
+    PHASES = ('bound_neural', 'bound_other', 'sample_shell', 'likelihood',
+              'collectives')
+
+    def phase_clock():
+        t = sampler.timing
+        return [t.get('bound_neural', 0.0),
+                t.get('bound_decompose', 0.0) + t.get('bound_envelope', 0.0),
+                t.get('sample_shell', 0.0), t.get('likelihood', 0.0),
+                comm.seconds if comm is not None else 0.0]
+
+    def per_rank(now, before=None):
+        mine = [a - b for a, b in zip(now, before or [0.0] * len(now))]
+        rows = comm.gather_floats(mine, 'cuda') if comm is not None else [mine]
+        return [dict(zip(PHASES, (round(v, 4) for v in row))) for row in rows]
+    clock_explored = phase_clock()
+    rank_phases = dict(exploration=per_rank(clock_explored))
     if comm is not None:
         sampler.n_batch = args.n_batch_setup * world
 
@@ -448,6 +472,7 @@ def main():
         comm.barrier()
     torch.cuda.synchronize()
     n_eff0, n_like0, prop0 = sampler.n_eff, sampler.n_like, proposals()
+    clock_timed = phase_clock()
     roctx_region(True)
     mallocs0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
     disp0 = dict(device.DISPATCHES)
@@ -462,6 +487,11 @@ def main():
         dt = time.time() - t0
     roctx_region(False)
     mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0) - mallocs0
+    rank_phases['timed_steps'] = per_rank(phase_clock(), clock_timed)
+    rank_dt = (comm.gather_floats([dt], 'cuda') if comm is not None
+               else [[dt]])
+    for row, t in zip(rank_phases['timed_steps'], rank_dt):
+        row['wall'] = round(t[0], 4)
     if comm is not None:
         comm.barrier()
         dt = comm.max_float(dt, 'cuda')
@@ -567,6 +597,12 @@ def main():
         full_run=dict(wall_s=setup_s + fill_s + dt,
                       ess_per_s=n_eff1 / (setup_s + fill_s + dt)),
         setup_breakdown={k: round(v, 2) for k, v in sampler.timing.items()},
+        # multi-GPU runs describe themselves: what the communicator spans
+        # (backend, ranks counted by an all-reduce, the device of every rank)
+        # and where every rank's wall time went, by phase
+        communicator=(comm_info if comm is not None else
+                      dict(backend=None, ranks_seen=1, world=1)),
+        per_rank_seconds=rank_phases,
         roofline=roofline)
 
     if rank == 0:

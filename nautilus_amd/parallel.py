@@ -43,16 +43,40 @@ def rank_key(seed, rank):
     return (int(seed) ^ ((rank * _MIX) & (2**63 - 1))) & (2**63 - 1)
 
 
+def _timed(fn):
+    """Accumulate the host wall time of a collective on the communicator."""
+    import functools
+    import time
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        depth = getattr(self, '_depth', 0)
+        self._depth = depth + 1
+        t0 = time.perf_counter()
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            self._depth = depth
+            if depth == 0:            # (gather_rows_async calls gather_rows)
+                self.seconds += time.perf_counter() - t0
+                self.calls += 1
+    return wrapper
+
+
 class _Gathered:
     """A gather in flight (input kept alive until it has landed)."""
 
-    def __init__(self, work, out, rows):
-        self.work, self.out, self.rows = work, out, rows
+    def __init__(self, work, out, rows, comm=None):
+        self.work, self.out, self.rows, self.comm = work, out, rows, comm
 
     def wait(self):
         if self.work is not None:
+            import time
+            t0 = time.perf_counter()
             self.work.wait()
             self.work = None
+            if self.comm is not None:
+                self.comm.seconds += time.perf_counter() - t0
         self.rows = None
         return self.out
 
@@ -66,7 +90,46 @@ class ShardedComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # host wall time spent inside the collectives (incl. waiting for the
+        # slowest rank) and their number, for the bench line's per-rank
+        # breakdown
+        self.seconds = 0.0
+        self.calls = 0
 
+    def describe(self, device='cuda'):
+        """What the communicator really spans: backend, ranks counted by an
+        all-reduce of ones, and the device every rank runs on (gathered)."""
+        backend = dist.get_backend(self.group)
+        seen = self.sum_ints([1], device)[0]
+        name = 'cpu'
+        if torch.cuda.is_available():
+            i = torch.cuda.current_device()
+            props = torch.cuda.get_device_properties(i)
+            name = '%s #%d (%s)' % (props.name, i, getattr(
+                props, 'gcnArchName', ''))
+        names = [None] * self.world
+        dist.all_gather_object(names, name, group=self.group)
+        out = dict(backend=backend, ranks_seen=int(seen), world=self.world,
+                   devices=names)
+        if backend == 'nccl':
+            try:
+                out['rccl_version'] = '.'.join(
+                    str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        return out
+
+    def gather_floats(self, values, device):
+        """(world, len(values)) nested list: every rank's short list of
+        floats (per-rank timings of the bench line)."""
+        t = torch.tensor([list(values)], dtype=torch.float64,
+                         device=self._dev(device))
+        out = torch.empty((self.world, t.shape[1]), dtype=torch.float64,
+                          device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().tolist()
+
+    @_timed
     def gather_rows(self, rows):
         """Concatenate equally sized (n_local, k) blocks of all ranks in rank
         order."""
@@ -82,6 +145,7 @@ class ShardedComm:
             dist.all_gather_into_tensor(out, rows, group=self.group)
         return out
 
+    @_timed
     def gather_rows_async(self, rows):
         """``gather_rows`` without waiting: returns a handle whose ``wait()``
         gives the gathered tensor (and makes the current stream wait for the
@@ -91,13 +155,14 @@ class ShardedComm:
         next batches are drawn (sampler.py, ``_sharded_batch``)."""
         rows = rows.contiguous()
         if rows.is_cuda and dist.get_backend(self.group) == 'gloo':
-            return _Gathered(None, self.gather_rows(rows), rows)
+            return _Gathered(None, self.gather_rows(rows), rows, self)
         out = torch.empty((self.world * rows.shape[0],) + tuple(rows.shape[1:]),
                           dtype=rows.dtype, device=rows.device)
         work = dist.all_gather_into_tensor(out, rows, group=self.group,
                                            async_op=True)
-        return _Gathered(work, out, rows)
+        return _Gathered(work, out, rows, self)
 
+    @_timed
     def sum_ints(self, values, device):
         """Element-wise sum of a short list of python ints over all ranks."""
         t = torch.tensor(list(values), dtype=torch.int64,
@@ -108,6 +173,7 @@ class ShardedComm:
     def _dev(self, device):
         return 'cpu' if dist.get_backend(self.group) == 'gloo' else device
 
+    @_timed
     def max_float(self, value, device):
         t = torch.tensor([float(value)], dtype=torch.float64,
                          device=self._dev(device))
@@ -126,6 +192,7 @@ class ShardedComm:
             raise RuntimeError('replicated %s diverged between ranks: %s vs %s'
                                % (what, lo.tolist(), hi.tolist()))
 
+    @_timed
     def sum_rows(self, rows):
         """Element-wise sum of equally shaped float tensors over all ranks
         (used with disjoint non-zero rows: x + 0 = x exactly, so the result is
@@ -138,6 +205,7 @@ class ShardedComm:
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out
 
+    @_timed
     def any_flag(self, flag):
         """True on every rank if ``flag`` is true on any (collective stop /
         continue decisions: wall-clock limits differ between ranks)."""

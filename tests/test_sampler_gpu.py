@@ -220,31 +220,52 @@ def test_nautilus_bound_two_peaks():
     assert b.n_net == 2
 
 
-def test_two_rank_sharded_run_on_one_gpu():
-    """The N > 1 path of bench.py end to end on real kernels: two processes
-    share cuda:0 and talk over gloo (RCCL needs one GPU per rank; the 8-GPU run
-    is the driver's).  Checks: replicated exploration identical on both ranks
-    (bench.py asserts it), one all-gather + all-reduce per batch, evidence."""
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_bench_on_one_gpu(world):
+    """The N > 1 path of bench.py end to end on real kernels: ``world``
+    processes share cuda:0 and talk over gloo (RCCL needs one GPU per rank;
+    the 8-GPU run is the driver's).  world = 8 is the split the driver's
+    --gpus 8 run will use: n_batch / 8 points per rank and batch, the four
+    networks of a bound on four of the eight ranks, up to four point gathers
+    in flight.  Checks: replicated exploration identical on all ranks
+    (bench.py asserts it), the communicator counts ``world`` ranks, every
+    rank reports its phases, evidence."""
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(29700 + os.getpid() % 200),
-           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4',
-           '--warmup', '1', '--dim', '6', '--n-live', '300', '--n-batch',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(29700 + (os.getpid() + world) % 200),
+           os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps',
+           '4', '--warmup', '1', '--dim', '6', '--n-live', '300', '--n-batch',
            '2048', '--n-batch-setup', '512', '--backend', 'gloo',
            '--same-device']
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
     res = json.loads(line)
-    assert res['n_gpus'] == 2 and res['scaling'] == 'weak'
-    assert res['config']['n_batch_global'] == 4096
+    assert res['n_gpus'] == world and res['scaling'] == 'weak'
+    assert res['config']['n_batch_global'] == 2048 * world
     assert abs(res['log_z']) < 0.05          # analytic log Z = 0
-    assert res['value'] > 0
+    assert res['value'] > 0 and res['value_full_run'] > 0
+    comm = res['communicator']
+    assert comm['backend'] == 'gloo' and comm['ranks_seen'] == world
+    assert len(comm['devices']) == world
+    assert res['ranks_training'] == min(world, res['networks_per_bound'])
+    assert res['ranks_idle_while_training'] == max(
+        0, world - res['networks_per_bound'])
+    for phase in ('exploration', 'timed_steps'):
+        rows = res['per_rank_seconds'][phase]
+        assert len(rows) == world
+        assert all(r['collectives'] > 0 and r['sample_shell'] > 0
+                   for r in rows)
+    # the networks are dealt out g mod world: with more ranks than networks
+    # the last ranks train nothing
+    trained = [r['bound_neural'] for r in
+               res['per_rank_seconds']['exploration']]
+    assert all(t > 0 for t in trained[:res['ranks_training']])
 
 
 def _run_sharded(world, *extra):
