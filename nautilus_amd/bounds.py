@@ -76,25 +76,45 @@ class _PhiloxStream:
 
 class _Fifo:
     """Accepted points waiting to be handed out (``self.points`` of the
-    reference's Union / NautilusBound), kept on the device."""
+    reference's Union / NautilusBound), kept on the device in one grow-only
+    buffer: rows [head, tail) are queued.  (Rebuilding the queue with
+    ``torch.cat`` on every refill asked the allocator for a block of a new
+    size every time -- device mallocs in the middle of the sampling phase.)"""
 
     def __init__(self, n_dim):
         self.n_dim = n_dim
-        self.buf = torch.empty((0, n_dim), dtype=torch.float64, device='cuda')
+        self.data = torch.empty((0, n_dim), dtype=torch.float64,
+                                device='cuda')
         self.head = 0
+        self.tail = 0
 
     def __len__(self):
-        return self.buf.shape[0] - self.head
+        return self.tail - self.head
+
+    @property
+    def buf(self):
+        """Rows 0 .. tail (the queue is ``buf[head:]``)."""
+        return self.data[:self.tail]
 
     def push(self, rows):
-        if self.head > 0 or len(self) == 0:
-            self.buf = torch.cat([self.buf[self.head:], rows])
-            self.head = 0
-        else:
-            self.buf = torch.cat([self.buf, rows])
+        k, m = int(rows.shape[0]), len(self)
+        cap = self.data.shape[0]
+        if self.tail + k > cap:
+            if m + k <= cap and self.head >= m:
+                # slide the queue to the front (source and target disjoint)
+                self.data[:m].copy_(self.data[self.head:self.tail])
+            else:
+                new = torch.empty((max(2 * cap, 2 * (m + k), 4096),
+                                   self.n_dim), dtype=torch.float64,
+                                  device='cuda')
+                new[:m].copy_(self.data[self.head:self.tail])
+                self.data = new
+            self.head, self.tail = 0, m
+        self.data[self.tail:self.tail + k].copy_(rows)
+        self.tail += k
 
     def pop(self, n):
-        out = self.buf[self.head:self.head + n]
+        out = self.data[self.head:self.head + n]
         self.head += n
         return out
 
@@ -103,17 +123,17 @@ class _Fifo:
         self.head -= n
 
     def clear(self):
-        self.buf = self.buf[:0]
-        self.head = 0
+        self.head = self.tail = 0
 
     def __getstate__(self):
         return dict(n_dim=self.n_dim,
-                    rows=self.buf[self.head:].cpu().numpy())
+                    rows=self.data[self.head:self.tail].cpu().numpy())
 
     def __setstate__(self, state):
         self.n_dim = state['n_dim']
-        self.buf = torch.from_numpy(state['rows']).cuda()
+        self.data = torch.from_numpy(state['rows']).cuda()
         self.head = 0
+        self.tail = int(self.data.shape[0])
 
 
 class _Persistent:

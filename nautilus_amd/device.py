@@ -282,15 +282,16 @@ class DeviceBoundList:
             self._lib.nb_boundlist_destroy(h)
             self._h = None
 
-    def eval(self, x, mode):
+    def eval(self, x, mode, reuse=False):
         """(status bytes, first containing bound or None) of the rows of the
         cuda tensor ``x`` against the list -- ``nb_list_eval``: geometric
         stage, candidate lists, ONE batched emulator launch; nothing returns
         to the host in between.  Rows are processed in slabs whose work space
-        stays below WORK_BYTES."""
+        stays below WORK_BYTES.  ``reuse``: the results live in the
+        process-wide scratch buffers (valid until the next such call)."""
         n = x.shape[0]
-        st = torch.empty(n, dtype=torch.uint8, device='cuda')
-        first = (torch.empty(n, dtype=torch.int32, device='cuda')
+        st = _buffer('list_status', (n,), torch.uint8, reuse)
+        first = (_buffer('list_first', (n,), torch.int32, reuse)
                  if mode == GEOM_FIRST else None)
         if n == 0:
             return st, first
@@ -315,9 +316,14 @@ class DeviceBoundList:
             DISPATCHES['nb_eval_fast_kernel'] += 1
         return st, first
 
+    def inside_flags(self, x, reuse=False):
+        """Status bytes of the rows of ``x`` for the compaction kernels: bit
+        GS_INSIDE is set where any bound of the list contains the row."""
+        return self.eval(as_device_points(x, self.n_dim), GEOM_ANY, reuse)[0]
+
     def contains_any(self, x, as_flags=False):
-        """mask[i] = any bound of the list contains x[i] (uint8 flags for the
-        compaction kernels with ``as_flags``)."""
+        """mask[i] = any bound of the list contains x[i] (uint8 0 / 1 with
+        ``as_flags``)."""
         x = as_device_points(x, self.n_dim)
         st, _ = self.eval(x, GEOM_ANY)
         inside = (st & GS_INSIDE) != 0
@@ -585,7 +591,7 @@ def compact_rows(x, flags, mask=1, want_index=False, reuse=False, flip=0):
     scratch = _buffer('compact_scratch',
                       (max(16, lib.nb_compact_scratch_bytes(n)),),
                       torch.uint8, reuse)
-    src = (torch.empty(n, dtype=torch.int64, device='cuda')
+    src = (_buffer('compact_index', (n,), torch.int64, reuse)
            if want_index else None)
     _lib.check(lib.nb_compact_rows(
         _ptr(x), _ptr(flags), mask, flip, n, d, _ptr(out),
@@ -800,6 +806,8 @@ DeviceBound.contains_stream = _timed('nb_ell_stream_kernel')(
     DeviceBound.contains_stream)
 DeviceBoundList.contains_any = _timed('bound_eval')(
     DeviceBoundList.contains_any)
+DeviceBoundList.inside_flags = _timed('bound_eval')(
+    DeviceBoundList.inside_flags)
 DeviceBoundList.first_containing = _timed('bound_eval')(
     DeviceBoundList.first_containing)
 compact_rows = _timed('nb_compact')(compact_rows)

@@ -509,9 +509,16 @@ class Sampler:
         s_idx = index % len(self.bounds)
         n_bound = 0
         have = 0
-        chunks = []
         idx_t = np.zeros(0, dtype=int)
         transfer = shell_t is not None and len(shell_t) > 0
+        # The batch is assembled in a buffer of its own: the rows a bound
+        # hands out are views of its queue, and the flags / compacted rows of
+        # a round live in the process-wide scratch buffers (no allocation of
+        # a new size per round).  Un-sharded runs reuse the batch buffer too:
+        # add_samples copies the batch into the shell's storage before the
+        # next one is drawn; a sharded run's batch may still be travelling.
+        out = device._buffer('shell_batch', (n_target, self.n_dim),
+                             torch.float64, self.comm is None)
 
         while have < n_target:
             need = n_target - have
@@ -529,9 +536,10 @@ class Sampler:
                 # sampler.py:796-799 on the device: flag the points inside a
                 # later bound, compact the others in order; the source row of
                 # the need-th survivor tells how many draws were examined
-                inside = later.contains_any(x, as_flags=True)
+                inside = later.inside_flags(x, reuse=True)
                 rows, counts, src = device.compact_rows(
-                    x, inside, mask=1, want_index=True, flip=1)
+                    x, inside, mask=device.GS_INSIDE, want_index=True,
+                    flip=device.GS_INSIDE, reuse=True)
                 probe = torch.cat([counts, src[max(0, min(
                     need, n_req) - 1):max(1, min(need, n_req))]]).cpu()
                 total = int(probe[1])
@@ -554,10 +562,10 @@ class Sampler:
             if transfer and x.shape[0] > 0:
                 x, idx_t = self._pair_with_candidates(x, shell_t, idx_t)
             if x.shape[0] > 0:
-                chunks.append(x)
+                out[have:have + x.shape[0]].copy_(x)
                 have += x.shape[0]
 
-        pts = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+        pts = out[:have]
         if shell_t is None:
             return pts, n_bound
         return pts, n_bound, idx_t
