@@ -37,8 +37,6 @@ namespace {
 
 typedef double nb_d2 __attribute__((ext_vector_type(2)));
 
-constexpr int TR_NW = 8;         // wavefronts per workgroup (two per SIMD)
-constexpr int TR_THREADS = 64 * TR_NW;
 constexpr int MAXB = 208;        // minibatch rows padded to 16 (batch <= 200)
 constexpr int LD1 = 112, LD2 = 64, LD3 = 32, LD4 = 16;
 constexpr int G_ROWT = MAXB / 16;   // 16-row tiles of a minibatch
@@ -158,16 +156,16 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
 }
 
 // cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows,
-// 16 bytes per thread: thread -> row (tid / 16) % 16, units c, c + 1 of every
-// block of 64; n_unit is a multiple of 16, so part of the threads skip the
-// last block)
+// 16 bytes per thread: thread -> row tid / 16, units 2 c, 2 c + 1 of every
+// block of 32; n_unit is a multiple of 16, so half the threads skip the last
+// block where it is a multiple of 16 only)
 __device__ __forceinline__ void flush_stash(const double* act, nb_gd* dst,
                                             int ld, int n_unit, int tile,
                                             int tid) {
-  const unsigned r = (tid >> 4) & 15, c = 2 * (tid & 15) + 32 * (tid >> 8);
+  const unsigned r = tid >> 4, c = 2 * (tid & 15);
   nb_gd* row = dst + (tile * 16) * ld;               // wave-uniform
   const unsigned off = r * ld + c;
-  for (int u = 0; u < n_unit; u += 64) {
+  for (int u = 0; u < n_unit; u += 32) {
     if (u + (int)c < n_unit) {
       const nb_d2 v = {act[(c + u) * LS + r], act[(c + 1 + u) * LS + r]};
       *(NB_G nb_d2*)(row + off + u) = v;
@@ -285,14 +283,12 @@ __device__ __forceinline__ void fb_gather(const NetData& nd, int D, int tile,
   const nb_gd* xr = nd.X + (long long)row * D;
 #pragma unroll
   for (int j = 0; j < KT1; ++j) {
-    const int f = 4 * (4 * j + (wave & 3)) + lg;
+    const int f = 4 * (4 * j + wave) + lg;
     const double v = xr[f < D ? f : D - 1];
     in.x[j] = (f < D) ? (valid ? v : 0.0) : ((f == D) ? 1.0 : 0.0);
   }
   const double yv = nd.y[row];
   in.yv = (wave == 0 && lg == 0 && valid) ? yv : 0.0;
-  // (wavefronts 4-7 of the workgroup read in-range garbage that is never
-  // used: the input block is filled by the first four)
 }
 
 #ifdef NB_TRAIN_TIMING
@@ -395,51 +391,51 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   // one contiguous 512-byte row block per operand), a layer or more ahead of
   // their use; nothing else sits in the memory queue in front of them -- the
   // stash stores of the step are issued at the very end. ---------------------
-  // (eight wavefronts: wavefront w < 7 owns output tile w of layer 1 and of
-  // the last backward product; the four-tile layers stay with wavefronts 0-3)
-  double w1r[KS1], w2r[26], w3r[14], w4r[6], b4r[2], b3r[6], b2r[14];
-  if (wave < NB_HT1) load_ops_l1<KT1>(rW, W1 + wave * NB_TILE, ks1, lane, w1r);
-  if constexpr (KT1 <= 4) {
-    if (wave < NB_HT2) load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
-  }
+  double w1r[2][KS1], w2r[26], w3r[14], w4r[6], b4r[2], b3r[6], b2r[2][14];
+  const int ht1b = (wave + 4 < NB_HT1) ? wave + 4 : wave;
+  load_ops_l1<KT1>(rW, W1 + wave * NB_TILE, ks1, lane, w1r[0]);
+  load_ops_l1<KT1>(rW, W1 + ht1b * NB_TILE, ks1, lane, w1r[1]);
+  if constexpr (KT1 <= 4)
+    load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
 
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
-  if (wave < 4) {
 #pragma unroll
-    for (int j = 0; j < KT1; ++j)
-      sA0[(4 * (4 * j + wave) + lg) * LS + li] = rows.x[j];
-  }
+  for (int j = 0; j < KT1; ++j)
+    sA0[(4 * (4 * j + wave) + lg) * LS + li] = rows.x[j];
   lds_barrier();
   FB_STAMP(11);
-  if constexpr (KT1 > 4) {
-    if (wave < NB_HT2) load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
-  }
+  if constexpr (KT1 > 4)
+    load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
 
-  // ---- layer 1: output tile = wave (seven tiles) --------------------------
-  if (wave < NB_HT1) {
+  // ---- layer 1: output tiles wave, wave + 4 ------------------------------
+  {
     double in[KS1];
     lds_operand<KS1>(sA0, lane, in);
-    const nb_d4 acc = mma_l1<KS1>(w1r, in, ks1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double v = fmax(acc[r], 0.0);
-      const int unit = 16 * wave + 4 * r + lg;
-      if (unit == NB_H1) v = 1.0;                    // bias unit
-      sA1[unit * LS + li] = v;
+    for (int rep = 0; rep < 2; ++rep) {
+      const int ht = wave + 4 * rep;
+      if (ht < NB_HT1) {
+        const nb_d4 acc = mma_l1<KS1>(w1r[rep], in, ks1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = fmax(acc[r], 0.0);
+          const int unit = 16 * ht + 4 * r + lg;
+          if (unit == NB_H1) v = 1.0;                    // bias unit
+          sA1[unit * LS + li] = v;
+        }
+      }
     }
   }
   lds_barrier();
   FB_STAMP(12);
   // the remaining operands, in the order of use (in flight during layer 2)
-  if (wave < NB_HT3) {
-    load_ops<14, NB_HT3>(rW, W3 + wave * NB_TILE, lane, w3r);
-    if (wave == 0) load_ops<6, 1>(rW, W4, lane, w4r);
-    load_ops<2, NB_HT3>(rT, T4 + wave * NB_TILE, lane, b4r);
-  }
-  if (wave < NB_HT2) load_ops<6, NB_HT2>(rT, T3 + wave * NB_TILE, lane, b3r);
+  load_ops<14, NB_HT3>(rW, W3 + (wave & 1) * NB_TILE, lane, w3r);
+  load_ops<6, 1>(rW, W4, lane, w4r);
+  load_ops<2, NB_HT3>(rT, T4 + (wave & 1) * NB_TILE, lane, b4r);
+  load_ops<6, NB_HT2>(rT, T3 + wave * NB_TILE, lane, b3r);
 
-  // ---- layer 2: output tile = wave (four tiles) ---------------------------
-  if (wave < NB_HT2) {
+  // ---- layer 2: output tile = wave ----------------------------------------
+  {
     double in[26];
     lds_operand<26>(sA1, lane, in);
     const nb_d4 acc = mma<26>(w2r, in);
@@ -455,7 +451,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(13);
   // (the operands of the last backward product take the registers layer 2's
   // have left; five stages until they are needed)
-  if (wave < NB_HT1) load_ops<14, NB_HT1>(rT, T2 + wave * NB_TILE, lane, b2r);
+  load_ops<14, NB_HT1>(rT, T2 + wave * NB_TILE, lane, b2r[0]);
+  load_ops<14, NB_HT1>(rT, T2 + ht1b * NB_TILE, lane, b2r[1]);
 
   // ---- layer 3: two output tiles ------------------------------------------
   if (wave < NB_HT3) {
@@ -510,7 +507,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(16);
 
   // ---- delta 2 --------------------------------------------------------------
-  if (wave < NB_HT2) {
+  {
     double dout[6];
     lds_operand<6>(sD3, lane, dout);
     const nb_d4 acc = mma<6>(b3r, dout);
@@ -526,16 +523,22 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(17);
 
   // ---- delta 1 --------------------------------------------------------------
-  if (wave < NB_HT1) {
+  {
     double dout[14];
     lds_operand<14>(sD2, lane, dout);
-    const nb_d4 acc = mma<14>(b2r, dout);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int unit = 16 * wave + 4 * r + lg;
-      double v = acc[r];
-      if (sA1[unit * LS + li] == 0.0 || unit == NB_H1) v = 0.0;
-      sD1[unit * LS + li] = v;
+    for (int rep = 0; rep < 2; ++rep) {
+      const int kt = wave + 4 * rep;
+      if (kt < NB_HT1) {
+        const nb_d4 acc = mma<14>(b2r[rep], dout);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = 16 * kt + 4 * r + lg;
+          double v = acc[r];
+          if (sA1[unit * LS + li] == 0.0 || unit == NB_H1) v = 0.0;
+          sD1[unit * LS + li] = v;
+        }
+      }
     }
   }
   lds_barrier();
@@ -568,14 +571,14 @@ __device__ __forceinline__ void fb_clear_deltas(const NetState& st, int ld0,
   nb_gd* d2 = sp.D2 + tile * 16 * LD2;
   nb_gd* d3 = sp.D3 + tile * 16 * LD3;
   nb_gd* d4 = sp.D4 + tile * 16 * LD4;
-  for (unsigned i = tid; i < 16 * LD1; i += TR_THREADS) d1[i] = 0.0;
-  for (unsigned i = tid; i < 16 * LD2; i += TR_THREADS) d2[i] = 0.0;
-  for (unsigned i = tid; i < 16 * LD3; i += TR_THREADS) d3[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD1; i += 256) d1[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD2; i += 256) d2[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD3; i += 256) d3[i] = 0.0;
   if (tid < 16 * LD4) d4[tid] = 0.0;
 }
 
 template <int KT1>
-__global__ void __launch_bounds__(TR_THREADS)
+__global__ void __launch_bounds__(256)
 nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   __shared__ __attribute__((aligned(16))) double lds[FbLds<KT1>::TOTAL];
   const NetState st = a.nets[blockIdx.y];
@@ -584,8 +587,7 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
     if (st.scal[4] == 0.0) fb_clear_deltas(st, 16 * KT1, tile);
     return;
   }
-  for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += TR_THREADS)
-    lds[i] = 0.0;
+  for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
   __syncthreads();
   FbRows<KT1> rows;
   const NetData nd = shared_data(a, (int)blockIdx.y);
@@ -624,7 +626,6 @@ __device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) 
 // round of 32 workgroups covers a network for every n_dim.
 constexpr int G_JOB_INTS = 5;     // layer (0..3), kt0, nk, ht0, nh
 constexpr int G_MAX_TILES = 4;
-constexpr int G_RED_TILE = TR_NW * 256;   // partial tiles of one weight tile
 
 struct GLayer {
   const nb_gd* as;    // activations of the layer's input  (rows x lda)
@@ -662,21 +663,18 @@ __device__ __forceinline__ GLayer g_layer(const NetState& st, int kt1,
   return g;
 }
 
-// one 16-column block of a stash matrix, rows 16 rt + 4 q + lg of the row
-// tiles rt = half, half + 2, ...: the operands of wavefront (q, half)
-// (wave-uniform row-tile address + a lane offset); slots past the last row
-// tile hold zeros
-constexpr int G_NRT = (G_ROWT + 1) / 2;
+// one 16-column block of a stash matrix, rows 16 rt + 4 wave + lg: the
+// operands of quarter `wave` (wave-uniform row-tile address + a lane offset)
 __device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
-                                           int q, int half, unsigned lane,
+                                           int wave, unsigned lane,
                                            double* v) {
   const unsigned li = lane & 15, lg = lane >> 4;
   const unsigned off = lg * ld + li;
-  const nb_gd* p = base + 16 * col + 4 * q * ld + 16 * half * ld;
+  const nb_gd* p = base + 16 * col + 4 * wave * ld;
 #pragma unroll
-  for (int i = 0; i < G_NRT; ++i) {
-    v[i] = (2 * i + half < G_ROWT) ? ld_xcd(&p[off]) : 0.0;
-    p += 32 * ld;
+  for (int rt = 0; rt < G_ROWT; ++rt) {
+    v[rt] = ld_xcd(&p[off]);
+    p += 16 * ld;
   }
 }
 
@@ -721,43 +719,33 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   asm volatile("" : "+v"(lane_));
   const unsigned lane = lane_;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = wave & 3, half = wave >> 2;
   const unsigned li = lane & 15, lg = lane >> 4;
   const int layer = jb.layer, kt0 = jb.kt0, nk = jb.nk, ht0 = jb.ht0,
             nh = jb.nh;
   const GLayer g = g_layer(st, a.kt1, layer);
   G_STAMP(33);
-  double av[2][G_NRT], bv[2][G_NRT];
-  g_load_col(g.as, g.lda, kt0, q, half, lane, av[0]);
-  g_load_col(g.bs, g.ldb, ht0, q, half, lane, bv[0]);
-  if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, q, half, lane, av[1]);
-  if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, q, half, lane, bv[1]);
+  double av[2][G_ROWT], bv[2][G_ROWT];
+  g_load_col(g.as, g.lda, kt0, wave, lane, av[0]);
+  g_load_col(g.bs, g.ldb, ht0, wave, lane, bv[0]);
+  if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, wave, lane, av[1]);
+  if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, wave, lane, bv[1]);
   G_STAMP(30);
   after_loads();
-  // Adam: the tiles of the job are dealt out over the two halves of the
-  // workgroup (four tiles: two each; two tiles: one each; one tile: half 0),
-  // wavefront (rq, half) owns rows lg + 4 rq of its tiles
-  const int n_t = nk * nh;
-  auto owner = [&](int ia, int ib) __attribute__((always_inline)) {
-    return n_t == 4 ? ia : (n_t == 2 ? (nk == 2 ? ia : ib) : 0);
-  };
-  // this lane's element of its tiles: row lg + 4 q, column li
-  const unsigned eoff = (lg + 4 * q) * 16 + li;        // moments: row major
-  const unsigned woff_e = tile_index(lg + 4 * q, li);
-  const unsigned toff_e = tile_index(li, lg + 4 * q);
+  // this lane's element of every tile of the job: row lg + 4 wave, column li
+  const unsigned eoff = (lg + 4 * wave) * 16 + li;     // moments: row major
+  const unsigned woff_e = tile_index(lg + 4 * wave, li);
+  const unsigned toff_e = tile_index(li, lg + 4 * wave);
   double w_old[G_MAX_TILES], m_old[G_MAX_TILES], v_old[G_MAX_TILES];
 #pragma unroll
   for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
-      if (ia < nk && ib < nh && owner(ia, ib) == half) {
+      if (ia < nk && ib < nh) {
         const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
         w_old[2 * ia + ib] = ld_xcd(&(st.W + woff)[woff_e]);
         m_old[2 * ia + ib] = ld_xcd(&(st.M + woff)[eoff]);
         v_old[2 * ia + ib] = ld_xcd(&(st.V + woff)[eoff]);
       }
-  // partial tiles: wavefront (q, half) contracts k-step q of its row tiles;
-  // red[tile][wavefront][register][lane]
 #pragma unroll
   for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
@@ -765,11 +753,11 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
       if (ia < nk && ib < nh) {
         nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < G_NRT; ++i)
-          acc = MFMA(av[ia][i], bv[ib][i], acc);
+        for (int rt = 0; rt < G_ROWT; ++rt)
+          acc = MFMA(av[ia][rt], bv[ib][rt], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          red[(((2 * ia + ib) * TR_NW + wave) * 4 + r) * 64 + lane] = acc[r];
+          red[(((2 * ia + ib) * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
       }
   G_STAMP(31);
   lds_barrier();
@@ -779,14 +767,10 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
-      if (ia < nk && ib < nh && owner(ia, ib) == half) {
+      if (ia < nk && ib < nh) {
         const int t = 2 * ia + ib;
-        // register q of every wavefront's partial: rows lg + 4 q; the eight
-        // partials are added in wavefront order (fixed: reproducible)
-        const double* p = red + ((t * TR_NW) * 4 + q) * 64 + lane;
-        double sum = p[0];
-#pragma unroll
-        for (int j = 1; j < TR_NW; ++j) sum += p[j * 4 * 64];
+        const double* p = red + (t * 16 + wave) * 64 + lane;
+        const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
         const double gr = sum * inv_nb;
         const double m = a.b1 * m_old[t] + (1.0 - a.b1) * gr;
         const double v = a.b2 * v_old[t] + (1.0 - a.b2) * (gr * gr);
@@ -804,9 +788,9 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   G_STAMP(32);
 }
 
-__global__ void __launch_bounds__(TR_THREADS)
+__global__ void __launch_bounds__(256)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
-  __shared__ __attribute__((aligned(16))) double red[G_MAX_TILES * G_RED_TILE];
+  __shared__ __attribute__((aligned(16))) double red[G_MAX_TILES * 1024];
   const NetState st = a.nets[blockIdx.y];
   if (st.scal[4] != 0.0) return;                 // network already stopped
   // the first workgroup also folds the step's loss (the resident kernel gives
@@ -946,7 +930,7 @@ __device__ const int g_stamp_order[19] = {0, 11, 12, 13, 14, 15, 16, 17,
 // concurrent trainer's, which leave at once here, or any other kernel's --
 // pass while this one is resident)
 template <int KT1>
-__global__ void __launch_bounds__(TR_THREADS, 1)
+__global__ void __launch_bounds__(256, 2)
 nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
   // own disjoint XCDs; map.net[x] = network of XCD x or -1
@@ -957,11 +941,9 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // grid, but not necessarily starting at XCD 0 when several queues are
   // active.)
   __shared__ int sh_slot;
-  constexpr int LDS_D = FbLds<KT1>::TOTAL > FbLds<KT1>::G_RED +
-                                               G_MAX_TILES * G_RED_TILE
-                            ? FbLds<KT1>::TOTAL
-                            : FbLds<KT1>::G_RED + G_MAX_TILES * G_RED_TILE;
-  __shared__ __attribute__((aligned(16))) double lds[LDS_D];
+  __shared__ __attribute__((aligned(16))) double lds[FbLds<KT1>::TOTAL];
+  static_assert(FbLds<KT1>::TOTAL - FbLds<KT1>::G_RED >= G_MAX_TILES * 1024,
+                "the partial tiles of G fit behind the input block");
   const int n_nets = map.n_nets;
   unsigned xcc_id;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
@@ -1001,8 +983,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // the zero padding of the input block (rows >= D + 1 of the last k-tile are
   // multiplied by zero weights and must not hold NaN bit patterns); every
   // step rewrites exactly the rows it fills
-  for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += TR_THREADS)
-    lds[i] = 0.0;
+  for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
   xcd_barrier(counter, err, phase, slots, few);
   // the Adam step counter lives with the network (epoch_body keeps it)
   long long t_adam = (long long)ld_xcd(&st.scal[0]);
@@ -1438,7 +1419,7 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
     NB_HIP_CHECK(hipMemsetAsync(t->sync_dev, 0, SYNC_INTS * sizeof(int), s));
     // 32 workgroups per XCD: all of them for its network, or 16 for each of
     // its two
-    const dim3 grid(XCD_COUNT * XCD_SLOTS), blk(TR_THREADS);
+    const dim3 grid(XCD_COUNT * XCD_SLOTS), blk(256);
     switch (t->kt1) {
 #define NB_CASE(KT1_)                                                      \
       case KT1_:                                                           \
@@ -1469,7 +1450,7 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
       // (all G_ROWT row tiles: the ones past the end of a short minibatch
       // clear their delta rows)
-      const dim3 gfb(G_ROWT, t->E), gg(t->n_jobs, t->E), blk(TR_THREADS);
+      const dim3 gfb(G_ROWT, t->E), gg(t->n_jobs, t->E), blk(256);
       t->t_adam += 1;
       switch (t->kt1) {
 #define NB_CASE(KT1_)                                                      \
