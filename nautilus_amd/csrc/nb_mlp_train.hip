@@ -4,32 +4,22 @@
 // (_fit_stochastic), :297-389 (_backprop), _stochastic_optimizers.py:255-287
 // (Adam), _base.py:187-189 (squared loss)).
 //
-// All networks of an emulator train concurrently.  An Adam step has two
-// phases, separated by a grid-wide synchronisation (barriers in one XCD's L2
-// in the resident kernel, kernel boundaries in the two-launch form):
+// All networks of an emulator train concurrently.  Every Adam step is two
+// kernel launches on one stream (the kernel boundary is the grid-wide sync):
 //
 //  FB  one workgroup of four wavefronts per 16-row tile of the minibatch:
 //      forward through the four layers (the output tiles of a layer are split
 //      over the wavefronts, activations / deltas are exchanged through LDS in
-//      [unit][row] layout), output delta, backward deltas through W^T (read
-//      from transposed copies of the tiles); every weight operand is loaded a
-//      layer or more before its use.  Then, with all activations and deltas
-//      of the tile still in LDS, the tile's own share of every gradient:
-//      dW[k][h] = sum over its 16 rows of act[row][k] delta[row][h], four
-//      MFMAs per 16x16 weight tile, written as a PARTIAL tile (16-byte stores)
-//      to part[row tile][weight tile].
-//  R   all workgroups of the network: every thread owns a pair of weight
-//      elements, adds the partials of the row tiles in row-tile order (fixed:
-//      deterministic, no atomics; 16-byte loads, perfectly coalesced and
-//      evenly spread over the CUs) and applies Adam in place (plus the
-//      transposed copy the next backward pass reads).  The bias is row K of
-//      the weight matrix (the activations carry a constant 1 in column K).
-//
-// (Rounds 1-3 wrote activations and deltas to a stash and contracted them
-// over the minibatch in a second phase of 2 x 2-tile jobs: 80-106 KB of
-// 8-byte, four-lines-per-instruction operand loads per job out of the L2 --
-// the phase was bound by exactly those bytes, 13.9 k of a step's 35 k cycles
-// at n_dim = 50, and by its slowest job.)
+//      [unit][row] layout), output delta, backward deltas through W^T read
+//      from the same 16x16 tile-major weights; every weight operand is
+//      loaded before the first barrier; activations and deltas go row-major
+//      to a stash in global memory (L2 resident, ~0.8 MB per network).
+//  G   one workgroup of four wavefronts per 16x16 weight tile: dW = act^T delta
+//      over the rows of the minibatch, wavefront q contracting k-step q of
+//      every 16-row tile; the four partial tiles meet in LDS, are added in a
+//      fixed order (deterministic, no atomics) and every wavefront applies
+//      Adam to a quarter of the tile in place.  The bias is row K of the
+//      weight matrix (the activations carry a constant 1 in column K).
 //
 // Minibatch order comes from the host (numpy RandomState shuffles identical to
 // sklearn's), so the device sees exactly the reference's data order.
@@ -96,7 +86,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const nb_gd* p) {
 struct NetState {
   nb_gd* W; nb_gd* M; nb_gd* V;      // tile-major weights and Adam moments
   nb_gd* WT;                         // transposed tiles of layers 2-4
-  nb_gd* part;                       // gradient partials [row tile][weight tile]
+  nb_gd* stash;                      // A0 A1 A2 A3 D1 D2 D3 D4
   nb_gd* loss_curve;
   nb_gd* scal;    // [0] adam t  [1] best loss  [2] stale  [3] n_iter  [4] done
 };
@@ -119,6 +109,8 @@ struct TrainArgs {
   const nb_gd* X;
   const nb_gd* y;
   const nb_gi* perm;    // (E, n_epochs, n)
+  const nb_gi* jobs;    // G phase: n_jobs records of G_JOB_INTS ints
+  int n_jobs;
   long long n;
   int n_dim, kt1, n_epochs, max_iter, n_iter_no_change, batch;
   double tol, lr, b1, b2, eps;
@@ -161,6 +153,24 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
   for (int ks = 0; ks < NREG; ++ks)
     in[ks] = act[(16 * (ks >> 2) + 8 * ((ks >> 1) & 1) + 2 * lg + (ks & 1)) *
                      LS + li];
+}
+
+// cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows,
+// 16 bytes per thread: thread -> row tid / 16, units 2 c, 2 c + 1 of every
+// block of 32; n_unit is a multiple of 16, so half the threads skip the last
+// block where it is a multiple of 16 only)
+__device__ __forceinline__ void flush_stash(const double* act, nb_gd* dst,
+                                            int ld, int n_unit, int tile,
+                                            int tid) {
+  const unsigned r = tid >> 4, c = 2 * (tid & 15);
+  nb_gd* row = dst + (tile * 16) * ld;               // wave-uniform
+  const unsigned off = r * ld + c;
+  for (int u = 0; u < n_unit; u += 32) {
+    if (u + (int)c < n_unit) {
+      const nb_d2 v = {act[(c + u) * LS + r], act[(c + 1 + u) * LS + r]};
+      *(NB_G nb_d2*)(row + off + u) = v;
+    }
+  }
 }
 
 // A operands of one 16x16 output tile, k-steps 0 .. N-1 (N even): `tile0` is
@@ -300,7 +310,8 @@ __shared__ long long s_ts[48];
 #endif
 
 // LDS of a workgroup: the activation / delta blocks of FB in [unit][row]
-// layout.
+// layout; the G phase reuses everything behind the input block for its
+// partial tiles.
 template <int KT1>
 struct FbLds {
   static constexpr int LD0 = 16 * KT1;
@@ -313,37 +324,23 @@ struct FbLds {
   static constexpr int D2 = D3 + LD3 * LS;
   static constexpr int D1 = D2 + LD2 * LS;
   static constexpr int TOTAL = D1 + LD1 * LS;
+  static constexpr int G_RED = A1;             // 1024 doubles per tile
 };
 
-// weight tiles of a network in the order of W: layer 1 [kt][ht], layer 2, ...
-template <int KT1>
-struct TileMap {
-  static constexpr int N1 = KT1 * NB_HT1, N2 = NB_HT1 * NB_HT2,
-                       N3 = NB_HT2 * NB_HT3, N4 = NB_HT3;
-  static constexpr int NT = N1 + N2 + N3 + N4;
+struct StashPtrs {
+  nb_gd *A0, *A1, *A2, *A3, *D1, *D2, *D3, *D4;
 };
-
-// One gradient partial: the 16 x 16 tile act_block^T delta_block over the 16
-// rows of the workgroup's row tile.  Both blocks sit in LDS as [unit][row]:
-// the MFMA operand of k-step s is element (unit = lane % 16, row = 4 s +
-// lane / 16) of either.  The tile leaves as two 16-byte stores per lane,
-// registers (0, 1) then (2, 3): element (2 h + e) of lane l at
-// (h * 64 + l) * 2 + e.
-__device__ __forceinline__ void grad_operand(const double* blk, int block,
-                                             unsigned lane, double* v) {
-  const unsigned li = lane & 15, lg = lane >> 4;
-  const double* p = blk + (16 * block + li) * LS + lg;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) v[s] = p[4 * s];
-}
-__device__ __forceinline__ void grad_tile(const double* a4, const double* b4,
-                                          nb_gd* dst, unsigned lane) {
-  nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acc = MFMA(a4[s], b4[s], acc);
-  const nb_d2 lo = {acc[0], acc[1]}, hi = {acc[2], acc[3]};
-  *(NB_G nb_d2*)(dst + 2 * lane) = lo;
-  *(NB_G nb_d2*)(dst + 128 + 2 * lane) = hi;
+__device__ __forceinline__ StashPtrs stash_ptrs(const NetState& st, int ld0) {
+  StashPtrs p;
+  p.A0 = st.stash;
+  p.A1 = p.A0 + MAXB * ld0;
+  p.A2 = p.A1 + MAXB * LD1;
+  p.A3 = p.A2 + MAXB * LD2;
+  p.D1 = p.A3 + MAXB * LD3;
+  p.D2 = p.D1 + MAXB * LD1;
+  p.D3 = p.D2 + MAXB * LD2;
+  p.D4 = p.D3 + MAXB * LD3;
+  return p;
 }
 
 template <int KT1, bool CHECK_DONE>
@@ -384,6 +381,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   constexpr unsigned W3 = W2 + NB_HT1 * NB_HT2 * NB_TILE;
   constexpr unsigned W4 = W3 + NB_HT2 * NB_HT3 * NB_TILE;
   constexpr unsigned T2 = WT2, T3 = WT3, T4 = WT4;
+  const StashPtrs sp = stash_ptrs(st, LD0);
 
   const int pt = tile * 16 + li;
   const bool valid = pt < nb;
@@ -545,47 +543,38 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(18);
-  // ---- the row tile's share of every gradient (see the file comment); the
-  // tiles of a layer are dealt out over the wavefronts so that the block they
-  // share is read once: layer 1 / 2 by output tile, layer 3 / 4 by input tile
-  {
-    using TM = TileMap<KT1>;
-    nb_gd* part = st.part + (size_t)tile * TM::NT * NB_TILE;
-    double a4[4], b4[4];
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      const int ht = wave + 4 * rep;
-      if (ht < NB_HT1) {
-        grad_operand(sD1, ht, lane, b4);
-#pragma unroll
-        for (int kt = 0; kt < KT1; ++kt) {
-          grad_operand(sA0, kt, lane, a4);
-          grad_tile(a4, b4, part + (kt * NB_HT1 + ht) * NB_TILE, lane);
-        }
-      }
-    }
-    grad_operand(sD2, wave, lane, b4);
-#pragma unroll
-    for (int kt = 0; kt < NB_HT1; ++kt) {
-      grad_operand(sA1, kt, lane, a4);
-      grad_tile(a4, b4, part + (TM::N1 + kt * NB_HT2 + wave) * NB_TILE, lane);
-    }
-    grad_operand(sA2, wave, lane, a4);
-#pragma unroll
-    for (int ht = 0; ht < NB_HT3; ++ht) {
-      grad_operand(sD3, ht, lane, b4);
-      grad_tile(a4, b4,
-                part + (TM::N1 + TM::N2 + wave * NB_HT3 + ht) * NB_TILE, lane);
-    }
-    if (wave < NB_HT3) {
-      grad_operand(sA3, wave, lane, a4);
-      grad_operand(sD4, 0, lane, b4);
-      grad_tile(a4, b4, part + (TM::N1 + TM::N2 + TM::N3 + wave) * NB_TILE,
-                lane);
-    }
-  }
+  // ---- the stash for the G phase, all of it at the end: every block is still
+  // in LDS.  (Written per stage as soon as a block was complete, the stores
+  // sat in the same in-order memory queue as the weight operands of the next
+  // stages, and every stage ended up waiting for a store acknowledgement.)
+  flush_stash(sA0, sp.A0, LD0, LD0, tile, tid);
+  flush_stash(sA1, sp.A1, LD1, LD1, tile, tid);
+  flush_stash(sA2, sp.A2, LD2, LD2, tile, tid);
+  flush_stash(sA3, sp.A3, LD3, LD3, tile, tid);
+  flush_stash(sD4, sp.D4, LD4, LD4, tile, tid);
+  flush_stash(sD3, sp.D3, LD3, LD3, tile, tid);
+  flush_stash(sD2, sp.D2, LD2, LD2, tile, tid);
+  flush_stash(sD1, sp.D1, LD1, LD1, tile, tid);
   if (wave == 0 && lane == 0) st.scal[8 + tile] = lp;
   FB_STAMP(19);
+}
+
+// A 16-row tile past the end of a short minibatch (the last step of an
+// epoch): its delta rows are cleared, so that G can contract all G_ROWT row
+// tiles of the stash without looking at the batch size (stale activations
+// times zero deltas).
+__device__ __forceinline__ void fb_clear_deltas(const NetState& st, int ld0,
+                                                int tile) {
+  const StashPtrs sp = stash_ptrs(st, ld0);
+  const unsigned tid = threadIdx.x;
+  nb_gd* d1 = sp.D1 + tile * 16 * LD1;
+  nb_gd* d2 = sp.D2 + tile * 16 * LD2;
+  nb_gd* d3 = sp.D3 + tile * 16 * LD3;
+  nb_gd* d4 = sp.D4 + tile * 16 * LD4;
+  for (unsigned i = tid; i < 16 * LD1; i += 256) d1[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD2; i += 256) d2[i] = 0.0;
+  for (unsigned i = tid; i < 16 * LD3; i += 256) d3[i] = 0.0;
+  if (tid < 16 * LD4) d4[tid] = 0.0;
 }
 
 template <int KT1>
@@ -594,9 +583,10 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   __shared__ __attribute__((aligned(16))) double lds[FbLds<KT1>::TOTAL];
   const NetState st = a.nets[blockIdx.y];
   const int tile = (int)blockIdx.x;
-  // (row tiles past the end of a short minibatch leave no partial: R adds the
-  // partials of the tiles in use only)
-  if (tile * 16 >= nb) return;
+  if (tile * 16 >= nb) {
+    if (st.scal[4] == 0.0) fb_clear_deltas(st, 16 * KT1, tile);
+    return;
+  }
   for (int i = threadIdx.x; i < FbLds<KT1>::LD0 * LS; i += 256) lds[i] = 0.0;
   __syncthreads();
   FbRows<KT1> rows;
@@ -606,7 +596,7 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   fb_body<KT1, true>(a, st, (int)blockIdx.y, tile, nb, rows, lds);
 }
 
-// ---- R: the partials of the row tiles added up, Adam ------------------------
+// ---- G: dW of 16x16 weight tiles over the minibatch + Adam ------------------
 // the step's loss partials folded into the epoch sum, in tile order
 // (deterministic); one wavefront, partial i in lane i
 __device__ __forceinline__ void loss_fold(const NetState& st, int nb,
@@ -624,102 +614,190 @@ __device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) 
          (1.0 - pow(a.b1, (double)t_adam));
 }
 
+// A job of the G phase: a block of nk x nh (each 1 or 2) weight tiles of one
+// layer -- k-tiles kt0 .. kt0 + nk - 1, output tiles ht0 .. ht0 + nh - 1 --
+// whose gradients share their operand columns: the nk activation column
+// blocks and the nh delta column blocks are read once for the nk * nh tiles.
+// (A CU gets 26 bytes per clock out of the L2 with 8-byte loads per lane when
+// everything misses its L1, as it does behind a barrier
+// (profiles/tools/l2_read_bench.hip): the bytes a workgroup pulls per step are
+// what the phase costs.  One tile per job reads two column blocks per tile, a
+// 2 x 2 block one.)  The job list is built by the host (g_jobs) so that one
+// round of 32 workgroups covers a network for every n_dim.
+constexpr int G_JOB_INTS = 5;     // layer (0..3), kt0, nk, ht0, nh
+constexpr int G_MAX_TILES = 4;
+
+struct GLayer {
+  const nb_gd* as;    // activations of the layer's input  (rows x lda)
+  const nb_gd* bs;    // deltas of the layer's output      (rows x ldb)
+  int lda, ldb;
+  int ht_n, kt_n;     // tiles of the layer
+  int wbase;          // offset of the layer's tiles in W / M / V
+  int tbase;          // offset of its transposed tiles in WT, -1 for layer 1
+};
+
+// (wave-uniform: scalar registers)
+__device__ __forceinline__ GLayer g_layer(const NetState& st, int kt1,
+                                          int layer) {
+  const StashPtrs sp = stash_ptrs(st, 16 * kt1);
+  const int n_gt1 = kt1 * NB_HT1, n_gt2 = NB_HT1 * NB_HT2,
+            n_gt3 = NB_HT2 * NB_HT3;
+  GLayer g;
+  if (layer == 0) {
+    g.as = sp.A0; g.lda = 16 * kt1; g.bs = sp.D1; g.ldb = LD1;
+    g.ht_n = NB_HT1; g.kt_n = kt1; g.wbase = 0; g.tbase = -1;
+  } else if (layer == 1) {
+    g.as = sp.A1; g.lda = LD1; g.bs = sp.D2; g.ldb = LD2;
+    g.ht_n = NB_HT2; g.kt_n = NB_HT1; g.wbase = n_gt1 * NB_TILE;
+    g.tbase = WT2;
+  } else if (layer == 2) {
+    g.as = sp.A2; g.lda = LD2; g.bs = sp.D3; g.ldb = LD3;
+    g.ht_n = NB_HT3; g.kt_n = NB_HT2; g.wbase = (n_gt1 + n_gt2) * NB_TILE;
+    g.tbase = WT3;
+  } else {
+    g.as = sp.A3; g.lda = LD3; g.bs = sp.D4; g.ldb = LD4;
+    g.ht_n = 1; g.kt_n = NB_HT3;
+    g.wbase = (n_gt1 + n_gt2 + n_gt3) * NB_TILE;
+    g.tbase = WT4;
+  }
+  return g;
+}
+
+// one 16-column block of a stash matrix, rows 16 rt + 4 wave + lg: the
+// operands of quarter `wave` (wave-uniform row-tile address + a lane offset)
+__device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
+                                           int wave, unsigned lane,
+                                           double* v) {
+  const unsigned li = lane & 15, lg = lane >> 4;
+  const unsigned off = lg * ld + li;
+  const nb_gd* p = base + 16 * col + 4 * wave * ld;
+#pragma unroll
+  for (int rt = 0; rt < G_ROWT; ++rt) {
+    v[rt] = ld_xcd(&p[off]);
+    p += 16 * ld;
+  }
+}
+
 #ifdef NB_TRAIN_TIMING
 #define G_STAMP(i) NB_STAMP(timed, i)
 #else
 #define G_STAMP(i)
 #endif
 
-// One item = the element pair (2 h, 2 h + 1) of lane l of weight tile tau:
-// input units i = l / 16 + 4 (2 h + e), output unit j = l % 16 (the register
-// layout of the MFMA result, see grad_tile).  The items of a network are
-// dealt out over all threads of its `slots` workgroups; a thread adds the
-// partials of its pair in row-tile order and applies Adam (sklearn
-// _stochastic_optimizers.py:255-287) to W, M, V and, for the layers 2-4, to
-// the transposed copy the next backward pass reads.  `after_loads` runs
-// behind the loads of the first item (the resident kernel fetches the next
-// step's input rows there).
-template <int KT1, class Hook>
-__device__ __forceinline__ void reduce_adam(const TrainArgs& a,
-                                            const NetState& st, int slot,
-                                            int slots, int nb, double lr_t,
-                                            Hook&& after_loads,
-                                            bool timed = false) {
-  using TM = TileMap<KT1>;
-  int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));      // (nothing hoisted out of the step loop)
-  const int n_rt = (nb + 15) >> 4;    // row tiles of this minibatch
-  const double inv_nb = 1.0 / (double)nb;
-  const __amdgpu_buffer_rsrc_t rP = tile_rsrc(st.part);
-  constexpr int ITEMS = TM::NT * 128;
-  constexpr unsigned RT_BYTES = (unsigned)TM::NT * NB_TILE * 8;
-  bool hooked = false;
+// One job by a workgroup of four wavefronts.  Wavefront q contracts the rows
+// 16 rt + 4 q + lg of the minibatch (k-step q of every 16-row tile, in the
+// order of rt; all G_ROWT row tiles -- the delta rows past a short minibatch
+// are zero), so a tile is four independent chains of 13 MFMAs on four SIMDs;
+// all operand loads are issued before the first chain.  The partial tiles go
+// through LDS; wavefront r then owns rows lg + 4 r of every tile: gradient =
+// ((p0 + p1) + p2) + p3, Adam (sklearn _stochastic_optimizers.py:255-287) in
+// place, and for the layers 2-4 the transposed copy the next backward pass
+// reads.  `after_loads` runs behind the operand loads (the resident kernel
+// fetches the next step's input rows there).
+struct GJob { int layer, kt0, nk, ht0, nh; };
+
+__device__ __forceinline__ GJob g_job_record(const TrainArgs& a, int job) {
+  const nb_gi* rec = a.jobs + job * G_JOB_INTS;
+  GJob j;
+  j.layer = __builtin_amdgcn_readfirstlane(rec[0]);
+  j.kt0 = __builtin_amdgcn_readfirstlane(rec[1]);
+  j.nk = __builtin_amdgcn_readfirstlane(rec[2]);
+  j.ht0 = __builtin_amdgcn_readfirstlane(rec[3]);
+  j.nh = __builtin_amdgcn_readfirstlane(rec[4]);
+  return j;
+}
+
+template <class Hook>
+__device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
+                                      const GJob& jb, int nb, double lr_t,
+                                      double* red, Hook&& after_loads,
+                                      bool timed = false) {
+  int lane_ = threadIdx.x & 63;
+  // (opaque to the optimiser: per-lane offsets derived from it are
+  // recomputed every step instead of being kept -- and spilled -- across the
+  // forward / backward pass)
+  asm volatile("" : "+v"(lane_));
+  const unsigned lane = lane_;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned li = lane & 15, lg = lane >> 4;
+  const int layer = jb.layer, kt0 = jb.kt0, nk = jb.nk, ht0 = jb.ht0,
+            nh = jb.nh;
+  const GLayer g = g_layer(st, a.kt1, layer);
   G_STAMP(33);
-  for (int it = slot * 256 + tid_; it < ITEMS; it += slots * 256) {
-    const int tau = it >> 7, h = (it >> 6) & 1, ln = it & 63;
-    const unsigned voff = (unsigned)(tau * NB_TILE + (h * 64 + ln) * 2) * 8;
-    nb_d2 p[G_ROWT];
+  double av[2][G_ROWT], bv[2][G_ROWT];
+  g_load_col(g.as, g.lda, kt0, wave, lane, av[0]);
+  g_load_col(g.bs, g.ldb, ht0, wave, lane, bv[0]);
+  if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, wave, lane, av[1]);
+  if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, wave, lane, bv[1]);
+  G_STAMP(30);
+  after_loads();
+  // this lane's element of every tile of the job: row lg + 4 wave, column li
+  const unsigned eoff = (lg + 4 * wave) * 16 + li;     // moments: row major
+  const unsigned woff_e = tile_index(lg + 4 * wave, li);
+  const unsigned toff_e = tile_index(li, lg + 4 * wave);
+  double w_old[G_MAX_TILES], m_old[G_MAX_TILES], v_old[G_MAX_TILES];
 #pragma unroll
-    for (int t = 0; t < G_ROWT; ++t) {
-      p[t] = nb_d2{0.0, 0.0};
-      if (t < n_rt) p[t] = ld_xcd2(rP, voff, (unsigned)t * RT_BYTES);
-    }
-    const int li = ln & 15, lg = ln >> 4;
-    double w_old[2], m_old[2], v_old[2];
-    const nb_gd* W = st.W + tau * NB_TILE;
-    const nb_gd* M = st.M + tau * NB_TILE;
-    const nb_gd* V = st.V + tau * NB_TILE;
+  for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int i = lg + 4 * (2 * h + e);
-      w_old[e] = ld_xcd(&W[tile_index(i, li)]);
-      m_old[e] = ld_xcd(&M[i * 16 + li]);
-      v_old[e] = ld_xcd(&V[i * 16 + li]);
-    }
-    if (!hooked) { after_loads(); hooked = true; }
-    G_STAMP(30);
-    nb_d2 sum = p[0];
+    for (int ib = 0; ib < 2; ++ib)
+      if (ia < nk && ib < nh) {
+        const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
+        w_old[2 * ia + ib] = ld_xcd(&(st.W + woff)[woff_e]);
+        m_old[2 * ia + ib] = ld_xcd(&(st.M + woff)[eoff]);
+        v_old[2 * ia + ib] = ld_xcd(&(st.V + woff)[eoff]);
+      }
 #pragma unroll
-    for (int t = 1; t < G_ROWT; ++t) sum += p[t];      // (zeros past n_rt)
-    G_STAMP(31);
-    // transposed copy: tiles [ht][kt] of the layers 2-4
-    int tbase = -1;
-    if (tau >= TM::N1 + TM::N2 + TM::N3) {
-      tbase = WT4 + (tau - (TM::N1 + TM::N2 + TM::N3)) * NB_TILE;
-    } else if (tau >= TM::N1 + TM::N2) {
-      const int q = tau - (TM::N1 + TM::N2);             // kt * NB_HT3 + ht
-      tbase = WT3 + ((q % NB_HT3) * NB_HT2 + q / NB_HT3) * NB_TILE;
-    } else if (tau >= TM::N1) {
-      const int q = tau - TM::N1;                        // kt * NB_HT2 + ht
-      tbase = WT2 + ((q % NB_HT2) * NB_HT1 + q / NB_HT2) * NB_TILE;
-    }
+  for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int i = lg + 4 * (2 * h + e);
-      const double gr = sum[e] * inv_nb;
-      const double m = a.b1 * m_old[e] + (1.0 - a.b1) * gr;
-      const double v = a.b2 * v_old[e] + (1.0 - a.b2) * (gr * gr);
-      const double w = w_old[e] + -lr_t * m / (sqrt(v) + a.eps);
-      (st.M + tau * NB_TILE)[i * 16 + li] = m;
-      (st.V + tau * NB_TILE)[i * 16 + li] = v;
-      (st.W + tau * NB_TILE)[tile_index(i, li)] = w;
-      if (tbase >= 0) (st.WT + tbase)[tile_index(li, i)] = w;
-    }
-  }
-  if (!hooked) after_loads();
+    for (int ib = 0; ib < 2; ++ib)
+      if (ia < nk && ib < nh) {
+        nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int rt = 0; rt < G_ROWT; ++rt)
+          acc = MFMA(av[ia][rt], bv[ib][rt], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(((2 * ia + ib) * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
+      }
+  G_STAMP(31);
+  lds_barrier();
+  G_STAMP(36);
+  const double inv_nb = 1.0 / (double)nb;
+#pragma unroll
+  for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+      if (ia < nk && ib < nh) {
+        const int t = 2 * ia + ib;
+        const double* p = red + (t * 16 + wave) * 64 + lane;
+        const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
+        const double gr = sum * inv_nb;
+        const double m = a.b1 * m_old[t] + (1.0 - a.b1) * gr;
+        const double v = a.b2 * v_old[t] + (1.0 - a.b2) * (gr * gr);
+        const double w = w_old[t] + -lr_t * m / (sqrt(v) + a.eps);
+        const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
+        (st.M + woff)[eoff] = m;
+        (st.V + woff)[eoff] = v;
+        (st.W + woff)[woff_e] = w;
+        if (g.tbase >= 0) {
+          const int toff =
+              g.tbase + ((ht0 + ib) * g.kt_n + kt0 + ia) * NB_TILE;
+          (st.WT + toff)[toff_e] = w;
+        }
+      }
   G_STAMP(32);
 }
 
-template <int KT1>
 __global__ void __launch_bounds__(256)
 nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
+  __shared__ __attribute__((aligned(16))) double red[G_MAX_TILES * 1024];
   const NetState st = a.nets[blockIdx.y];
   if (st.scal[4] != 0.0) return;                 // network already stopped
   // the first workgroup also folds the step's loss (the resident kernel gives
-  // that to its last workgroup)
+  // that to its least loaded workgroup)
   if (blockIdx.x == 0 && threadIdx.x < 64) loss_fold(st, nb, (int)threadIdx.x);
-  reduce_adam<KT1>(a, st, (int)blockIdx.x, (int)gridDim.x, nb,
-                   adam_lr(a, t_adam), []() {});
+  g_job(a, st, g_job_record(a, (int)blockIdx.x), nb, adam_lr(a, t_adam), red,
+        []() {});
 }
 
 // end of epoch: loss curve and the stopping rule of _fit_stochastic
@@ -864,6 +942,8 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // active.)
   __shared__ int sh_slot;
   __shared__ __attribute__((aligned(16))) double lds[FbLds<KT1>::TOTAL];
+  static_assert(FbLds<KT1>::TOTAL - FbLds<KT1>::G_RED >= G_MAX_TILES * 1024,
+                "the partial tiles of G fit behind the input block");
   const int n_nets = map.n_nets;
   unsigned xcc_id;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
@@ -892,6 +972,8 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   int* err = counter + 1;
   const NetState st = a.nets[net];
   const NetData nd = fleet.d[net];
+  // this workgroup's job of the G phase (the same in every step)
+  const GJob my_job = g_job_record(a, slot < a.n_jobs ? slot : 0);
   int phase = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -952,6 +1034,8 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
         // neither of the two dependent loads is waited for where it is issued
         if (next_rows) row_next = fb_row_index(nd, slot, ep2, start2, nb2);
         fb_body<KT1, false>(a, st, net, slot, nb, rows, lds);
+      } else if (slot < G_ROWT) {
+        fb_clear_deltas(st, 16 * KT1, slot);
       }
       TR_STAMP(1);
       // (the step size -- two pow() -- is computed while waiting)
@@ -959,20 +1043,30 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
       const double lr_t = adam_lr(a, t_adam);
       xcd_wait(counter, err, phase, slots, few);
       TR_STAMP(2);
-      // R: the partials of the row tiles -> gradients -> Adam, the weight
-      // elements dealt out over all workgroups of the network (also the ones
-      // without a row tile in FB); the last workgroup folds the loss
+      // jobs slot, slot + 32, ... of the G phase (all 32 CUs of the XCD take
+      // part, also the ones without a row tile in FB; the host's job list
+      // fits one round); the last workgroup folds the loss
       if (slot == slots - 1 && wave == 3) loss_fold(st, nb, lane);
       // the rows of the next step (read-only data) are fetched behind the
-      // loads of this phase, back long before the barrier
+      // operand loads of this phase: in flight under its MFMA chains, back
+      // long before the barrier
       have_rows = next_rows && slot * 16 < nb;
-      reduce_adam<KT1>(a, st, slot, slots, nb, lr_t,
-                       [&]() __attribute__((always_inline)) {
-                         if (have_rows)
-                           fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next,
-                                          rows);
-                       },
-                       net == 0 && slot == 0);
+      {
+        bool fetched = false;
+        for (int job = slot; job < a.n_jobs; job += slots) {
+          g_job(a, st, job == slot ? my_job : g_job_record(a, job), nb, lr_t,
+                lds + FbLds<KT1>::G_RED,
+                [&]() __attribute__((always_inline)) {
+                  if (have_rows && !fetched)
+                    fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
+                  fetched = true;
+                },
+                net == 0 && slot == 0);
+          if (job + slots < a.n_jobs) lds_barrier();   // red is reused
+        }
+        if (have_rows && !fetched)
+          fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
+      }
       TR_STAMP(3);
       xcd_barrier(counter, err, phase, slots, few);
       TR_STAMP(4);
@@ -994,6 +1088,28 @@ double get_w(const double* tiles, int ht_n, int k, int h) {
   return tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE +
                tile_index(k & 15, h & 15)];
 }
+// The job list of the G phase (see g_job): blocks of up to 2 x 2 tiles per
+// layer, shaped so that a network needs at most 32 jobs -- one round of the
+// resident kernel's workgroups -- at every n_dim.
+std::vector<int> g_jobs(int kt1) {
+  std::vector<int> jobs;
+  auto blocks = [&](int layer, int kt_n, int ht_n, int bk, int bh) {
+    for (int kt = 0; kt < kt_n; kt += bk)
+      for (int ht = 0; ht < ht_n; ht += bh) {
+        const int rec[G_JOB_INTS] = {layer, kt, kt + bk <= kt_n ? bk : 1, ht,
+                                     ht + bh <= ht_n ? bh : 1};
+        jobs.insert(jobs.end(), rec, rec + G_JOB_INTS);
+      }
+  };
+  // layer 1 (kt1 x 7 tiles): pairs along k up to 64 dimensions, 2 x 2 beyond
+  blocks(0, kt1, NB_HT1, 2, kt1 <= 4 ? 1 : 2);
+  // layer 2 (7 x 4): pairs along h, 2 x 2 where layer 1 needs the workgroups
+  blocks(1, NB_HT1, NB_HT2, kt1 >= 7 ? 2 : 1, 2);
+  blocks(2, NB_HT2, NB_HT3, 2, 2);      // layer 3 (4 x 2)
+  blocks(3, NB_HT3, 1, 2, 1);           // layer 4 (2 x 1)
+  return jobs;
+}
+
 // transposed copy: tiles [ht][kt], element (hh, kk)
 void put_wt(double* tiles, int kt_n, int k, int h, double v) {
   tiles[((size_t)(h >> 4) * kt_n + (k >> 4)) * NB_TILE +
@@ -1042,6 +1158,8 @@ struct nb_trainer {
   double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
   long long t_adam = 0;
   int* sync_dev = nullptr;         // per network: counter, error, xcc mask
+  int* jobs_dev = nullptr;         // job list of the G phase
+  int n_jobs = 0;
   bool two_launch = false;         // fall back to two launches per step
   XcdMap xcd_map;                  // XCDs owned by this trainer's networks
   unsigned xcd_owned = 0;
@@ -1112,10 +1230,9 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
       t->shared_set = false;
   }
   t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
-  // gradient partials: one tile per (row tile of the minibatch, weight tile)
-  const long long part = (long long)G_ROWT * nb_net_tiles(t->kt1) * NB_TILE;
+  const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
   const long long curve = t->max_iter;
-  const long long per_net = 3 * t->n_w + WT_DOUBLES + part + curve + 32;
+  const long long per_net = 3 * t->n_w + WT_DOUBLES + stash + curve + 32;
   t->per_net = per_net;
   const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
   hipError_t e = hipMalloc((void**)&t->pool, bytes);
@@ -1124,6 +1241,15 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
     e = hipMalloc((void**)&t->nets_dev, n_networks * sizeof(NetState));
   if (e == hipSuccess)
     e = hipMalloc((void**)&t->sync_dev, SYNC_INTS * sizeof(int));
+  {
+    const std::vector<int> jobs = g_jobs(t->kt1);
+    t->n_jobs = (int)jobs.size() / G_JOB_INTS;
+    if (e == hipSuccess)
+      e = hipMalloc((void**)&t->jobs_dev, jobs.size() * sizeof(int));
+    if (e == hipSuccess)
+      e = hipMemcpy(t->jobs_dev, jobs.data(), jobs.size() * sizeof(int),
+                    hipMemcpyHostToDevice);
+  }
   // (NB_TRAIN_NO_RESIDENT: the library-side switch only, for the test of the
   // host's fallback when the resident kernel is not to be had)
   t->two_launch = n_networks > MAX_RESIDENT ||
@@ -1180,8 +1306,8 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
     double* base = t->pool + (size_t)i * per_net;
     s.W = (nb_gd*)base; s.M = s.W + t->n_w; s.V = s.M + t->n_w;
     s.WT = s.V + t->n_w;
-    s.part = s.WT + WT_DOUBLES;
-    s.loss_curve = s.part + part;
+    s.stash = s.WT + WT_DOUBLES;
+    s.loss_curve = s.stash + stash;
     s.scal = s.loss_curve + curve;
     t->nets_host.push_back(s);
     std::fill(w.begin(), w.end(), 0.0);
@@ -1273,6 +1399,7 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
   TrainArgs a;
   a.nets = t->nets_dev; a.X = (const nb_gd*)t->X; a.y = (const nb_gd*)t->y;
   a.perm = (const nb_gi*)perm_dev_of[0];
+  a.jobs = (const nb_gi*)t->jobs_dev; a.n_jobs = t->n_jobs;
   a.n = t->n; a.n_dim = t->n_dim; a.kt1 = t->kt1; a.n_epochs = n_epochs;
   a.max_iter = t->max_iter; a.n_iter_no_change = t->n_iter_no_change;
   a.batch = (int)((t->n < t->batch) ? t->n : t->batch);
@@ -1323,21 +1450,20 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
       const int nb = (int)((n - start < a.batch) ? (n - start) : a.batch);
       // (all G_ROWT row tiles: the ones past the end of a short minibatch
       // clear their delta rows)
-      const dim3 gfb(G_ROWT, t->E), gg(XCD_SLOTS, t->E), blk(256);
+      const dim3 gfb(G_ROWT, t->E), gg(t->n_jobs, t->E), blk(256);
       t->t_adam += 1;
       switch (t->kt1) {
 #define NB_CASE(KT1_)                                                      \
         case KT1_:                                                         \
           hipLaunchKernelGGL(nb_train_fb_kernel<KT1_>, gfb, blk, 0, s, a,  \
                              ep, start, nb);                               \
-          hipLaunchKernelGGL(nb_train_g_kernel<KT1_>, gg, blk, 0, s, a,    \
-                             nb, t->t_adam);                               \
           break;
         NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
         NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
 #undef NB_CASE
         default: nb_set_error("n_dim unsupported"); return NB_ERR_UNSUPPORTED;
       }
+      hipLaunchKernelGGL(nb_train_g_kernel, gg, blk, 0, s, a, nb, t->t_adam);
     }
     hipLaunchKernelGGL(nb_train_epoch_kernel, dim3(t->E), dim3(64), 0, s, a,
                        t->t_adam);
@@ -1485,6 +1611,7 @@ int nb_trainer_destroy(nb_trainer* t) {
   g_xcd_in_use &= ~t->xcd_owned;
   if (t->nets_dev) (void)hipFree(t->nets_dev);
   if (t->sync_dev) (void)hipFree(t->sync_dev);
+  if (t->jobs_dev) (void)hipFree(t->jobs_dev);
   if (t->pin_scal) (void)hipHostFree(t->pin_scal);
   if (t->pin_sync) (void)hipHostFree(t->pin_sync);
   for (int i = 0; i < nb_trainer::RING; ++i)
