@@ -135,6 +135,13 @@ __host__ __device__ inline double nb_unit(uint32_t hi, uint32_t lo) {
          (1.0 / 9007199254740992.0);
 }
 
+// uniform in (0, 1) from ONE word: (w + 1/2) / 2^32 (the normals of the
+// proposal draw: 2^-32 is far below anything a direction on the sphere can
+// resolve statistically, and a Philox call then feeds two Box-Muller pairs)
+__host__ __device__ inline double nb_unit32(uint32_t w) {
+  return ((double)w + 0.5) * (1.0 / 4294967296.0);
+}
+
 // two uniforms in [0,1) for proposal g, block, tag
 __host__ __device__ inline void nb_uniform_pair(uint64_t seed, uint64_t g,
                                                 uint32_t block, uint32_t tag,

@@ -20,11 +20,16 @@ done with them:
 * survivors are kept in proposal order (stable compaction), the counters are
   the reference's ``n_sample`` / ``n_reject`` at both levels.
 
-Stream layout per proposal (each Philox call yields two 53-bit uniforms):
-    tag 0, block 0 : (u_member, u_accept)
+Stream layout per proposal (a Philox call yields four 32-bit words):
+    tag 0, block 0 : (u_member, u_accept)        two 53-bit uniforms in [0, 1)
     tag 0, block 1 : (u_radius, unused)
-    tag 1, block j : Box-Muller pair -> normals 2j, 2j+1 (ellipsoid columns)
-    tag 2, block j : uniforms for cube columns 2j, 2j+1
+    tag 1, block q : two Box-Muller pairs -> normals 4q .. 4q+3 (ellipsoid
+                     columns); every word w is one uniform (w + 1/2) / 2^32
+                     in (0, 1): words (0, 1) -> normals 4q, 4q+1, words
+                     (2, 3) -> 4q+2, 4q+3
+    tag 2, block j : uniforms for cube columns 2j, 2j+1 (53 bits each)
+(Round 4: the normals took a 53-bit uniform per word pair before, one Philox
+call per Box-Muller pair; the integer rounds were half of the draw kernel.)
 """
 
 import numpy as np
@@ -72,12 +77,23 @@ def uniform_pair(seed, g, block, tag):
     return to_unit(w[0], w[1]), to_unit(w[2], w[3])
 
 
-def normal_pair(seed, g, block):
-    """Box-Muller on the tag-1 stream."""
-    u0, u1 = uniform_pair(seed, g, block, TAG_NORMAL)
-    r = np.sqrt(-2.0 * np.log(1.0 - u0))
-    t = 2.0 * np.pi * u1
-    return r * np.cos(t), r * np.sin(t)
+def unit32(w):
+    """Uniform in (0, 1) from one 32-bit word: (w + 1/2) / 2^32."""
+    return (w.astype(np.float64) + 0.5) / 4294967296.0
+
+
+def normal_quad(seed, g, block):
+    """Two Box-Muller pairs from block ``block`` of the tag-1 stream: the
+    normals 4 block .. 4 block + 3 of proposals ``g``."""
+    g = np.asarray(g, dtype=np.uint64)
+    w = philox4x32(g & MASK, g >> np.uint64(32), block, TAG_NORMAL,
+                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    out = []
+    for a, b in ((w[0], w[1]), (w[2], w[3])):
+        r = np.sqrt(-2.0 * np.log(unit32(a)))
+        t = 2.0 * np.pi * unit32(b)
+        out += [r * np.cos(t), r * np.sin(t)]
+    return out
 
 
 def member_cdf(log_v_all):
@@ -122,11 +138,10 @@ def union_propose(union, seed, offset, n_draw):
         if ell is not None:
             de = ell.n_dim
             z = np.zeros((len(rows), de))
-            for j in range((de + 1) // 2):
-                n0, n1 = normal_pair(seed, gi, j)
-                z[:, 2 * j] = n0
-                if 2 * j + 1 < de:
-                    z[:, 2 * j + 1] = n1
+            for q in range((de + 3) // 4):
+                for k, col in enumerate(normal_quad(seed, gi, q)):
+                    if 4 * q + k < de:
+                        z[:, 4 * q + k] = col
             z = z / np.sqrt(np.sum(z**2, axis=1))[:, None]
             z *= (u_radius[rows]**(1.0 / de))[:, None]
             x[np.ix_(rows, np.flatnonzero(~dim_cube))] = \

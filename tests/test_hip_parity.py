@@ -933,6 +933,35 @@ def test_emulator_training_ragged_batches(dev):
         assert np.allclose(nets[0].coefs_[0], ref.coefs[0], rtol=0, atol=1e-8)
 
 
+def test_emulator_training_large_n(dev):
+    """The trainer on a training set of the size the samplers reach late in
+    a run (120 000 rows: 600 Adam steps per epoch, shuffles from the native
+    MT19937 streams) against the restated MLPRegressor.fit: the first epochs
+    agree to rounding.  (Later epochs drift apart the way ANY two summation
+    orders do -- tests/tools/train_divergence.py prints the growth next to
+    that of two CPU runs which differ in summation order only.)"""
+    import torch
+    from nautilus_amd import emulator
+    from oracle import mlp_oracle as mo
+    rng = np.random.default_rng(21)
+    n, d, n_ep = 120000, 50, 3
+    x = rng.normal(size=(n, d))
+    r = np.linalg.norm(x[:, :8], axis=1) + 0.3 * rng.normal(size=n)
+    y = np.argsort(np.argsort(-r)) / n
+    nets, stats = emulator.train_networks(
+        torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), [0, 5],
+        max_epochs=n_ep)
+    assert stats['n_rows'] == n
+    for seed, net in zip([0, 5], nets):
+        ref = mo.fit_network(x, y, seed, max_iter=n_ep)
+        assert net.n_iter_ == ref.n_iter == n_ep
+        assert np.allclose(net.loss_curve_, ref.loss_curve, rtol=1e-9, atol=0)
+        for k in range(4):
+            assert np.allclose(net.coefs_[k], ref.coefs[k], rtol=0, atol=1e-8)
+            assert np.allclose(net.intercepts_[k], ref.intercepts[k], rtol=0,
+                               atol=1e-8)
+
+
 @pytest.mark.parametrize('name,e', [('emulator_D5_E1', 1),
                                     ('emulator_D20_E2', 2),
                                     ('emulator_D50_E4', 4)])
