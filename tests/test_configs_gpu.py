@@ -185,11 +185,15 @@ def test_C4_mixture_explored_and_evidence():
 
 def test_C5_funnel_real_size():
     """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
-    the device MVEE / mixture fit at 100 dimensions.  Default: 60 s of the
-    run and the invariants of a run in progress; NB_FULL_CONFIGS=1: the whole
-    run against the Monte-Carlo evidence of the reference's own funnel test
-    (tests/test_sampler.py:311-326) -- the committed full run is in
-    profiles/r03/configs.json."""
+    the device MVEE / mixture fit at 100 dimensions -- 60 s of the run and
+    the invariants of a run in progress.  The run itself does not end inside
+    any budget this project has (the exploration front
+    has to walk down the funnel to x_0 ~ 0.27, ~830 bounds at the measured
+    8.3 bounds per dimension, with training sets beyond 10^6 rows from bound
+    50 on; a GPU lease lasts one hour and a checkpoint of ~10 GB cannot
+    travel between leases).  What CAN be verified end to end is verified in
+    ``test_C5_family_finishes``: the same problem at the dimensions whose
+    runs finish."""
     c, s, done, host_calls = _run('C5', timeout=np.inf if FULL else 60.0)
     assert not host_calls
     _invariants(c, s)
@@ -197,3 +201,26 @@ def test_C5_funnel_real_size():
     if FULL:
         assert done and s.n_eff >= 10000
         assert abs(s.log_z - c['analytic_log_z']) < 0.1
+
+
+@pytest.mark.parametrize('name', ['C5-D10'] + (['C5-D20'] if FULL else []))
+def test_C5_family_finishes(name):
+    """Configuration 5's problem -- the D-dimensional form of the reference's
+    funnel test (tests/test_sampler.py:311-326), n_live 10000, 8 networks, the
+    reference's defaults otherwise (discard_exploration=False, n_eff 10000)
+    -- at the dimensions where a run ends: complete runs with the REFERENCE'S
+    OWN ASSERTION, |log Z - log Z_true| < 0.1 (measured: -0.0540 against
+    -0.0501 at D = 10 in 35 s and 80 bounds, -0.0619 against -0.0591 at D = 20
+    in 175 s and 166 bounds; profiles/r04/C5-D*.json), and the funnel's
+    posterior mean."""
+    c, s, done, host_calls = _run(name, discard_exploration=False)
+    assert not host_calls
+    assert done and s.explored and s.n_eff >= 10000
+    assert s.n_dead_bounds <= 2
+    assert abs(s.log_z - c['analytic_log_z']) < 0.1
+    pts, log_w, _ = s.posterior()
+    mean = np.average(pts, weights=np.exp(log_w), axis=0)
+    # x_0 ~ N(0.5, 0.1) truncated by the cube of the OTHER coordinates (wide
+    # slices lose mass): slightly below 0.5; all others symmetric about 0.5
+    assert 0.46 < mean[0] < 0.5
+    assert np.all(np.abs(mean[1:] - 0.5) < 0.01)
