@@ -32,7 +32,8 @@ def gpu_only():
         pytest.skip('no GPU')
 
 
-def _run(name, seed=0, timeout=np.inf, n_batch=None, n_eff=10000):
+def _run(name, seed=0, timeout=np.inf, n_batch=None, n_eff=10000,
+         discard_exploration=True):
     import torch
     from nautilus_amd import Sampler, geometry, unit_prior
     from nautilus_amd.configs import baseline_config
@@ -50,7 +51,8 @@ def _run(name, seed=0, timeout=np.inf, n_batch=None, n_eff=10000):
                     n_live=c['n_live'], n_networks=c['n_networks'],
                     n_batch=n_batch or c['n_batch'], vectorized=True,
                     seed=seed)
-        done = s.run(n_eff=n_eff, discard_exploration=True, timeout=timeout)
+        done = s.run(n_eff=n_eff, discard_exploration=discard_exploration,
+                     timeout=timeout)
         torch.cuda.synchronize()
     finally:
         geometry._best_of_inits_host = orig
