@@ -59,7 +59,7 @@ def parse():
     p.add_argument('--n-batch-setup', type=int, default=16384,
                    help='batch size while the bounds are built and every '
                         'shell receives its first batch (untimed setup).  '
-                        'Chosen by end-to-end time (DESIGN.md section 8): '
+                        'Chosen by end-to-end time (DESIGN.md section 11): '
                         'larger batches mean fewer, thicker shells -- 94 / 80 '
                         '/ 72 / 51 / 44 / 41 bounds at 2048 ... 32768 -- and '
                         'the whole run is shortest at 16384; log Z stays '
