@@ -107,6 +107,17 @@ for case in CASES:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     f2 = n * (d * (d + 1) + e * 2.0 * (100 * d + 6020))
+    for r in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(lib.nb_neural_score_rows(
+            dev._h, 1, 0, x.data_ptr(), None, n, out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        dt0 = time.perf_counter() - t0
+    print('   the same rows without an index list: %.2f ms, %.1f TFLOP/s = '
+          '%.3f' % (dt0 * 1e3, f2 / dt0 / 1e12, f2 / dt0 / 1e12 / PEAK),
+          flush=True)
     print('   gathered emulator scores (neural bound 1 of 4, %d rows by '
           'index): %.2f ms, %.1f TFLOP/s = %.3f' % (
               n, dt * 1e3, f2 / dt / 1e12, f2 / dt / 1e12 / PEAK), flush=True)

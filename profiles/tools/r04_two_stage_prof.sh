@@ -19,7 +19,7 @@ for c in 50 100; do
   find /tmp/ab_$c -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/accept_bench_${c}_kernel_stats.csv
   head -6 $OUT/accept_bench_${c}_kernel_stats.csv | cut -c1-160
 done
-for ctr in FETCH_SIZE WRITE_SIZE; do
+for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rm -rf /tmp/pm_$ctr
   timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pm_$ctr -o p -- python $R/profiles/tools/accept_bench.py 50 > /dev/null 2>&1
   python - "$ctr" <<'PY' | tee -a $OUT/cand_pmc.txt
@@ -28,10 +28,11 @@ c = sys.argv[1]
 fs = glob.glob('/tmp/pm_%s/**/*counter_collection.csv' % c, recursive=True)
 if not fs:
     print(c, 'no data'); sys.exit()
+rows = [r for r in csv.DictReader(open(fs[0])) if r['Counter_Name'] == c]
 for kern in ('nb_cand_kernel', 'nb_cand_compact_kernel', 'nb_eval_fast_kernel'):
-    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(fs[0]))
-            if kern + '<' in r['Kernel_Name'] + '<' and r['Kernel_Name'].startswith(('void ' + kern, kern)) and r['Counter_Name'] == c]
+    vals = [float(r['Counter_Value']) for r in rows
+            if ('::' + kern + '<') in r['Kernel_Name'] or ('::' + kern + '(') in r['Kernel_Name']]
     if vals:
-        print('%s %s dispatches %d mean KB %.1f (raw counter; FETCH_SIZE x 2 on gfx950 for bytes)' % (c, kern, len(vals), sum(vals) / len(vals)))
+        print('%s %s dispatches %d mean %.4g (raw counter; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE x 2 on gfx950 for bytes)' % (c, kern, len(vals), sum(vals) / len(vals)))
 PY
 done
