@@ -688,7 +688,13 @@ __attribute__((constructor)) static void nb_install_abort_trace(void) {
 
 // ---- two-stage queries (nb_cand.hip + nb_eval_fast.hip BATCH) --------------
 // groups per slice of a long list: the second stage's pass table holds 1024
-constexpr int NB_SLICE_GROUPS = 1024;
+// (NB_LIST_SLICE_GROUPS lowers it: the test of the slicing itself)
+static int nb_slice_groups() {
+  const char* e = getenv("NB_LIST_SLICE_GROUPS");
+  const int v = e != nullptr ? atoi(e) : 1024;
+  return v < 1 ? 1 : (v > 1024 ? 1024 : v);
+}
+#define NB_SLICE_GROUPS nb_slice_groups()
 
 int64_t nb_list_eval_work_bytes(const nb_boundlist* l, int64_t n) {
   const int g = l->n_groups < NB_SLICE_GROUPS ? l->n_groups : NB_SLICE_GROUPS;

@@ -6,6 +6,8 @@ decision value lies within 1e-11 of the decision threshold (fp64 sums are
 associated differently on the matrix cores than in numpy/BLAS); floating
 point outputs agree to 1e-11 relative."""
 
+import os
+
 import numpy as np
 import torch
 import pytest
@@ -458,6 +460,15 @@ def test_list_eval_matches_the_one_kernel_form(dev):
         assert torch.equal(lst.first_containing(x), ref_first)
     finally:
         device.WORK_BYTES = old
+    # a list with more groups than the second stage's pass table holds is
+    # evaluated in slices (rows already inside stay as they are, the first
+    # containing bound is kept): forced here with two groups per slice
+    os.environ['NB_LIST_SLICE_GROUPS'] = '2'
+    try:
+        assert torch.equal(lst.contains_any(x, as_flags=True), ref_any)
+        assert torch.equal(lst.first_containing(x), ref_first)
+    finally:
+        del os.environ['NB_LIST_SLICE_GROUPS']
 
 
 @pytest.fixture(scope='module')
