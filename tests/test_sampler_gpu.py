@@ -268,6 +268,35 @@ def test_sharded_bench_on_one_gpu(world):
     assert all(t > 0 for t in trained[:res['ranks_training']])
 
 
+def test_bench_over_rccl_single_rank():
+    """The collective code path of bench.py over the backend the driver's
+    --gpus N runs use: torch.distributed 'nccl' (= RCCL), here with the one
+    rank a single-GPU box allows (--force-comm) -- communicator set-up,
+    all_gather_into_tensor / all_reduce on device tensors, the asynchronous
+    point gathers, all_gather_object, the sharded emulator training."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(29500 + os.getpid() % 150),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3',
+           '--warmup', '1', '--dim', '6', '--n-live', '300', '--n-batch',
+           '2048', '--n-batch-setup', '512', '--backend', 'nccl',
+           '--force-comm', '--no-cpu-baseline']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    res = json.loads(line)
+    comm = res['communicator']
+    assert comm['backend'] == 'nccl' and comm['ranks_seen'] == 1
+    assert 'rccl_version' in comm
+    assert abs(res['log_z']) < 0.05
+    assert res['per_rank_seconds']['timed_steps'][0]['collectives'] > 0
+
+
 def _run_sharded(world, *extra):
     import subprocess
     import sys
