@@ -11,7 +11,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value
 
 all: $(LIB)
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h $(CSRC)/nb_tile.h $(CSRC)/nb_sym.h $(CSRC)/nb_mlp.h include/nautilus_hip.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h $(CSRC)/nb_tile.h $(CSRC)/nb_sym.h $(CSRC)/nb_mlp.h $(CSRC)/nb_draw.h include/nautilus_hip.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
@@ -25,7 +25,7 @@ $(LIB): $(OBJS)
 DBGDIR := build/obj_dbg
 DBGLIB := nautilus_amd/lib/libnautilus_hip_dbg.so
 DBGOBJS := $(patsubst $(CSRC)/%.hip,$(DBGDIR)/%.o,$(SRCS))
-$(DBGDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h $(CSRC)/nb_tile.h $(CSRC)/nb_sym.h $(CSRC)/nb_mlp.h include/nautilus_hip.h FORCE
+$(DBGDIR)/%.o: $(CSRC)/%.hip $(CSRC)/nb_common.h $(CSRC)/nb_tile.h $(CSRC)/nb_sym.h $(CSRC)/nb_mlp.h $(CSRC)/nb_draw.h include/nautilus_hip.h FORCE
 	@mkdir -p $(DBGDIR)
 	$(HIPCC) $(FLAGS) $(DEFS) -c $< -o $@
 debug: $(DBGOBJS)

@@ -153,6 +153,18 @@ int nb_accept(const nb_bound* bound, uint64_t seed, uint64_t offset,
               const double* x_dev, int64_t n, uint8_t* flags_dev,
               void* stream);
 
+/* nb_propose + nb_accept in one kernel (NautilusBound.sample,
+ * nautilus.py:212-222, for a bound with ONE full-ellipsoid outer member and
+ * ONE neural bound, n_dim <= 64: the case the sampling phase of a unimodal
+ * problem spends its time in): the acceptance kernel draws proposal offset + i
+ * of the bound's stream itself -- the same streams as nb_propose, the normals
+ * drawn straight into the matrix cores' operand layout, x = c + B z on the
+ * matrix cores --, writes it to x_dev[i] and its flags to flags_dev[i].
+ * nb_accept_draw_available: 1 if the bound carries the operands for it.      */
+int nb_accept_draw_available(const nb_bound* bound);
+int nb_accept_draw(const nb_bound* bound, uint64_t seed, uint64_t offset,
+                   int64_t n, double* x_dev, uint8_t* flags_dev, void* stream);
+
 /* Stable stream compaction (the reference's boolean indexing
  * `points[in_bound]`, `points[in_shell]`): rows with ((flags ^ flip) & mask)
  * != 0 are copied to out_dev in input order (flip = 1, mask = 1 keeps the

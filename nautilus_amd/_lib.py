@@ -68,6 +68,9 @@ _SIGNATURES = {
                              C.c_void_p, C.c_void_p]),
     'nb_accept': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                             C.c_int64, C.c_void_p, C.c_void_p]),
+    'nb_accept_draw_available': (C.c_int, [C.c_void_p]),
+    'nb_accept_draw': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'nb_compact_scratch_bytes': (C.c_int64, [C.c_int64]),
     'nb_compact_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint8,
                                   C.c_uint8, C.c_int64, C.c_int32, C.c_void_p,

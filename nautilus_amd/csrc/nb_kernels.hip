@@ -1,6 +1,8 @@
 // Proposal draw, stream compaction, shell statistics and small helpers.
 #include "nb_common.h"
 
+#include "nb_draw.h"
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -24,72 +26,6 @@ namespace {
 // footprint per wavefront at a quarter: 24 wavefronts per CU instead of 6
 // hide the latency of the dependent fp64 chains.
 // ---------------------------------------------------------------------------
-// ---- the two transcendental functions of a Box-Muller pair, for the
-// arguments the draw actually has: u = (w + 1/2) / 2^32, w a 32-bit word.
-// The library's log / sincospi handle every double (zeros, subnormals,
-// infinities, huge arguments) at twice the instructions; these are the
-// classic polynomial kernels (fdlibm: e_log.c, k_sin.c, k_cos.c) on the
-// reduced ranges, < 1 ulp against the exact values (checked against mpmath
-// over 2 x 10^6 words, the corner words included).
-
-// a / b for b in [1.7, 2.5]: reciprocal estimate + two Newton steps + residual
-__device__ __forceinline__ double draw_div(double a, double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  const double q = a * r;
-  return fma(fma(-b, q, a), r, q);
-}
-
-// log(u), u normal in (0, 1)
-__device__ __forceinline__ double draw_log(double u) {
-  double m = __builtin_amdgcn_frexp_mant(u);          // [0.5, 1)
-  int e = __builtin_amdgcn_frexp_exp(u);
-  const bool low = m < 0.70710678118654752;
-  m = low ? 2.0 * m : m;                              // [sqrt(1/2), sqrt(2))
-  const double k = (double)(low ? e - 1 : e);
-  const double f = m - 1.0;
-  const double s = draw_div(f, 2.0 + f);
-  const double z = s * s, w = z * z;
-  const double t1 =
-      w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-              3.999999999940941908e-01);
-  const double t2 =
-      z * fma(w, fma(w, fma(w, 1.479819860511658591e-01,
-                            1.818357216161805012e-01),
-                     2.857142874366239149e-01),
-              6.666666666666735130e-01);
-  const double R = t1 + t2, hfsq = 0.5 * f * f;
-  return k * 6.93147180369123816490e-01 -
-         ((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f);
-}
-
-// sin(2 pi u), cos(2 pi u) for u in (0, 1): quadrant q = rint(4 u), the rest
-// y = (4 u - q) pi / 2 in [-pi/4, pi/4] (4 u - q is exact)
-__device__ __forceinline__ void draw_sincos(double u, double& sn, double& cs) {
-  const double a = 4.0 * u, q = __builtin_rint(a);
-  const double y = (a - q) * 1.5707963267948966;
-  const double z = y * y;
-  const double r = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10,
-                                            -2.50507602534068634195e-08),
-                                     2.75573137070700676789e-06),
-                              -1.98412698298579493134e-04),
-                       8.33333333332248946124e-03);
-  const double s0 = fma(y * z, fma(z, r, -1.66666666666666324348e-01), y);
-  const double rc =
-      z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11,
-                                          2.08757232129817482790e-09),
-                                   -2.75573143513906633035e-07),
-                            2.48015872894767294178e-05),
-                     -1.38888888888741095749e-03),
-              4.16666666666666019037e-02);
-  const double c0 = 1.0 - (0.5 * z - z * rc);
-  const int qi = (int)q & 3;
-  const double sb = (qi & 1) ? c0 : s0, cb = (qi & 1) ? s0 : c0;
-  sn = (qi & 2) ? -sb : sb;
-  cs = ((qi + 1) & 2) ? -cb : cb;
-}
-
 constexpr int ZS = 65;     // LDS row stride (odd: transposed reads conflict-free)
 constexpr int DW = 4;      // wavefronts per workgroup
 constexpr int RB = 8;      // terms of a row product per trip
@@ -176,12 +112,8 @@ nb_draw_kernel(const double* __restrict__ blob, unsigned long long seed,
     for (int h = 0; h < 2; ++h) {
       const int j = 2 * q + h;                   // Box-Muller pair
       if (2 * j < ne) {
-        const double u0 = nb_unit32(h == 0 ? w.x : w.z);
-        const double u1 = nb_unit32(h == 0 ? w.y : w.w);
-        const double r = sqrt(-2.0 * draw_log(u0));
-        double sn, cs;
-        draw_sincos(u1, sn, cs);
-        const double z0 = r * cs, z1 = r * sn;
+        double z0, z1;
+        draw_normal_pair(h == 0 ? w.x : w.z, h == 0 ? w.y : w.w, z0, z1);
         zs[(2 * j) * ZS + lane] = z0;
         part += z0 * z0;
         if (2 * j + 1 < ne) {

@@ -148,6 +148,9 @@ class DeviceBound:
         _lib.check(lib.nb_bound_create(C.byref(desc), C.byref(handle)))
         self._h = handle
         self._lib = lib
+        # the blob carries the operands of nb_accept_draw (one full-ellipsoid
+        # member, one neural bound with networks, n_dim <= 64)
+        self.can_draw = bool(lib.nb_accept_draw_available(handle))
         del keep
 
     def __del__(self):
@@ -255,10 +258,25 @@ class DeviceBound:
         ``reuse=True`` (the bounds' refill loops): the launch works in the
         process-wide scratch buffers and the returned rows are only valid
         until the next such launch."""
-        x = self.propose(seed, offset, n_draw, reuse)
-        flags = self.accept(seed, offset, x, reuse)
+        if (self.can_draw and FUSED_DRAW and self.dense_need is not None and
+                self.dense_need > 0.5):
+            x, flags = self.accept_draw(seed, offset, n_draw, reuse)
+        else:
+            x = self.propose(seed, offset, n_draw, reuse)
+            flags = self.accept(seed, offset, x, reuse)
         out, counts, _ = compact_rows(x, flags, mask, reuse=reuse)
         return out, counts
+
+    def accept_draw(self, seed, offset, n, reuse=False):
+        """``propose`` + ``accept`` in one kernel (``nb_accept_draw``): the
+        acceptance kernel draws the proposals itself.  Returns (proposals,
+        flags)."""
+        x = _buffer('propose', (n, self.n_dim), torch.float64, reuse)
+        flags = _buffer('accept', (n,), torch.uint8, reuse)
+        _lib.check(self._lib.nb_accept_draw(self._h, seed, offset, n, _ptr(x),
+                                            _ptr(flags), _stream()))
+        DISPATCHES['nb_eval_fast_kernel'] += 1
+        return x, flags
 
 
 class DeviceBoundList:
@@ -338,6 +356,9 @@ class DeviceBoundList:
                            first)
 
 
+# NB_FUSED_DRAW=0: proposals through nb_propose + nb_accept also where the
+# acceptance kernel could draw them itself (A/B measurements)
+FUSED_DRAW = os.environ.get('NB_FUSED_DRAW', '1') != '0'
 GEOM_ANY, GEOM_FIRST, GEOM_SAMPLE = 0, 1, 2
 NO_BOUND = 2**31 - 1       # nb_list_eval: no bound of the list contains the row
 WORK_BYTES = 256 << 20     # candidate lists of one slab of rows
@@ -800,6 +821,7 @@ def _timed(name):
 # emulator scores behind it.
 DeviceBound.contains = _timed('bound_eval')(DeviceBound.contains)
 DeviceBound.accept = _timed('bound_eval')(DeviceBound.accept)
+DeviceBound.accept_draw = _timed('bound_eval')(DeviceBound.accept_draw)
 DeviceBound.neural_score = _timed('bound_eval')(DeviceBound.neural_score)
 DeviceBound.propose = _timed('nb_draw_kernel')(DeviceBound.propose)
 DeviceBound.contains_stream = _timed('nb_ell_stream_kernel')(
