@@ -356,9 +356,14 @@ class DeviceBoundList:
                            first)
 
 
-# NB_FUSED_DRAW=0: proposals through nb_propose + nb_accept also where the
-# acceptance kernel could draw them itself (A/B measurements)
-FUSED_DRAW = os.environ.get('NB_FUSED_DRAW', '1') != '0'
+# NB_FUSED_DRAW=1: sample_launch lets the acceptance kernel draw its own
+# proposals (nb_accept_draw) where the bound allows it.  Off by default: built,
+# parity-green and measured -- 11.11 against 11.04 ms per step of the headline
+# bench with nb_propose + nb_accept (profiles/r04/fused_draw_ab.txt): the
+# wavefronts of a workgroup run their per-pass prologues in lockstep behind
+# the stage barriers, so the draw's VALU work finds no MFMA stream of a
+# neighbour to hide in and costs what the separate kernel cost.
+FUSED_DRAW = os.environ.get('NB_FUSED_DRAW', '0') == '1'
 GEOM_ANY, GEOM_FIRST, GEOM_SAMPLE = 0, 1, 2
 NO_BOUND = 2**31 - 1       # nb_list_eval: no bound of the list contains the row
 WORK_BYTES = 256 << 20     # candidate lists of one slab of rows
