@@ -351,7 +351,11 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
       if (m_sample) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          if (valid[t]) {
+          if (valid[t] && K == 1) {
+            // one member: u > 1 - 1 / 1 = 0, true but for a 2^-53 event --
+            // the draw is not made
+            if (in_cube[t]) st[t] |= CS_OUTER;
+          } else if (valid[t]) {
             double u0, u_acc;
             nb_uniform_pair(a.seed, a.offset + (unsigned long long)row[t], 0u,
                             NB_TAG_CTRL, u0, u_acc);

@@ -518,10 +518,10 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         in_cube[t] = !point_any(cbad[t], lane);
-        double u0, u_acc;
-        nb_uniform_pair(a.seed, a.offset + (unsigned long long)pt[t], 0u,
-                        NB_TAG_CTRL, u0, u_acc);
-        acc_outer[t] = in_cube[t] && (u_acc > 1.0 - 1.0 / (double)K);
+        // (at most one outer member here: the acceptance draw u > 1 - 1 / k
+        // of union.py:318-319 is u > 0 -- true but for a 2^-53 event -- and
+        // is not made: ten Philox rounds per pass)
+        acc_outer[t] = in_cube[t];
         want[t] = valid[t] && acc_outer[t];
       }
     } else {
