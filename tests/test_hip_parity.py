@@ -445,14 +445,20 @@ def test_accept_draw_equals_propose_plus_accept(dev, d, monkeypatch):
             icpts.append(rs.uniform(-lim, lim, fo))
         nets.append(Network(coefs, icpts))
     emu = NeuralNetworkEmulator.from_weights(np.zeros(d), np.ones(d), nets)
-    neural = nbd.NeuralBound.from_parts(
-        nbd.Ellipsoid.from_params(c, 0.99 * B, np.linalg.inv(0.99 * B),
-                                  np.linalg.inv(0.9801 * cov)), emu, 0.0)
-    outer = nbd.Union.from_members([ell], unit=True)
-    outer.log_v_all = np.array([ell.log_v])
-    bound = nbd.NautilusBound.from_parts(outer, [neural],
-                                         rng=np.random.default_rng(1))
-    b = bound.device_bound()
+
+    def make(threshold):
+        neural = nbd.NeuralBound.from_parts(
+            nbd.Ellipsoid.from_params(c, 0.99 * B, np.linalg.inv(0.99 * B),
+                                      np.linalg.inv(0.9801 * cov)), emu,
+            threshold)
+        outer = nbd.Union.from_members([ell], unit=True)
+        outer.log_v_all = np.array([ell.log_v])
+        return nbd.NautilusBound.from_parts(
+            outer, [neural], rng=np.random.default_rng(1)).device_bound()
+    # the emulator's threshold at the median score of the bound's proposals
+    probe = make(0.0)
+    score = probe.neural_score(probe.propose(3, 0, 20000))[1]
+    b = make(float(score.median()))
     assert b.can_draw
     seed, offset, n = 1234567 + d, 10**11 + 3, 70001
     x_ref = b.propose(seed, offset, n)
