@@ -351,10 +351,6 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
                            d->members[0].n_ell == n_dim);
   const int64_t off_drawt = off;
   if (draw_tiles) off += 128 + (int64_t)dt * (dt + 1) / 2 * NB_TILE;
-  // candidate blocks (nb_cand.hip): members, then neural bounds
-  const int64_t cand_stride = dp + (int64_t)dt * (dt + 1) / 2 * NB_TILE;
-  const int64_t off_cand = off;
-  off += (int64_t)(K + M) * cand_stride;
   const int64_t total = off;
 
   std::vector<double> buf((size_t)total, 0.0);
@@ -379,8 +375,6 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   put_i64(buf, NB_H_OFF_STREAM, single_full ? off_stream : 0);
   put_i64(buf, NB_H_OFF_SHIFT, d->n_periodic > 0 ? off_shift : 0);
   put_i64(buf, NB_H_OFF_DRAWT, draw_tiles ? off_drawt : 0);
-  put_i64(buf, NB_H_OFF_CAND, off_cand);
-  put_i64(buf, NB_H_CAND_STRIDE, cand_stride);
   if (draw_tiles) {
     const nb_member_desc& md = d->members[0];
     for (int f = 0; f < n_dim; ++f)
@@ -532,28 +526,6 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
         fill_net(scale + dp + (size_t)e * net_stride, n_dim, kt1,
                  nd.mlp->coefs + 4 * e, nd.mlp->intercepts + 4 * e);
     }
-  }
-
-  // candidate blocks: the ell blocks' centre and lower-triangular tiles again,
-  // k-steps paired (nb_common.h hdr[21])
-  for (int j = 0; j < K + M; ++j) {
-    const size_t src = j < K ? (size_t)(off_members + j * ell_size)
-                             : (size_t)(off_neural + (j - K) * neural_stride);
-    const double* c = &buf[src + 2 + 2 * dp];
-    const double* tiles = c + dp;
-    double* cp = &buf[(size_t)(off_cand + j * cand_stride)];
-    double* tp = cp + dp;
-    for (int P = 0; P < 2 * dt; ++P)
-      for (int g = 0; g < 4; ++g)
-        for (int jj = 0; jj < 2; ++jj)
-          cp[(P * 4 + g) * 2 + jj] = c[4 * (2 * P + jj) + g];
-    for (int ht = 0; ht < dt; ++ht)
-      for (int kt = 0; kt <= ht; ++kt)
-        for (int s4 = 0; s4 < 4; ++s4)
-          for (int l = 0; l < 64; ++l)
-            tp[((size_t)(ht * (ht + 1)) / 2 + kt) * NB_TILE + (s4 >> 1) * 128 +
-               2 * l + (s4 & 1)] =
-                tiles[((size_t)kt * dt + ht) * NB_TILE + s4 * 64 + l];
   }
 
   nb_bound* b = new nb_bound();

@@ -68,19 +68,17 @@ struct CandArgs {
   unsigned long long* counters; // optional, as in nb_eval.hip
 };
 
-// the PAIRS of k-steps of a lower-triangular ellipsoid transform in execution
-// order: row tile ht runs the k-steps 0 .. 4 (ht + 1) - 1, i.e. pairs 0 .. 2
-// (ht + 1) - 1
+// the k-steps of a lower-triangular ellipsoid transform in execution order
 template <int DT>
-struct PairTable {
-  static constexpr int N = DT * (DT + 1);
-  unsigned char ht[N], pr[N];
-  constexpr PairTable() : ht(), pr() {
+struct StepTable {
+  static constexpr int N = 2 * DT * (DT + 1);
+  unsigned char ht[N], ks[N];
+  constexpr StepTable() : ht(), ks() {
     int i = 0;
     for (int h = 0; h < DT; ++h)
-      for (int p = 0; p < 2 * (h + 1); ++p) {
+      for (int k = 0; k < 4 * (h + 1); ++k) {
         ht[i] = (unsigned char)h;
-        pr[i] = (unsigned char)p;
+        ks[i] = (unsigned char)k;
         ++i;
       }
   }
@@ -88,23 +86,20 @@ struct PairTable {
 
 // inside[t] = point of tile t passes the block's box limits and lies inside
 // its ellipsoid.  X(t, ks) = coordinate slot ks of tile t (lane layout of
-// nb_tile.h).  `blk`: the ell block (box limits); `cnd`: its candidate block
-// (nb_common.h hdr[21]): centre and A operands of TWO k-steps per 16-byte
-// load, straight from L2 / L1, PD pairs ahead of their MFMAs.  (With 8-byte
-// loads the kernel sat at what a CU gets out of its L2 that way: the matrix
-// pipe was busy 63 % of a launch.)  Same summation order as ell_eval /
-// ell_eval_centre, so r2 is bit-identical to the other kernels'.
+// nb_tile.h).  Operands (A tile rows, centre) come from global memory PD
+// k-steps ahead; same summation order as ell_eval / ell_eval_centre, so r2
+// is bit-identical to the other kernels'.
 template <int DT, int T, int PD, class XF>
-__device__ __forceinline__ void cand_inside(const nb_gd* blk, const nb_gd* cnd,
-                                            bool has_ell, bool has_box, XF&& X,
-                                            int lane, bool (&inside)[T]) {
+__device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
+                                            bool has_box, XF&& X, int lane,
+                                            bool (&inside)[T]) {
   constexpr int DP = 16 * DT;
-  constexpr PairTable<DT> TAB{};
-  constexpr int N = PairTable<DT>::N;
+  constexpr StepTable<DT> TAB{};
+  constexpr int N = StepTable<DT>::N;
   const nb_gd* lo = blk + 2;
   const nb_gd* hi = lo + DP;
-  const nb_gd* cp = cnd;
-  const nb_gd* tiles = cnd + DP;
+  const nb_gd* c = hi + DP;
+  const nb_gd* tiles = c + DP;
   const int lg = lane >> 4;
   bool bad[T];
 #pragma unroll
@@ -126,13 +121,11 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, const nb_gd* cnd,
 #pragma unroll
   for (int t = 0; t < T; ++t) part[t] = 0.0;
   if (has_ell) {
-    double2 a[PD], cv[PD];
+    double a[PD], cv[PD];
     auto fetch = [&](int i, int slot) __attribute__((always_inline)) {
-      const int ht = TAB.ht[i], pr = TAB.pr[i];
-      a[slot] = *(const NB_G double2*)(
-          tiles + (ht * (ht + 1) / 2 + (pr >> 1)) * NB_TILE + (pr & 1) * 128 +
-          2 * lane);
-      cv[slot] = *(const NB_G double2*)(cp + (pr * 4 + lg) * 2);
+      const int ht = TAB.ht[i], ks = TAB.ks[i];
+      a[slot] = tiles[((ks >> 2) * DT + ht) * NB_TILE + (ks & 3) * 64 + lane];
+      cv[slot] = c[4 * ks + lg];
     };
 #pragma unroll
     for (int i = 0; i < PD && i < N; ++i) fetch(i, i);
@@ -142,28 +135,24 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, const nb_gd* cnd,
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int ht = TAB.ht[i], pr = TAB.pr[i];
-      if (pr == 0) {
+      const int ht = TAB.ht[i], ks = TAB.ks[i];
+      if (ks == 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
       }
-      const double2 av = a[i % PD];
-      double2 cc = cv[i % PD];
+      const double av = a[i % PD];
+      double cc = cv[i % PD];
       // the wait lands here; and the centre stays opaque: recognised as the
       // value of an earlier k-step it would keep every x - c of the block
       // alive next to x (twice the registers)
-      asm volatile("" : "+v"(cc.x), "+v"(cc.y) : "v"(av.x));
+      asm volatile("" : "+v"(cc) : "v"(av));
       __builtin_amdgcn_sched_barrier(0);
       if (i + PD < N) fetch(i + PD, i % PD);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < T; ++t)
-        acc[t] = MFMA(av.x, X(t, 2 * pr) - cc.x, acc[t]);
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-        acc[t] = MFMA(av.y, X(t, 2 * pr + 1) - cc.y, acc[t]);
+      for (int t = 0; t < T; ++t) acc[t] = MFMA(av, X(t, ks) - cc, acc[t]);
       __builtin_amdgcn_sched_barrier(0);
-      if (pr == 2 * (ht + 1) - 1) {
+      if (ks == 4 * (ht + 1) - 1) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -185,7 +174,7 @@ template <int DT, int T, int OCC>
 __global__ void __launch_bounds__(64 * CD_WPB)
 __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   constexpr int DP = 16 * DT;
-  constexpr int PD = OCC >= 4 ? 3 : 5;    // PAIRS of k-steps the operands run ahead
+  constexpr int PD = OCC >= 4 ? 6 : 10;   // k-steps the operands run ahead
   extern __shared__ int cur[];           // [n_groups][CD_WPB] fill counts
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -258,8 +247,6 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
       const long long neural_stride = nb_hdr(hdr, NB_H_NEURAL_STRIDE);
       const long long off_shift = nb_hdr(hdr, NB_H_OFF_SHIFT);
       const nb_gd* nblk0 = blob + nb_hdr(hdr, NB_H_OFF_NEURAL);
-      const nb_gd* cand0 = blob + nb_hdr(hdr, NB_H_OFF_CAND);
-      const long long cand_stride = nb_hdr(hdr, NB_H_CAND_STRIDE);
       // contains() of a bound with periodic dimensions sees recentred points
       // (nautilus.py:162-163, periodic.py:69-71: x <- (x + 0.5 - centre) mod
       // 1); proposals already live in the shifted frame.  Rare: the shift is
@@ -351,8 +338,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
           const bool has_ell = ((const NB_G long long*)blk)[0] > 0;
           const bool has_box = ((const NB_G long long*)blk)[1] != 0;
           bool ins[T];
-          cand_inside<DT, T, PD>(blk, cand0 + m * cand_stride, has_ell,
-                                 has_box, X, lane, ins);
+          cand_inside<DT, T, PD>(blk, has_ell, has_box, X, lane, ins);
 #pragma unroll
           for (int t = 0; t < T; ++t) k_cnt[t] += ins[t] ? 1 : 0;
         }
@@ -398,8 +384,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         if (!__any(any_want)) break;
         const nb_gd* nb_m = nblk0 + m * neural_stride;
         bool ins[T];
-        cand_inside<DT, T, PD>(nb_m, cand0 + (K + m) * cand_stride, true,
-                               false, X, lane, ins);
+        cand_inside<DT, T, PD>(nb_m, true, false, X, lane, ins);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const bool test = want[t] && !decided[t];

@@ -64,17 +64,6 @@ typedef NB_G int nb_gi;
 //                           g of row tile ht = feature 16 ht + 8 (r / 2) + 2 g
 //                           + r % 2) and whose k-steps run over z in slot
 //                           order (nb_eval_fast.hip)
-//   hdr[21] off_cand, hdr[22] cand_stride: K + M "candidate blocks" (members,
-//                           then neural bounds) for nb_cand.hip, which reads
-//                           its operands straight from L2: the centre and the
-//                           lower-triangular tiles of the ell block again,
-//                           with the operands of TWO consecutive k-steps side
-//                           by side (one 16-byte load per lane and pair; a CU
-//                           gets twice the bytes per clock out of its L2 with
-//                           16-byte loads): cp[(P * 4 + g) * 2 + j] = c[4 (2 P
-//                           + j) + g] (DP doubles), then tile p = ht (ht + 1)
-//                           / 2 + kt at p * 256, k-step s of lane l at (s / 2)
-//                           * 128 + 2 l + s % 2
 //
 // Ell block (member of the outer union, or ellipsoid of a neural bound):
 //   [0]            n_ell (as int64 bits; 0 => pure cube member, no MFMA work)
@@ -100,7 +89,7 @@ enum {
   NB_H_OFF_ULO, NB_H_OFF_UHI, NB_H_OFF_MEMBERS, NB_H_ELL_STRIDE,
   NB_H_OFF_NEURAL, NB_H_NEURAL_STRIDE, NB_H_OFF_DRAW, NB_H_DRAW_STRIDE,
   NB_H_NET_STRIDE, NB_H_KT1, NB_H_TOTAL, NB_H_OFF_STREAM, NB_H_OFF_SHIFT,
-  NB_H_OFF_DRAWT, NB_H_OFF_CAND, NB_H_CAND_STRIDE
+  NB_H_OFF_DRAWT
 };
 
 __host__ __device__ inline int64_t nb_hdr(const double* blob, int i) {
