@@ -490,7 +490,11 @@ unsigned long long* nb_eval_counters();
 // of wavefronts, padded list length (all multiples the kernels rely on).
 void nb_cand_shape(int dt, long long n, int* chunk, int* n_waves,
                    long long* n_pad) {
-  const int tile = 16 * 2;               // T = 2 tiles per wavefront
+  // tiles per wavefront: two up to n_dim 64, one beyond (two spill there,
+  // and a kernel with scratch in the stream makes the queue idle between
+  // dispatches in some process states: 9.8 instead of 5.0 ms per call at
+  // n_dim 100 after n_dim 50 kernels had run in the process)
+  const int tile = 16 * (dt <= 4 ? 2 : 1);
   const long long passes = (n + tile - 1) / tile;
   const long long per_wave = (passes + CD_MAX_WAVES - 1) / CD_MAX_WAVES;
   *chunk = (int)((per_wave < 1 ? 1 : per_wave) * tile);
@@ -548,10 +552,10 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
     case 2: rc = launch_cand_t<2, 2, 3>(a, stream); break;
     case 3: rc = launch_cand_t<3, 2, 2>(a, stream); break;
     case 4: rc = launch_cand_t<4, 2, 2>(a, stream); break;
-    case 5: rc = launch_cand_t<5, 2, 2>(a, stream); break;
-    case 6: rc = launch_cand_t<6, 2, 2>(a, stream); break;
-    case 7: rc = launch_cand_t<7, 2, 2>(a, stream); break;
-    case 8: rc = launch_cand_t<8, 2, 2>(a, stream); break;
+    case 5: rc = launch_cand_t<5, 1, 2>(a, stream); break;
+    case 6: rc = launch_cand_t<6, 1, 2>(a, stream); break;
+    case 7: rc = launch_cand_t<7, 1, 2>(a, stream); break;
+    case 8: rc = launch_cand_t<8, 1, 2>(a, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;
