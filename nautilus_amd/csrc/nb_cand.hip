@@ -490,14 +490,19 @@ unsigned long long* nb_eval_counters();
 // of wavefronts, padded list length (all multiples the kernels rely on).
 void nb_cand_shape(int dt, long long n, int* chunk, int* n_waves,
                    long long* n_pad) {
-  const int tile = 16 * 2;               // T = 2 tiles per wavefront
+  // Tiles per wavefront: two up to n_dim 64, ONE beyond.  Two are faster there
+  // in a process of their own (5.0 against 6.1 ms per 2^20 proposals at n_dim
+  // 100, K = M = 4) but spill (440 bytes of scratch per lane), and a kernel
+  // with that much scratch made the queue idle between the dispatches of a
+  // call whenever smaller-n_dim kernels had run in the process before: 9.8 to
+  // 17.5 ms per call (profiles/r04/accept_bench_50_then_100_one_process.txt;
+  // under rocprofv3 the gaps vanish, profiles/r04/trace_50_then_100.txt; a
+  // smaller grid did not help).  One tile per wavefront needs no scratch up
+  // to n_dim 112 and runs the same 6.1 ms in both situations.
+  const int tile = 16 * (dt <= 4 ? 2 : 1);
   // wavefronts of the grid: what the chip holds at once at the kernel's
   // register budget (two per SIMD from n_dim 33 on: 2048), twice that for the
-  // small kernels.  Beyond n_dim 64 the kernel spills (440 bytes of scratch
-  // per lane at n_dim 100), and the runtime sizes a dispatch's scratch by its
-  // grid: with 4096 wavefronts the queue idled between the dispatches of a
-  // call in some process states (9.8 instead of 5.0 ms per call at n_dim 100
-  // after n_dim 50 kernels had run in the process).
+  // small kernels
   const int max_waves = dt >= 3 ? CD_MAX_WAVES / 2 : CD_MAX_WAVES;
   const long long passes = (n + tile - 1) / tile;
   const long long per_wave = (passes + max_waves - 1) / max_waves;
@@ -556,10 +561,10 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
     case 2: rc = launch_cand_t<2, 2, 3>(a, stream); break;
     case 3: rc = launch_cand_t<3, 2, 2>(a, stream); break;
     case 4: rc = launch_cand_t<4, 2, 2>(a, stream); break;
-    case 5: rc = launch_cand_t<5, 2, 2>(a, stream); break;
-    case 6: rc = launch_cand_t<6, 2, 2>(a, stream); break;
-    case 7: rc = launch_cand_t<7, 2, 2>(a, stream); break;
-    case 8: rc = launch_cand_t<8, 2, 2>(a, stream); break;
+    case 5: rc = launch_cand_t<5, 1, 2>(a, stream); break;
+    case 6: rc = launch_cand_t<6, 1, 2>(a, stream); break;
+    case 7: rc = launch_cand_t<7, 1, 2>(a, stream); break;
+    case 8: rc = launch_cand_t<8, 1, 2>(a, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;
