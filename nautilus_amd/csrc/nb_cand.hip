@@ -170,7 +170,7 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
 // wavefront per SIMD; two per SIMD run without spills up to n_dim = 64 and
 // were faster than three with spills: 2.81 against 3.10 ms per 2^20 proposals
 // at n_dim = 50, K = M = 4)
-template <int DT, int T, int OCC>
+template <int DT, int T, int OCC, bool SAMPLE>
 __global__ void __launch_bounds__(64 * CD_WPB)
 __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   constexpr int DP = 16 * DT;
@@ -182,7 +182,9 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   for (int i = threadIdx.x; i < a.n_groups * CD_WPB; i += 64 * CD_WPB)
     cur[i] = 0;
   __syncthreads();
-  const bool m_sample = a.mode == CM_SAMPLE;
+  // (instantiated per mode: the proposals' acceptance draw and the lists'
+  // sphere pre-test / periodic shift do not share registers)
+  constexpr bool m_sample = SAMPLE;
   const nb_gd* const NB_G* blobs = (const nb_gd* const NB_G*)a.blobs;
   const NB_G int* group_base = (const NB_G int*)a.group_base;
   const int n_dim = (int)nb_hdr((const double*)blobs[0], NB_H_NDIM);
@@ -477,8 +479,14 @@ template <int DT, int T, int OCC>
 int launch_cand_t(const CandArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)a.n_groups * CD_WPB * sizeof(int);
   const int blocks = (a.n_waves + CD_WPB - 1) / CD_WPB;
-  hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC>), dim3((unsigned)blocks),
-                     dim3(64 * CD_WPB), lds, stream, a);
+  if (a.mode == CM_SAMPLE)
+    hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, true>),
+                       dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream,
+                       a);
+  else
+    hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, false>),
+                       dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream,
+                       a);
   return NB_OK;
 }
 
