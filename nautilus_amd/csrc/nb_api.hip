@@ -35,7 +35,7 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
                    unsigned long long seed, unsigned long long offset,
                    int** dense_out, int** totals_out, long long* n_pad_out,
                    hipStream_t stream);
-long long nb_cand_work_bytes(int dt, long long n, int n_groups);
+long long nb_cand_work_bytes(int dt, int mode, long long n, int n_groups);
 int nb_launch_eval_fast_batch(const double* blob0_dev, int n_dim, int recentre,
                               const double* x, const void* groups_dev,
                               int n_groups, const int* totals_dev,
@@ -738,11 +738,11 @@ int64_t nb_list_eval_work_bytes(const nb_boundlist* l, int64_t n) {
     const int k = l->group_base[i + 1] - l->group_base[i];
     most = k > most ? k : most;
   }
-  return nb_cand_work_bytes(l->dt, n, (g > most ? g : most) + 1);
+  return nb_cand_work_bytes(l->dt, 0, n, (g > most ? g : most) + 1);
 }
 
 int64_t nb_accept_staged_work_bytes(const nb_bound* b, int64_t n) {
-  return nb_cand_work_bytes(b->dt, n, b->n_groups + 1);
+  return nb_cand_work_bytes(b->dt, 2, n, b->n_groups + 1);
 }
 
 static int nb_stage_two(const double* blob0, int n_dim, int recentre,

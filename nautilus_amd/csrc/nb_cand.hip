@@ -475,18 +475,19 @@ nb_cand_compact_kernel(const int* __restrict__ counts,
   }
 }
 
-template <int DT, int T, int OCC>
-int launch_cand_t(const CandArgs& a, hipStream_t stream) {
+template <int DT, int T, int OCC, bool SAMPLE>
+void launch_cand_m(const CandArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)a.n_groups * CD_WPB * sizeof(int);
   const int blocks = (a.n_waves + CD_WPB - 1) / CD_WPB;
-  if (a.mode == CM_SAMPLE)
-    hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, true>),
-                       dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream,
-                       a);
-  else
-    hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, false>),
-                       dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream,
-                       a);
+  hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, SAMPLE>),
+                     dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream, a);
+}
+
+// T_S / T_L: tiles per wavefront for proposals / lists (cand_tiles)
+template <int DT, int T_S, int T_L, int OCC>
+int launch_cand_t(const CandArgs& a, hipStream_t stream) {
+  if (a.mode == CM_SAMPLE) launch_cand_m<DT, T_S, OCC, true>(a, stream);
+  else launch_cand_m<DT, T_L, OCC, false>(a, stream);
   return NB_OK;
 }
 
@@ -494,9 +495,15 @@ int launch_cand_t(const CandArgs& a, hipStream_t stream) {
 
 unsigned long long* nb_eval_counters();
 
+// tiles per wavefront (see nb_cand_shape)
+static int cand_tiles(int dt, int mode) {
+  (void)mode;
+  return dt <= 4 ? 2 : 1;
+}
+
 // Geometry of the candidate lists for n points: points per wavefront, number
 // of wavefronts, padded list length (all multiples the kernels rely on).
-void nb_cand_shape(int dt, long long n, int* chunk, int* n_waves,
+void nb_cand_shape(int dt, int mode, long long n, int* chunk, int* n_waves,
                    long long* n_pad) {
   // Tiles per wavefront: two up to n_dim 64, ONE beyond.  Two are faster there
   // in a process of their own (5.0 against 6.1 ms per 2^20 proposals at n_dim
@@ -505,9 +512,11 @@ void nb_cand_shape(int dt, long long n, int* chunk, int* n_waves,
   // call whenever smaller-n_dim kernels had run in the process before: 9.8 to
   // 17.5 ms per call (profiles/r04/accept_bench_50_then_100_one_process.txt;
   // under rocprofv3 the gaps vanish, profiles/r04/trace_50_then_100.txt; a
-  // smaller grid did not help).  One tile per wavefront needs no scratch up
-  // to n_dim 112 and runs the same 6.1 ms in both situations.
-  const int tile = 16 * (dt <= 4 ? 2 : 1);
+  // smaller grid did not help; the proposals' instantiation alone, 244 bytes
+  // of scratch, showed the same: 4.9 ms on its own or behind n_dim = 20
+  // kernels, 14.3 ms behind n_dim = 50 kernels).  One tile per wavefront needs
+  // no scratch up to n_dim 112 and runs the same 6.1 ms in all of these.
+  const int tile = 16 * cand_tiles(dt, mode);
   // wavefronts of the grid: what the chip holds at once at the kernel's
   // register budget (two per SIMD from n_dim 33 on: 2048), twice that for the
   // small kernels
@@ -524,10 +533,10 @@ void nb_cand_shape(int dt, long long n, int* chunk, int* n_waves,
 // work space (bytes) of one query over n points and n_groups groups:
 // [seg][dense] int32 (n_groups x n_pad each), [counts] (n_groups x n_waves),
 // [totals] (n_groups)
-long long nb_cand_work_bytes(int dt, long long n, int n_groups) {
+long long nb_cand_work_bytes(int dt, int mode, long long n, int n_groups) {
   int chunk, n_waves;
   long long n_pad;
-  nb_cand_shape(dt, n, &chunk, &n_waves, &n_pad);
+  nb_cand_shape(dt, mode, n, &chunk, &n_waves, &n_pad);
   return ((long long)n_groups * (2 * n_pad + n_waves + 1) + 64) *
          (long long)sizeof(int);
 }
@@ -557,7 +566,7 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
   a.b_off = b_off; a.g_off = g_off; a.accumulate = accumulate;
   a.st = st; a.first = first; a.seed = seed; a.offset = offset;
   a.counters = nb_eval_counters();
-  nb_cand_shape(dt, n, &a.chunk, &a.n_waves, &a.n_pad);
+  nb_cand_shape(dt, mode, n, &a.chunk, &a.n_waves, &a.n_pad);
   const long long gp = (long long)n_groups * a.n_pad;
   a.seg = work;
   int* dense = work + gp;
@@ -565,14 +574,14 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
   int* totals = a.counts + (long long)n_groups * a.n_waves;
   int rc = NB_OK;
   switch (dt) {
-    case 1: rc = launch_cand_t<1, 2, 4>(a, stream); break;
-    case 2: rc = launch_cand_t<2, 2, 3>(a, stream); break;
-    case 3: rc = launch_cand_t<3, 2, 2>(a, stream); break;
-    case 4: rc = launch_cand_t<4, 2, 2>(a, stream); break;
-    case 5: rc = launch_cand_t<5, 1, 2>(a, stream); break;
-    case 6: rc = launch_cand_t<6, 1, 2>(a, stream); break;
-    case 7: rc = launch_cand_t<7, 1, 2>(a, stream); break;
-    case 8: rc = launch_cand_t<8, 1, 2>(a, stream); break;
+    case 1: rc = launch_cand_t<1, 2, 2, 4>(a, stream); break;
+    case 2: rc = launch_cand_t<2, 2, 2, 3>(a, stream); break;
+    case 3: rc = launch_cand_t<3, 2, 2, 2>(a, stream); break;
+    case 4: rc = launch_cand_t<4, 2, 2, 2>(a, stream); break;
+    case 5: rc = launch_cand_t<5, 1, 1, 2>(a, stream); break;
+    case 6: rc = launch_cand_t<6, 1, 1, 2>(a, stream); break;
+    case 7: rc = launch_cand_t<7, 1, 1, 2>(a, stream); break;
+    case 8: rc = launch_cand_t<8, 1, 1, 2>(a, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;
