@@ -499,7 +499,10 @@ class Sampler:
         """Fill one batch of the shell ``index`` (sampler.py:751-830).
 
         Returns (points on the device, n_bound[, idx_t]).  ``n_target``
-        (default ``n_batch``) is this rank's share of the batch."""
+        (default ``n_batch``) is this rank's share of the batch.  In an
+        un-sharded run the points are a view of a scratch buffer: valid until
+        the next call (``add_samples`` copies them into the shell's storage
+        right away)."""
         n_target = self.n_batch if n_target is None else n_target
         if shell_t is not None and index not in [-1, len(self.bounds) - 1]:
             raise ValueError("'shell_t' must be empty list if not sampling "
