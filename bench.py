@@ -632,6 +632,36 @@ def main():
             traffic=None, points=n_pts, bytes_per_point=8 * d + 1,
             avg_launch_ms=ms, inside_fraction=float(mask.double().mean()))
         del x, mask
+        # ... and at BASELINE configuration 5's dimension, where D (D + 1)
+        # flop per 8 D + 1 bytes put it behind the fp64 MFMA roof (ridge at
+        # n_dim 78), not the HBM one
+        d2 = 100
+        rng2 = np.random.default_rng(d2)
+        a2 = rng2.normal(size=(d2, d2))
+        cov2 = (a2 @ a2.T / d2 + np.eye(d2)) * 0.02
+        b2 = np.linalg.cholesky(cov2)
+        ell2 = Ellipsoid.from_params(0.5 * np.ones(d2), b2, np.linalg.inv(b2),
+                                     np.linalg.inv(cov2)).device_bound()
+        n2 = 1 << 23
+        x = torch.rand((n2, d2), dtype=torch.float64, device='cuda')
+        x[::2] = 0.5 + 0.6 * (x[::2] - 0.5)
+        ell2.contains_stream(x)
+        ev0.record()
+        for _ in range(reps):
+            mask = ell2.contains_stream(x)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        tf = n2 * d2 * (d2 + 1.0) / (ms * 1e-3) / 1e12
+        gbs = n2 * (8 * d2 + 1) / (ms * 1e-3) / 1e9
+        out['roofline_contains_d100'] = dict(
+            kernel='nb_ell_stream_kernel', bound='mfma', achieved=tf,
+            peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s',
+            frac=tf / FP64_MFMA_PEAK_TF, hbm_gbs=gbs,
+            hbm_frac=gbs / HBM_PEAK_GBS, traffic=None, points=n2,
+            flop_per_point=d2 * (d2 + 1), bytes_per_point=8 * d2 + 1,
+            avg_launch_ms=ms, inside_fraction=float(mask.double().mean()))
+        del x, mask
         out['mfma_f64_probe_tflops'] = device.mfma_f64_peak(20000)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(
