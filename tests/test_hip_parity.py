@@ -1005,6 +1005,32 @@ def test_emulator_training_ragged_batches(dev):
         assert np.allclose(nets[0].coefs_[0], ref.coefs[0], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize('d', [63, 64, 65, 80, 100, 112, 127, 128])
+def test_emulator_training_wide_inputs(dev, d):
+    """The trainer beyond 64 input dimensions (five to nine k-tiles in layer
+    1: other register schedules, a different job list of the gradient phase)
+    against the restated MLPRegressor.fit -- configuration 5 trains at 100."""
+    import torch
+    from nautilus_amd import emulator
+    from oracle import mlp_oracle as mo
+    rng = np.random.default_rng(100 + d)
+    n, n_ep = 1237, 4
+    x = rng.normal(size=(n, d))
+    y = rng.random(n)
+    seeds = [0, 1, 2, 3, 4, 5, 6, 7] if d == 100 else [0, 3]
+    nets, _ = emulator.train_networks(
+        torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), seeds,
+        max_epochs=n_ep)
+    for seed, net in zip(seeds, nets):
+        ref = mo.fit_network(x, y, seed, max_iter=n_ep)
+        assert net.n_iter_ == ref.n_iter == n_ep
+        assert np.allclose(net.loss_curve_, ref.loss_curve, rtol=1e-9, atol=0)
+        for k in range(4):
+            assert np.allclose(net.coefs_[k], ref.coefs[k], rtol=0, atol=1e-8)
+            assert np.allclose(net.intercepts_[k], ref.intercepts[k], rtol=0,
+                               atol=1e-8)
+
+
 def test_emulator_training_large_n(dev):
     """The trainer on a training set of the size the samplers reach late in
     a run (120 000 rows: 600 Adam steps per epoch, shuffles from the native
