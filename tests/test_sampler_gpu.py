@@ -268,6 +268,39 @@ def test_sharded_bench_on_one_gpu(world):
     assert all(t > 0 for t in trained[:res['ranks_training']])
 
 
+def test_device_fifo_grows_slides_and_unpops():
+    """The bounds' queue of accepted points (reference: ``self.points`` of
+    Union / NautilusBound, np.vstack on every refill) as one grow-only device
+    buffer: order of the rows through pushes that append, slide the queue to
+    the front or reallocate, pops, ``unpop`` and pickling."""
+    import pickle
+    from nautilus_amd.bounds import _Fifo
+    rng = np.random.default_rng(0)
+    q, ref = _Fifo(3), []
+    stamp = 0
+    for it in range(400):
+        if rng.random() < 0.5 or len(ref) < 50:
+            k = int(rng.integers(1, 3000))
+            rows = torch.arange(stamp, stamp + k, dtype=torch.float64,
+                                device='cuda')[:, None].repeat(1, 3)
+            stamp += k
+            q.push(rows)
+            ref += list(range(stamp - k, stamp))
+        else:
+            k = int(rng.integers(1, len(ref) + 1))
+            got = q.pop(k)[:, 0].cpu().numpy()
+            assert np.array_equal(got, ref[:k])
+            back = int(rng.integers(0, k + 1))
+            q.unpop(back)                      # the tail goes back in front
+            ref = ref[k - back:]
+        assert len(q) == len(ref)
+        if it % 97 == 0:
+            q = pickle.loads(pickle.dumps(q))
+    assert np.array_equal(q.buf[q.head:, 0].cpu().numpy(), ref)
+    q.clear()
+    assert len(q) == 0
+
+
 def test_bench_over_rccl_single_rank():
     """The collective code path of bench.py over the backend the driver's
     --gpus N runs use: torch.distributed 'nccl' (= RCCL), here with the one
