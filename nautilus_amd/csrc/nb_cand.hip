@@ -36,6 +36,7 @@
 #include <limits.h>
 
 #include "nb_common.h"
+#include <cstdlib>
 
 #include "nb_tile.h"
 
@@ -496,8 +497,15 @@ int launch_cand_t(const CandArgs& a, hipStream_t stream) {
 unsigned long long* nb_eval_counters();
 
 // tiles per wavefront (see nb_cand_shape)
+static bool cand_two_tiles_experiment() {
+  // NB_CAND_TWO_TILES=1: two tiles per wavefront at n_dim 97-112 (the
+  // spilling instantiation of the scratch experiment, see nb_cand_shape)
+  static const bool on = getenv("NB_CAND_TWO_TILES") != nullptr;
+  return on;
+}
 static int cand_tiles(int dt, int mode) {
   (void)mode;
+  if (dt == 7 && cand_two_tiles_experiment()) return 2;
   return dt <= 4 ? 2 : 1;
 }
 
@@ -580,7 +588,10 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
     case 4: rc = launch_cand_t<4, 2, 2, 2>(a, stream); break;
     case 5: rc = launch_cand_t<5, 1, 1, 2>(a, stream); break;
     case 6: rc = launch_cand_t<6, 1, 1, 2>(a, stream); break;
-    case 7: rc = launch_cand_t<7, 1, 1, 2>(a, stream); break;
+    case 7:
+      if (cand_two_tiles_experiment()) rc = launch_cand_t<7, 2, 2, 2>(a, stream);
+      else rc = launch_cand_t<7, 1, 1, 2>(a, stream);
+      break;
     case 8: rc = launch_cand_t<8, 1, 1, 2>(a, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");

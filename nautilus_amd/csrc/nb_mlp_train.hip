@@ -12,11 +12,11 @@
 //      over the wavefronts, activations / deltas are exchanged through LDS in
 //      [unit][row] layout), output delta, backward deltas through W^T read
 //      from the same 16x16 tile-major weights; every weight operand is
-//      loaded before the first barrier; activations and deltas go row-major
-//      to a stash in global memory (L2 resident, ~0.8 MB per network).
+//      loaded before the first barrier; activations and deltas go to a stash
+//      in global memory (L2 resident, ~0.8 MB per network; stash_index).
 //  G   one workgroup of four wavefronts per 16x16 weight tile: dW = act^T delta
-//      over the rows of the minibatch, wavefront q contracting k-step q of
-//      every 16-row tile; the four partial tiles meet in LDS, are added in a
+//      over the rows of the minibatch, wavefront q contracting two k-steps of
+//      every other 16-row tile; the four partial tiles meet in LDS, are added in a
 //      fixed order (deterministic, no atomics) and every wavefront applies
 //      Adam to a quarter of the tile in place.  The bias is row K of the
 //      weight matrix (the activations carry a constant 1 in column K).
@@ -100,6 +100,21 @@ struct NetData {
   int batch;            // min(batch size, n)
 };
 
+// A pointer every lane holds the same value of, moved to scalar registers:
+// the record of a network is loaded through vector registers (its index is
+// uniform but not provably so), and every address derived from it -- hoisted
+// out of the step loop -- then lived in vector registers or, beyond 256 of
+// them, in scratch, with a wait for the whole memory queue at every reload.
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long b = (unsigned long long)p;
+  // (the builtin returns int: through unsigned, or the low word sign-extends)
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi =
+      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return (T*)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+
 constexpr int MAX_RESIDENT = 16;   // networks of one resident launch
 struct FleetData { NetData d[MAX_RESIDENT]; };
 
@@ -155,20 +170,35 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
                      LS + li];
 }
 
-// cooperative LDS [unit][row] -> global stash [row][unit] (coalesced rows,
-// 16 bytes per thread: thread -> row tid / 16, units 2 c, 2 c + 1 of every
-// block of 32; n_unit is a multiple of 16, so half the threads skip the last
-// block where it is a multiple of 16 only)
+// The stash of one matrix (activations or deltas of a layer, `ld` units padded
+// to 16) holds the 16-row tile rt of the minibatch at rt * 16 * ld, and in it
+// element (unit 16 ut + li, row 8 h + 2 lg + j) at
+//   ((((ut * 2 + h) * 4 + lg) * 16 + li) * 2 + j
+// -- the two rows a lane of the G phase feeds to two consecutive MFMAs of its
+// chain side by side: one 16-byte load per lane and PAIR of k-steps, 1 KB
+// contiguous per wavefront (what the weight operands of FB already do; with
+// 8-byte loads a CU got 11-16 B / clk out of its L2 for these columns).
+__host__ __device__ constexpr int stash_index(int unit, int row) {
+  return (((((unit >> 4) * 2 + (row >> 3)) * 4 + ((row >> 1) & 3)) * 16 +
+           (unit & 15)) * 2 + (row & 1));
+}
+
+// cooperative LDS [unit][row] -> global stash (16 bytes per thread, 1 KB
+// contiguous per wavefront: wavefront w of iteration it writes half w % 2 of
+// unit tile w / 2 + 2 it; n_unit is a multiple of 16, so half the wavefronts
+// skip the last iteration where it is a multiple of 16 only)
 __device__ __forceinline__ void flush_stash(const double* act, nb_gd* dst,
                                             int ld, int n_unit, int tile,
                                             int tid) {
-  const unsigned r = tid >> 4, c = 2 * (tid & 15);
+  const unsigned li = tid & 15, lg = (tid >> 4) & 3, h = (tid >> 6) & 1;
+  const unsigned ut = tid >> 7;
   nb_gd* row = dst + (tile * 16) * ld;               // wave-uniform
-  const unsigned off = r * ld + c;
+  const unsigned off = (((ut * 2 + h) * 4 + lg) * 16 + li) * 2;
+  const unsigned src = (16 * ut + li) * LS + 8 * h + 2 * lg;
   for (int u = 0; u < n_unit; u += 32) {
-    if (u + (int)c < n_unit) {
-      const nb_d2 v = {act[(c + u) * LS + r], act[(c + 1 + u) * LS + r]};
-      *(NB_G nb_d2*)(row + off + u) = v;
+    if (u + 16 * (int)ut < n_unit) {
+      const nb_d2 v = {act[src + u * LS], act[src + u * LS + 1]};
+      *(NB_G nb_d2*)(row + off + u * 16) = v;
     }
   }
 }
@@ -272,23 +302,35 @@ __device__ __forceinline__ int fb_row_index(const NetData& nd, int tile,
   return perm[pt < nb ? pt : 0];
 }
 
+// (The loads are unconditional -- clamped addresses -- and their values leave
+// this function RAW: the masks (feature past n_dim, bias column, row past the
+// minibatch) are applied by fb_body where the block goes to LDS.  A select on
+// a loaded value here was turned into a branch around the load with a wait for
+// the whole memory queue behind it: five dependent round trips per step, each
+// behind all the operand loads of the G phase in which the prefetch sits.)
 template <int KT1>
 __device__ __forceinline__ void fb_gather(const NetData& nd, int D, int tile,
                                           int nb, int row, FbRows<KT1>& in) {
   int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-  const bool valid = tile * 16 + li < nb;
+  const int lg = lane >> 4;
   const nb_gd* xr = nd.X + (long long)row * D;
 #pragma unroll
   for (int j = 0; j < KT1; ++j) {
     const int f = 4 * (4 * j + wave) + lg;
-    const double v = xr[f < D ? f : D - 1];
-    in.x[j] = (f < D) ? (valid ? v : 0.0) : ((f == D) ? 1.0 : 0.0);
+    in.x[j] = xr[f < D ? f : D - 1];
   }
-  const double yv = nd.y[row];
-  in.yv = (wave == 0 && lg == 0 && valid) ? yv : 0.0;
+  in.yv = nd.y[row];
+}
+
+// the input block entry of k-tile j from the raw gathered value: feature f of
+// a valid row, 1 in the bias column, 0 elsewhere (v * 1 + 0 and v * 0 + c are
+// exact for the finite v of a standardised training set)
+__device__ __forceinline__ double fb_input(double v, int f, int D, bool valid) {
+  const double m = (f < D && valid) ? 1.0 : 0.0;
+  const double c = (f == D) ? 1.0 : 0.0;
+  return __builtin_fma(v, m, c);
 }
 
 #ifdef NB_TRAIN_TIMING
@@ -401,7 +443,8 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
 #pragma unroll
   for (int j = 0; j < KT1; ++j)
-    sA0[(4 * (4 * j + wave) + lg) * LS + li] = rows.x[j];
+    sA0[(4 * (4 * j + wave) + lg) * LS + li] =
+        fb_input(rows.x[j], 4 * (4 * j + wave) + lg, a.n_dim, valid);
   lds_barrier();
   FB_STAMP(11);
   if constexpr (KT1 > 4)
@@ -663,18 +706,27 @@ __device__ __forceinline__ GLayer g_layer(const NetState& st, int kt1,
   return g;
 }
 
-// one 16-column block of a stash matrix, rows 16 rt + 4 wave + lg: the
-// operands of quarter `wave` (wave-uniform row-tile address + a lane offset)
+// one 16-unit column block of a stash matrix (stash_index): wavefront q takes
+// half q % 2 (rows 8 (q % 2) + 2 lg + {0, 1}) of the row tiles q / 2, q / 2 + 2,
+// ... -- two k-steps per row tile and 16-byte load, G_PAIRS loads per block
+// (the last one of the wavefronts 2 and 3 would be row tile G_ROWT: zeros)
+constexpr int G_PAIRS = (G_ROWT + 1) / 2;
 __device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
                                            int wave, unsigned lane,
-                                           double* v) {
-  const unsigned li = lane & 15, lg = lane >> 4;
-  const unsigned off = lg * ld + li;
-  const nb_gd* p = base + 16 * col + 4 * wave * ld;
+                                           nb_d2* v) {
+  // (the base is wave-uniform -- chosen by the job's layer -- but not provably
+  // so: without the readfirstlane every load sits in a waterfall loop)
+  const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(uniform_ptr(base));
+  const unsigned voff = lane * 16;
+  unsigned soff = ((unsigned)(wave >> 1) * 16 * ld +
+                   (unsigned)(col * 2 + (wave & 1)) * 128) * 8;
 #pragma unroll
-  for (int rt = 0; rt < G_ROWT; ++rt) {
-    v[rt] = ld_xcd(&p[off]);
-    p += 16 * ld;
+  for (int it = 0; it < G_PAIRS; ++it) {
+    const nb_d2 zero = {0.0, 0.0};
+    // (G_ROWT is odd: only the last pair of the wavefronts 2, 3 is past it)
+    if (2 * it + 1 < G_ROWT || wave < 2) v[it] = ld_xcd2(rsrc, voff, soff);
+    else v[it] = zero;
+    soff += 2 * 16 * ld * 8;
   }
 }
 
@@ -685,15 +737,15 @@ __device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
 #endif
 
 // One job by a workgroup of four wavefronts.  Wavefront q contracts the rows
-// 16 rt + 4 q + lg of the minibatch (k-step q of every 16-row tile, in the
-// order of rt; all G_ROWT row tiles -- the delta rows past a short minibatch
-// are zero), so a tile is four independent chains of 13 MFMAs on four SIMDs;
-// all operand loads are issued before the first chain.  The partial tiles go
+// 8 (q % 2) + 2 lg + j (j = 0, 1: two MFMAs) of the row tiles q / 2, q / 2 + 2,
+// ... in that order (all G_ROWT row tiles -- the delta rows past a short
+// minibatch are zero), so a tile is four independent chains of 14 / 12 MFMAs
+// on four SIMDs; all operand loads are issued before the first chain.  The partial tiles go
 // through LDS; wavefront r then owns rows lg + 4 r of every tile: gradient =
 // ((p0 + p1) + p2) + p3, Adam (sklearn _stochastic_optimizers.py:255-287) in
 // place, and for the layers 2-4 the transposed copy the next backward pass
-// reads.  `after_loads` runs behind the operand loads (the resident kernel
-// fetches the next step's input rows there).
+// reads.  `first_loads` runs in front of the operand loads (the resident
+// kernel fetches the next step's input rows there).
 struct GJob { int layer, kt0, nk, ht0, nh; };
 
 __device__ __forceinline__ GJob g_job_record(const TrainArgs& a, int job) {
@@ -710,7 +762,7 @@ __device__ __forceinline__ GJob g_job_record(const TrainArgs& a, int job) {
 template <class Hook>
 __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
                                       const GJob& jb, int nb, double lr_t,
-                                      double* red, Hook&& after_loads,
+                                      double* red, Hook&& first_loads,
                                       bool timed = false) {
   int lane_ = threadIdx.x & 63;
   // (opaque to the optimiser: per-lane offsets derived from it are
@@ -724,13 +776,17 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
             nh = jb.nh;
   const GLayer g = g_layer(st, a.kt1, layer);
   G_STAMP(33);
-  double av[2][G_ROWT], bv[2][G_ROWT];
+  // (first in the memory queue: vector memory returns in order, and every
+  // load behind the operands is conditional -- the wait in front of the first
+  // MFMA chain is therefore one for the whole queue; the rows come from HBM
+  // while the operand columns stream out of the L2 behind them)
+  first_loads();
+  nb_d2 av[2][G_PAIRS], bv[2][G_PAIRS];
   g_load_col(g.as, g.lda, kt0, wave, lane, av[0]);
   g_load_col(g.bs, g.ldb, ht0, wave, lane, bv[0]);
   if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, wave, lane, av[1]);
   if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, wave, lane, bv[1]);
   G_STAMP(30);
-  after_loads();
   // this lane's element of every tile of the job: row lg + 4 wave, column li
   const unsigned eoff = (lg + 4 * wave) * 16 + li;     // moments: row major
   const unsigned woff_e = tile_index(lg + 4 * wave, li);
@@ -753,8 +809,10 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
       if (ia < nk && ib < nh) {
         nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int rt = 0; rt < G_ROWT; ++rt)
-          acc = MFMA(av[ia][rt], bv[ib][rt], acc);
+        for (int it = 0; it < G_PAIRS; ++it) {
+          acc = MFMA(av[ia][it].x, bv[ib][it].x, acc);
+          acc = MFMA(av[ia][it].y, bv[ib][it].y, acc);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           red[(((2 * ia + ib) * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
@@ -970,8 +1028,13 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   const int slot = arrival - which * slots;
   int* counter = sync + SYNC_WORDS * net;
   int* err = counter + 1;
-  const NetState st = a.nets[net];
-  const NetData nd = fleet.d[net];
+  NetState st = a.nets[net];
+  st.W = uniform_ptr(st.W); st.M = uniform_ptr(st.M); st.V = uniform_ptr(st.V);
+  st.WT = uniform_ptr(st.WT); st.stash = uniform_ptr(st.stash);
+  st.loss_curve = uniform_ptr(st.loss_curve); st.scal = uniform_ptr(st.scal);
+  NetData nd = fleet.d[net];
+  nd.X = uniform_ptr(nd.X); nd.y = uniform_ptr(nd.y);
+  nd.perm = uniform_ptr(nd.perm);
   // this workgroup's job of the G phase (the same in every step)
   const GJob my_job = g_job_record(a, slot < a.n_jobs ? slot : 0);
   int phase = 0;
@@ -987,6 +1050,9 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   xcd_barrier(counter, err, phase, slots, few);
   // the Adam step counter lives with the network (epoch_body keeps it)
   long long t_adam = (long long)ld_xcd(&st.scal[0]);
+  // step size of the step about to run (adam_lr of its t)
+  double lr_next = adam_lr(a, t_adam + 1);
+  asm volatile("" : "+v"(lr_next));
   FbRows<KT1> rows;
   bool have_rows = false;        // rows = the slice of the step about to run
   int row_next = 0;              // ... and the row index of the step after it
@@ -1038,18 +1104,20 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
         fb_clear_deltas(st, 16 * KT1, slot);
       }
       TR_STAMP(1);
-      // (the step size -- two pow() -- is computed while waiting)
       xcd_arrive(counter);
-      const double lr_t = adam_lr(a, t_adam);
+      // (the step size -- two pow(), ~500 VALU instructions -- was computed
+      // behind the arrival at the barrier that ended the step before; written
+      // here without the pin it was scheduled next to its use, between the
+      // MFMA chains and the Adam update of every job)
+      const double lr_t = lr_next;
       xcd_wait(counter, err, phase, slots, few);
       TR_STAMP(2);
       // jobs slot, slot + 32, ... of the G phase (all 32 CUs of the XCD take
       // part, also the ones without a row tile in FB; the host's job list
       // fits one round); the last workgroup folds the loss
       if (slot == slots - 1 && wave == 3) loss_fold(st, nb, lane);
-      // the rows of the next step (read-only data) are fetched behind the
-      // operand loads of this phase: in flight under its MFMA chains, back
-      // long before the barrier
+      // the rows of the next step (read-only data) are fetched in front of the
+      // operand loads of this phase, back long before the barrier
       have_rows = next_rows && slot * 16 < nb;
       {
         bool fetched = false;
@@ -1068,7 +1136,12 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
           fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
       }
       TR_STAMP(3);
-      xcd_barrier(counter, err, phase, slots, few);
+      xcd_arrive(counter);
+      // the next step's size while the others finish their jobs (the
+      // workgroups with a row tile in FB have the lighter jobs)
+      lr_next = adam_lr(a, t_adam + 1);
+      asm volatile("" : "+v"(lr_next));
+      xcd_wait(counter, err, phase, slots, few);
       TR_STAMP(4);
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
@@ -1231,7 +1304,7 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   }
   t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
   const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
-  const long long curve = t->max_iter;
+  const long long curve = (t->max_iter + 1) & ~1LL;   // 16-byte alignment
   const long long per_net = 3 * t->n_w + WT_DOUBLES + stash + curve + 32;
   t->per_net = per_net;
   const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
