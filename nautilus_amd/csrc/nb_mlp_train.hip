@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -125,6 +126,10 @@ struct TrainArgs {
   const nb_gd* y;
   const nb_gi* perm;    // (E, n_epochs, n)
   const nb_gi* jobs;    // G phase: n_jobs records of G_JOB_INTS ints
+  const nb_gi* sched;   // resident kernel, 32 workgroups per network: the
+                        // (early, late) job of every workgroup -- indices
+                        // into sched_jobs -- or null
+  const nb_gi* sched_jobs;
   int n_jobs;
   long long n;
   int n_dim, kt1, n_epochs, max_iter, n_iter_no_change, batch;
@@ -200,6 +205,24 @@ __device__ __forceinline__ void flush_stash(const double* act, nb_gd* dst,
       const nb_d2 v = {act[src + u * LS], act[src + u * LS + 1]};
       *(NB_G nb_d2*)(row + off + u * 16) = v;
     }
+  }
+}
+
+// ... the same block by ONE wavefront (2 * N_UNIT / 16 stores of 1 KB): the
+// blocks of the upper layers leave while their wavefront has nothing to
+// compute (fb_body), so that the G jobs of the layers 2-4 can start before the
+// backward pass has ended
+template <int N_UNIT>
+__device__ __forceinline__ void flush_wave(const double* act, nb_gd* dst,
+                                           int ld, int tile, unsigned lane) {
+  const unsigned li = lane & 15, lg = lane >> 4;
+  nb_gd* row = dst + (tile * 16) * ld + lane * 2;    // stash_index
+  const double* src = act + li * LS + 2 * lg;
+#pragma unroll
+  for (int c = 0; c < N_UNIT / 8; ++c) {             // c = 2 ut + h
+    const nb_d2 v = {src[(c >> 1) * 16 * LS + (c & 1) * 8],
+                     src[(c >> 1) * 16 * LS + (c & 1) * 8 + 1]};
+    *(NB_G nb_d2*)(row + c * 128) = v;
   }
 }
 
@@ -340,7 +363,14 @@ __device__ __forceinline__ double fb_input(double v, int f, int D, bool valid) {
 // charged the whole latency of prefetched operands to the stage it sat in);
 // workgroup 0 of network 0 folds the differences once per step.
 __device__ long long g_train_ticks[64];
+// per workgroup of network 0 (NB_TRAIN_SLOT_TIMING: every workgroup keeps four
+// time stamps per step in LDS and adds its sums here when the launch ends):
+// [0] last barrier open -> arrival at the barrier behind FB (FB, or the early
+// job), [1] ... -> that barrier seen open, [2] ... -> arrival at the last
+// barrier (late job), [3] ... -> seen open, [4] steps
+__device__ long long g_slot_ticks[32 * 8];
 __shared__ long long s_ts[48];
+__shared__ long long s_slot[8];
 #define NB_STAMP(cond, i)                                                     \
   do {                                                                        \
     if ((cond) && threadIdx.x == 0)                                           \
@@ -385,10 +415,14 @@ __device__ __forceinline__ StashPtrs stash_ptrs(const NetState& st, int ld0) {
   return p;
 }
 
-template <int KT1, bool CHECK_DONE>
+// `upper_ready` is called by wavefront 3 once the activations of the layers
+// 1-3 and the deltas of the layers 2-4 of this tile are in the L2 (all of the
+// stash except the layer-1 deltas).
+template <int KT1, bool CHECK_DONE, class Hook>
 __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
                                         int net, int tile, int nb,
-                                        const FbRows<KT1>& rows, double* lds) {
+                                        const FbRows<KT1>& rows, double* lds,
+                                        Hook&& upper_ready) {
   constexpr int KS1 = 4 * KT1;
   constexpr int LD0 = 16 * KT1;
   // activations / deltas of the tile in [unit][row] layout
@@ -497,7 +531,14 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   load_ops<14, NB_HT1>(rT, T2 + wave * NB_TILE, lane, b2r[0]);
   load_ops<14, NB_HT1>(rT, T2 + ht1b * NB_TILE, lane, b2r[1]);
 
-  // ---- layer 3: two output tiles ------------------------------------------
+  // ---- layer 3: two output tiles; the other two wavefronts send the blocks
+  // that are complete to the stash (their weight operands are all older than
+  // these stores in the in-order memory queue: nothing ever waits for them) ---
+  if (wave == 2) flush_wave<LD1>(sA1, sp.A1, LD1, tile, lane);
+  if (wave == 3) {
+    flush_wave<LD2>(sA2, sp.A2, LD2, tile, lane);
+    flush_wave<LD0>(sA0, sp.A0, LD0, tile, lane);
+  }
   if (wave < NB_HT3) {
     double in[14];
     lds_operand<14>(sA2, lane, in);
@@ -515,6 +556,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 
   // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
   double lp = 0.0;
+  if (wave == 1) flush_wave<LD3>(sA3, sp.A3, LD3, tile, lane);
   if (wave == 0) {
     double in[6];
     lds_operand<6>(sA3, lane, in);
@@ -534,6 +576,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(15);
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
+  if (wave == 2) flush_wave<LD4>(sD4, sp.D4, LD4, tile, lane);
   if (wave < NB_HT3) {
     double dout[2];
     lds_operand<2>(sD4, lane, dout);
@@ -562,10 +605,19 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       sD2[unit * LS + li] = v;
     }
   }
+  // (every wavefront's stash stores so far have arrived: issued stages ago)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
   FB_STAMP(17);
 
-  // ---- delta 1 --------------------------------------------------------------
+  // ---- delta 1; wavefront 3 -- one output tile here, the others two -- sends
+  // the last two upper blocks first and reports the upper stash when its tile
+  // is through (the stores have long been acknowledged by then: a round trip
+  // to the L2 is ~500 ticks) -------------------------------------------------
+  if (wave == 3) {
+    flush_wave<LD3>(sD3, sp.D3, LD3, tile, lane);
+    flush_wave<LD2>(sD2, sp.D2, LD2, tile, lane);
+  }
   {
     double dout[14];
     lds_operand<14>(sD2, lane, dout);
@@ -584,19 +636,17 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       }
     }
   }
+  if (wave == 3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    upper_ready();
+  }
   lds_barrier();
   FB_STAMP(18);
-  // ---- the stash for the G phase, all of it at the end: every block is still
-  // in LDS.  (Written per stage as soon as a block was complete, the stores
-  // sat in the same in-order memory queue as the weight operands of the next
-  // stages, and every stage ended up waiting for a store acknowledgement.)
-  flush_stash(sA0, sp.A0, LD0, LD0, tile, tid);
-  flush_stash(sA1, sp.A1, LD1, LD1, tile, tid);
-  flush_stash(sA2, sp.A2, LD2, LD2, tile, tid);
-  flush_stash(sA3, sp.A3, LD3, LD3, tile, tid);
-  flush_stash(sD4, sp.D4, LD4, LD4, tile, tid);
-  flush_stash(sD3, sp.D3, LD3, LD3, tile, tid);
-  flush_stash(sD2, sp.D2, LD2, LD2, tile, tid);
+  // ---- the layer-1 deltas, the only block of the stash still to go.  (An
+  // earlier form wrote every block as soon as it was complete from ALL
+  // wavefronts: the stores then sat in front of weight operands in the in-order
+  // memory queue and every stage waited for a store acknowledgement; the
+  // wavefronts that flush now have issued their last operand load before.)
   flush_stash(sD1, sp.D1, LD1, LD1, tile, tid);
   if (wave == 0 && lane == 0) st.scal[8 + tile] = lp;
   FB_STAMP(19);
@@ -636,7 +686,7 @@ nb_train_fb_kernel(TrainArgs a, int ep, long long start, int nb) {
   const NetData nd = shared_data(a, (int)blockIdx.y);
   fb_gather<KT1>(nd, a.n_dim, tile, nb, fb_row_index(nd, tile, ep, start, nb),
                  rows);
-  fb_body<KT1, true>(a, st, (int)blockIdx.y, tile, nb, rows, lds);
+  fb_body<KT1, true>(a, st, (int)blockIdx.y, tile, nb, rows, lds, []() {});
 }
 
 // ---- G: dW of 16x16 weight tiles over the minibatch + Adam ------------------
@@ -651,14 +701,23 @@ __device__ __forceinline__ void loss_fold(const NetState& st, int nb,
   if (lane == 0) st.scal[5] = acc;
 }
 
+// (hi + lo) *= b for an unevaluated sum hi + lo: the product hi * b exactly
+// (fma), the rest in working precision, renormalised
+__device__ __forceinline__ void dd_scale(double& hi, double& lo, double b) {
+  const double p = hi * b;
+  const double e = __builtin_fma(hi, b, -p) + lo * b;
+  hi = p + e;
+  lo = e - (hi - p);
+}
+
 // step size of Adam step t (sklearn _stochastic_optimizers.py:276-279)
 __device__ __forceinline__ double adam_lr(const TrainArgs& a, long long t_adam) {
   return a.lr * sqrt(1.0 - pow(a.b2, (double)t_adam)) /
          (1.0 - pow(a.b1, (double)t_adam));
 }
 
-// A job of the G phase: a block of nk x nh (each 1 or 2) weight tiles of one
-// layer -- k-tiles kt0 .. kt0 + nk - 1, output tiles ht0 .. ht0 + nh - 1 --
+// A job of the G phase: a block of nk x nh (each 1 or 2, or 3 x 1) weight tiles
+// of one layer -- k-tiles kt0 .. kt0 + nk - 1, output tiles ht0 .. ht0 + nh - 1 --
 // whose gradients share their operand columns: the nk activation column
 // blocks and the nh delta column blocks are read once for the nk * nh tiles.
 // (A CU gets 26 bytes per clock out of the L2 with 8-byte loads per lane when
@@ -731,8 +790,10 @@ __device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
 }
 
 #ifdef NB_TRAIN_TIMING
+#define G_TIMED (net == 0 && slot == NB_TRAIN_TIMING_SLOT)
 #define G_STAMP(i) NB_STAMP(timed, i)
 #else
+#define G_TIMED false
 #define G_STAMP(i)
 #endif
 
@@ -748,8 +809,8 @@ __device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
 // kernel fetches the next step's input rows there).
 struct GJob { int layer, kt0, nk, ht0, nh; };
 
-__device__ __forceinline__ GJob g_job_record(const TrainArgs& a, int job) {
-  const nb_gi* rec = a.jobs + job * G_JOB_INTS;
+__device__ __forceinline__ GJob g_job_record(const nb_gi* jobs, int job) {
+  const nb_gi* rec = jobs + job * G_JOB_INTS;
   GJob j;
   j.layer = __builtin_amdgcn_readfirstlane(rec[0]);
   j.kt0 = __builtin_amdgcn_readfirstlane(rec[1]);
@@ -781,68 +842,77 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   // MFMA chain is therefore one for the whole queue; the rows come from HBM
   // while the operand columns stream out of the L2 behind them)
   first_loads();
-  nb_d2 av[2][G_PAIRS], bv[2][G_PAIRS];
-  g_load_col(g.as, g.lda, kt0, wave, lane, av[0]);
-  g_load_col(g.bs, g.ldb, ht0, wave, lane, bv[0]);
-  if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, wave, lane, av[1]);
-  if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, wave, lane, bv[1]);
+  // Up to four operand column blocks: c0 / c2 = the activation blocks kt0,
+  // kt0 + 1, c1 = the delta block ht0, and cx = the delta block ht0 + 1 (nh =
+  // 2) or the activation block kt0 + 2 (nk = 3, nh = 1) -- one set of
+  // registers for both.  Tiles of a job: t = 0: (kt0, ht0); 1: (kt0, ht0 + 1);
+  // 2: (kt0 + 1, ht0); 3: (kt0 + 1, ht0 + 1), or (kt0 + 2, ht0) for nk = 3.
+  const bool three = nk == 3;
+  nb_d2 c0[G_PAIRS], c1[G_PAIRS], c2[G_PAIRS], cx[G_PAIRS];
+  g_load_col(g.as, g.lda, kt0, wave, lane, c0);
+  g_load_col(g.bs, g.ldb, ht0, wave, lane, c1);
+  if (nk > 1) g_load_col(g.as, g.lda, kt0 + 1, wave, lane, c2);
+  if (three) g_load_col(g.as, g.lda, kt0 + 2, wave, lane, cx);
+  else if (nh > 1) g_load_col(g.bs, g.ldb, ht0 + 1, wave, lane, cx);
   G_STAMP(30);
   // this lane's element of every tile of the job: row lg + 4 wave, column li
   const unsigned eoff = (lg + 4 * wave) * 16 + li;     // moments: row major
   const unsigned woff_e = tile_index(lg + 4 * wave, li);
   const unsigned toff_e = tile_index(li, lg + 4 * wave);
+  // (wave-uniform) k-tile / output tile of tile t and whether the job has it
+  const bool has[G_MAX_TILES] = {true, nh > 1, nk > 1, three || (nk > 1 && nh > 1)};
+  const int tk[G_MAX_TILES] = {kt0, kt0, kt0 + 1, three ? kt0 + 2 : kt0 + 1};
+  const int th[G_MAX_TILES] = {ht0, ht0 + 1, ht0, three ? ht0 : ht0 + 1};
   double w_old[G_MAX_TILES], m_old[G_MAX_TILES], v_old[G_MAX_TILES];
 #pragma unroll
-  for (int ia = 0; ia < 2; ++ia)
+  for (int t = 0; t < G_MAX_TILES; ++t)
+    if (has[t]) {
+      const int woff = g.wbase + (tk[t] * g.ht_n + th[t]) * NB_TILE;
+      w_old[t] = ld_xcd(&(st.W + woff)[woff_e]);
+      m_old[t] = ld_xcd(&(st.M + woff)[eoff]);
+      v_old[t] = ld_xcd(&(st.V + woff)[eoff]);
+    }
+  auto chain = [&](const nb_d2* av, const nb_d2* bv, int t)
+                   __attribute__((always_inline)) {
+    nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-      if (ia < nk && ib < nh) {
-        const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
-        w_old[2 * ia + ib] = ld_xcd(&(st.W + woff)[woff_e]);
-        m_old[2 * ia + ib] = ld_xcd(&(st.M + woff)[eoff]);
-        v_old[2 * ia + ib] = ld_xcd(&(st.V + woff)[eoff]);
-      }
+    for (int it = 0; it < G_PAIRS; ++it) {
+      acc = MFMA(av[it].x, bv[it].x, acc);
+      acc = MFMA(av[it].y, bv[it].y, acc);
+    }
 #pragma unroll
-  for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-      if (ia < nk && ib < nh) {
-        nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int it = 0; it < G_PAIRS; ++it) {
-          acc = MFMA(av[ia][it].x, bv[ib][it].x, acc);
-          acc = MFMA(av[ia][it].y, bv[ib][it].y, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          red[(((2 * ia + ib) * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
-      }
+    for (int r = 0; r < 4; ++r)
+      red[((t * 4 + wave) * 4 + r) * 64 + lane] = acc[r];
+  };
+  chain(c0, c1, 0);
+  if (has[1]) chain(c0, cx, 1);
+  if (has[2]) chain(c2, c1, 2);
+  if (has[3]) {
+    if (three) chain(cx, c1, 3);
+    else chain(c2, cx, 3);
+  }
   G_STAMP(31);
   lds_barrier();
   G_STAMP(36);
   const double inv_nb = 1.0 / (double)nb;
 #pragma unroll
-  for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-      if (ia < nk && ib < nh) {
-        const int t = 2 * ia + ib;
-        const double* p = red + (t * 16 + wave) * 64 + lane;
-        const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
-        const double gr = sum * inv_nb;
-        const double m = a.b1 * m_old[t] + (1.0 - a.b1) * gr;
-        const double v = a.b2 * v_old[t] + (1.0 - a.b2) * (gr * gr);
-        const double w = w_old[t] + -lr_t * m / (sqrt(v) + a.eps);
-        const int woff = g.wbase + ((kt0 + ia) * g.ht_n + ht0 + ib) * NB_TILE;
-        (st.M + woff)[eoff] = m;
-        (st.V + woff)[eoff] = v;
-        (st.W + woff)[woff_e] = w;
-        if (g.tbase >= 0) {
-          const int toff =
-              g.tbase + ((ht0 + ib) * g.kt_n + kt0 + ia) * NB_TILE;
-          (st.WT + toff)[toff_e] = w;
-        }
+  for (int t = 0; t < G_MAX_TILES; ++t)
+    if (has[t]) {
+      const double* p = red + (t * 16 + wave) * 64 + lane;
+      const double sum = ((p[0] + p[4 * 64]) + p[8 * 64]) + p[12 * 64];
+      const double gr = sum * inv_nb;
+      const double m = a.b1 * m_old[t] + (1.0 - a.b1) * gr;
+      const double v = a.b2 * v_old[t] + (1.0 - a.b2) * (gr * gr);
+      const double w = w_old[t] + -lr_t * m / (sqrt(v) + a.eps);
+      const int woff = g.wbase + (tk[t] * g.ht_n + th[t]) * NB_TILE;
+      (st.M + woff)[eoff] = m;
+      (st.V + woff)[eoff] = v;
+      (st.W + woff)[woff_e] = w;
+      if (g.tbase >= 0) {
+        const int toff = g.tbase + (th[t] * g.kt_n + tk[t]) * NB_TILE;
+        (st.WT + toff)[toff_e] = w;
       }
+    }
   G_STAMP(32);
 }
 
@@ -854,7 +924,7 @@ nb_train_g_kernel(TrainArgs a, int nb, long long t_adam) {
   // the first workgroup also folds the step's loss (the resident kernel gives
   // that to its least loaded workgroup)
   if (blockIdx.x == 0 && threadIdx.x < 64) loss_fold(st, nb, (int)threadIdx.x);
-  g_job(a, st, g_job_record(a, (int)blockIdx.x), nb, adam_lr(a, t_adam), red,
+  g_job(a, st, g_job_record(a.jobs, (int)blockIdx.x), nb, adam_lr(a, t_adam), red,
         []() {});
 }
 
@@ -959,6 +1029,25 @@ __device__ __forceinline__ void xcd_barrier(int* counter, int* err, int& phase,
   xcd_wait(counter, err, phase, n_wg, few);
 }
 
+// wait until `counter` has reached `target` (the count of row tiles whose
+// upper stash is in the L2: fb_body's upper_ready)
+__device__ __forceinline__ void xcd_wait_for(int* counter, int* err, int target,
+                                             bool few) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (few) __builtin_amdgcn_s_sleep(NB_POLL_SLEEP_FEW);
+      else __builtin_amdgcn_s_sleep(NB_POLL_SLEEP);
+      if (++spins > SYNC_LIMIT) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  lds_barrier();
+}
+
 // networks of the XCDs: up to two per XCD (two workgroups per CU), -1 = none
 struct XcdMap {
   int n_nets;
@@ -974,13 +1063,43 @@ __global__ void nb_xcc_probe_kernel(int* out) {
 }
 
 #ifdef NB_TRAIN_TIMING
-#define TR_STAMP(i) NB_STAMP(net == 0 && slot == 0, i)
-// order of the stamps within a step of workgroup 0
-__device__ const int g_stamp_order[19] = {0, 11, 12, 13, 14, 15, 16, 17,
-                                          18, 19, 1, 2, 33, 30, 31, 36, 32,
-                                          3, 4};
+// (NB_TRAIN_TIMING_SLOT: the stamped workgroup of network 0; one without a
+// row tile -- 13 to 31 -- has the stamps of the second list)
+#ifndef NB_TRAIN_TIMING_SLOT
+#define NB_TRAIN_TIMING_SLOT 0
+#endif
+#ifdef NB_TRAIN_SLOT_TIMING
+#define TR_TIMED false
+#define SLOT_STAMP(i)                                                         \
+  do {                                                                        \
+    if (net == 0 && threadIdx.x == 0) {                                       \
+      const long long now_ = (long long)__builtin_amdgcn_s_memtime();         \
+      s_slot[i] += now_ - s_slot[5];                                          \
+      s_slot[5] = now_;                                                       \
+    }                                                                         \
+  } while (0)
+#else
+#define TR_TIMED (net == 0 && slot == NB_TRAIN_TIMING_SLOT)
+#define SLOT_STAMP(i)
+#endif
+#define TR_STAMP(i) NB_STAMP(TR_TIMED, i)
+// order of the stamps within a step of the stamped workgroup
+#if NB_TRAIN_TIMING_SLOT < 13
+constexpr int N_STAMPS = 19;
+__device__ const int g_stamp_order[N_STAMPS] = {0, 11, 12, 13, 14, 15, 16, 17,
+                                                18, 19, 1, 2, 33, 30, 31, 36,
+                                                32, 3, 4};
+#else
+// 5: the upper stash is there; 6: the early job is through; 2: the barrier
+// behind FB has opened; 3: the late job (if any) is through (the stamps of
+// g_job are those of the early job: the late one is not stamped)
+constexpr int N_STAMPS = 12;
+__device__ const int g_stamp_order[N_STAMPS] = {0, 1, 5, 33, 30, 31, 36, 32,
+                                                6, 2, 3, 4};
+#endif
 #else
 #define TR_STAMP(i)
+#define SLOT_STAMP(i)
 #endif
 
 // (two workgroups per CU: the register budget of 256 leaves every CU of an
@@ -1035,8 +1154,25 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   NetData nd = fleet.d[net];
   nd.X = uniform_ptr(nd.X); nd.y = uniform_ptr(nd.y);
   nd.perm = uniform_ptr(nd.perm);
-  // this workgroup's job of the G phase (the same in every step)
-  const GJob my_job = g_job_record(a, slot < a.n_jobs ? slot : 0);
+  // this workgroup's jobs of the G phase (the same in every step).  With the
+  // host's schedule (a network on all 32 CUs of its XCD): an EARLY job, of the
+  // layers 2-4, which starts as soon as every row tile has reported its upper
+  // stash -- the workgroups without a row tile would otherwise idle through
+  // the whole forward / backward pass, and the weights of these layers are not
+  // read again in this step once every tile is past its delta-2 stage -- and a
+  // LATE job, of layer 1, behind the barrier that ends FB.  Without it (two
+  // networks per XCD): jobs slot, slot + slots, ... behind that barrier.
+  const bool use_sched = a.sched != nullptr && !two;
+  int early_i = -1, late_i = slot < a.n_jobs ? slot : -1;
+  if (use_sched) {
+    early_i = __builtin_amdgcn_readfirstlane(a.sched[2 * slot]);
+    late_i = __builtin_amdgcn_readfirstlane(a.sched[2 * slot + 1]);
+  }
+  const nb_gi* job_list = use_sched ? a.sched_jobs : a.jobs;
+  const GJob early_job = g_job_record(job_list, early_i >= 0 ? early_i : 0);
+  const GJob late_job = g_job_record(job_list, late_i >= 0 ? late_i : 0);
+  int* upper = counter + 2;      // row tiles whose upper stash is in the L2
+  int ustep = 0;                 // steps run by this launch
   int phase = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1050,9 +1186,22 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   xcd_barrier(counter, err, phase, slots, few);
   // the Adam step counter lives with the network (epoch_body keeps it)
   long long t_adam = (long long)ld_xcd(&st.scal[0]);
-  // step size of the step about to run (adam_lr of its t)
-  double lr_next = adam_lr(a, t_adam + 1);
-  asm volatile("" : "+v"(lr_next));
+  // beta_1^t and beta_2^t of the step size (adam_lr), carried from step to
+  // step as unevaluated sums hi + lo (one exact product and a renormalisation
+  // per step: ~20 instructions, the error of the pair grows by ~2^-104 per
+  // step, so hi stays the correctly rounded power for any length of fit).  The
+  // two pow() calls they replace were ~500 instructions per step, and wherever
+  // they were put -- between the MFMA chains and Adam by the compiler, behind
+  // the arrival at the last barrier by hand -- the workgroups with a row tile
+  // had them on the critical path: they are never idle.
+#ifdef NB_TRAIN_SLOT_TIMING
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 8; ++i) s_slot[i] = 0;
+    s_slot[5] = (long long)__builtin_amdgcn_s_memtime();
+  }
+#endif
+  double p1h = pow(a.b1, (double)t_adam), p1l = 0.0;
+  double p2h = pow(a.b2, (double)t_adam), p2l = 0.0;
   FbRows<KT1> rows;
   bool have_rows = false;        // rows = the slice of the step about to run
   int row_next = 0;              // ... and the row index of the step after it
@@ -1067,12 +1216,14 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
       const long long start = (long long)sidx * batch;
       const int nb = (int)((n - start < batch) ? (n - start) : batch);
       t_adam += 1;
+      dd_scale(p1h, p1l, a.b1);
+      dd_scale(p2h, p2l, a.b2);
       if (done) continue;
 #ifdef NB_TRAIN_TIMING
-      if (net == 0 && slot == 0 && threadIdx.x == 0) {
+      if (TR_TIMED && threadIdx.x == 0) {
         if (have_stamps) {
           long long prev = s_ts[0];
-          for (int i = 1; i < 19; ++i) {
+          for (int i = 1; i < N_STAMPS; ++i) {
             const int k = g_stamp_order[i];
             g_train_ticks[k] += s_ts[k] - prev;
             prev = s_ts[k];
@@ -1099,50 +1250,86 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
         // where the rows themselves are fetched behind the barrier signal:
         // neither of the two dependent loads is waited for where it is issued
         if (next_rows) row_next = fb_row_index(nd, slot, ep2, start2, nb2);
-        fb_body<KT1, false>(a, st, net, slot, nb, rows, lds);
+        fb_body<KT1, false>(a, st, net, slot, nb, rows, lds,
+                            [&]() __attribute__((always_inline)) {
+                              if (lane == 0)
+                                __hip_atomic_fetch_add(
+                                    upper, 1, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+                            });
       } else if (slot < G_ROWT) {
         fb_clear_deltas(st, 16 * KT1, slot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+          __hip_atomic_fetch_add(upper, 1, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
       }
       TR_STAMP(1);
+      if (!(use_sched && early_i >= 0)) SLOT_STAMP(0);
       xcd_arrive(counter);
-      // (the step size -- two pow(), ~500 VALU instructions -- was computed
-      // behind the arrival at the barrier that ended the step before; written
-      // here without the pin it was scheduled next to its use, between the
-      // MFMA chains and the Adam update of every job)
-      const double lr_t = lr_next;
-      xcd_wait(counter, err, phase, slots, few);
-      TR_STAMP(2);
-      // jobs slot, slot + 32, ... of the G phase (all 32 CUs of the XCD take
-      // part, also the ones without a row tile in FB; the host's job list
-      // fits one round); the last workgroup folds the loss
-      if (slot == slots - 1 && wave == 3) loss_fold(st, nb, lane);
-      // the rows of the next step (read-only data) are fetched in front of the
-      // operand loads of this phase, back long before the barrier
+      const double lr_t =
+          a.lr * sqrt(1.0 - (p2h + p2l)) / (1.0 - (p1h + p1l));
+      ustep += 1;
+      // One call site of g_job for the early job, the late job and the rounds
+      // of the schedule-less form.  The rows of the next step (read-only
+      // data) are fetched in front of the operand loads of the first job
+      // behind the barrier, back long before the next one.
       have_rows = next_rows && slot * 16 < nb;
       {
-        bool fetched = false;
-        for (int job = slot; job < a.n_jobs; job += slots) {
-          g_job(a, st, job == slot ? my_job : g_job_record(a, job), nb, lr_t,
-                lds + FbLds<KT1>::G_RED,
-                [&]() __attribute__((always_inline)) {
-                  if (have_rows && !fetched)
-                    fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
-                  fetched = true;
-                },
-                net == 0 && slot == 0);
-          if (job + slots < a.n_jobs) lds_barrier();   // red is reused
+        bool fetched = false, past_fb = false, red_used = false;
+        for (int r = 0;; ++r) {
+          int job;
+          bool early = false;
+          if (use_sched) {
+            if (r >= 2) break;
+            early = r == 0;
+            job = early ? early_i : late_i;
+          } else {
+            job = slot + r * slots;
+            if (job >= a.n_jobs) job = -1;
+            if (job < 0 && past_fb) break;
+          }
+          if (early) {
+            if (job >= 0) xcd_wait_for(upper, err, ustep * G_ROWT, few);
+            TR_STAMP(5);
+          } else if (!past_fb) {
+            TR_STAMP(6);
+            if (use_sched && early_i >= 0) SLOT_STAMP(0);
+            xcd_wait(counter, err, phase, slots, few);
+            TR_STAMP(2);
+            SLOT_STAMP(1);
+            // the last workgroup folds the loss
+            if (slot == slots - 1 && wave == 3) loss_fold(st, nb, lane);
+            past_fb = true;
+          }
+          if (job >= 0) {
+            if (red_used) lds_barrier();             // red is reused
+            const GJob jb = use_sched ? (early ? early_job : late_job)
+                                      : (r == 0 ? late_job
+                                                : g_job_record(a.jobs, job));
+            g_job(a, st, jb, nb, lr_t, lds + FbLds<KT1>::G_RED,
+                  [&]() __attribute__((always_inline)) {
+                    if (past_fb && have_rows && !fetched) {
+                      fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
+                      fetched = true;
+                    }
+                  },
+                  G_TIMED && !(use_sched && !early && early_i >= 0));
+            red_used = true;
+          }
         }
         if (have_rows && !fetched)
           fb_gather<KT1>(nd, a.n_dim, slot, nb2, row_next, rows);
       }
       TR_STAMP(3);
-      xcd_arrive(counter);
-      // the next step's size while the others finish their jobs (the
-      // workgroups with a row tile in FB have the lighter jobs)
-      lr_next = adam_lr(a, t_adam + 1);
-      asm volatile("" : "+v"(lr_next));
-      xcd_wait(counter, err, phase, slots, few);
+      SLOT_STAMP(2);
+      xcd_barrier(counter, err, phase, slots, few);
       TR_STAMP(4);
+      SLOT_STAMP(3);
+#ifdef NB_TRAIN_SLOT_TIMING
+      if (net == 0 && threadIdx.x == 0) s_slot[4] += 1;
+#endif
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_AGENT) != 0)
         return;
@@ -1150,7 +1337,17 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
     if (done) continue;
     if (slot == 0 && threadIdx.x == 0) epoch_body(a, st, n, t_adam);
     xcd_barrier(counter, err, phase, slots, few);
+#ifdef NB_TRAIN_SLOT_TIMING
+    if (net == 0 && threadIdx.x == 0)
+      s_slot[5] = (long long)__builtin_amdgcn_s_memtime();
+#endif
   }
+#ifdef NB_TRAIN_SLOT_TIMING
+  if (net == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 5; ++i)
+      atomicAdd((unsigned long long*)&g_slot_ticks[slot * 8 + i],
+                (unsigned long long)s_slot[i]);
+#endif
 }
 
 void put_w(double* tiles, int ht_n, int k, int h, double v) {
@@ -1161,10 +1358,10 @@ double get_w(const double* tiles, int ht_n, int k, int h) {
   return tiles[((size_t)(k >> 4) * ht_n + (h >> 4)) * NB_TILE +
                tile_index(k & 15, h & 15)];
 }
-// The job list of the G phase (see g_job): blocks of up to 2 x 2 tiles per
-// layer, shaped so that a network needs at most 32 jobs -- one round of the
-// resident kernel's workgroups -- at every n_dim.
-std::vector<int> g_jobs(int kt1) {
+// The job list of the forms without a schedule (two launches per step; two
+// networks per XCD): blocks of up to 2 x 2 tiles per layer, shaped so that a
+// network needs at most 32 jobs at every n_dim (two rounds of 16 workgroups).
+std::vector<int> g_jobs_rounds(int kt1) {
   std::vector<int> jobs;
   auto blocks = [&](int layer, int kt_n, int ht_n, int bk, int bh) {
     for (int kt = 0; kt < kt_n; kt += bk)
@@ -1181,6 +1378,161 @@ std::vector<int> g_jobs(int kt1) {
   blocks(2, NB_HT2, NB_HT3, 2, 2);      // layer 3 (4 x 2)
   blocks(3, NB_HT3, 1, 2, 1);           // layer 4 (2 x 1)
   return jobs;
+}
+
+// The jobs of the G phase (see g_job) and their schedule on the 32 workgroups
+// of a resident network.
+//
+// Jobs: blocks of nk x nh (1 or 2 each) weight tiles of one layer.  Measured
+// on the resident kernel (profiles/r04/second_session/train_phases_*.txt) a
+// job costs about 2.2 k ticks + 0.8 k per operand column block + 1.35 k per
+// tile (MFMA chains, reduction, Adam, stores).
+//
+// Schedule: the G_ROWT workgroups with a row tile run FB; the other 19 start
+// an EARLY job each -- the 38 tiles of the layers 2-4 -- G_HEAD ticks before
+// the barrier that ends FB opens, and are free for a LATE job when they are
+// through; the layer-1 tiles are all late.  Searched: the block shape of the
+// late jobs (the job that ends last is split while that shortens the phase),
+// and the number of workgroups without a row tile that are kept for a late
+// job ONLY -- the early jobs then move together, pairs of them becoming 2 x 2
+// blocks.  (n_dim 50: thirteen 2-tile late jobs on the FB workgroups, the
+// fourteenth on a workgroup of its own, sixteen 2-tile early jobs and two of
+// 3 x 1 tiles.)  G_HEAD is small: the report of the upper stash takes three
+// round trips to the L2 (store acknowledgement, counter, poll) of ~500 ticks.
+constexpr double G_HEAD = 3.0;
+static double g_cost(int nk, int nh) {
+  return 2.2 + 0.8 * (nk + nh) + 1.35 * nk * nh;
+}
+struct GRec { int layer, kt0, nk, ht0, nh; };
+
+static void g_blocks(std::vector<GRec>& out, int layer, int kt_n, int ht_n,
+                     int bk, int bh) {
+  for (int kt = 0; kt < kt_n; kt += bk)
+    for (int ht = 0; ht < ht_n; ht += bh)
+      out.push_back({layer, kt, kt + bk <= kt_n ? bk : kt_n - kt, ht,
+                     ht + bh <= ht_n ? bh : 1});
+}
+
+// the early jobs (the 38 tiles of the layers 2-4): 19 of two tiles, or fewer
+// with 3 x 1 jobs among them -- level 1: layer 3 as (3, 3, 2) tiles instead of
+// four pairs; levels 2, 3: the columns of one / both output-tile pairs of
+// layer 2 as (3, 2, 2) along k instead of seven 1 x 2 jobs per pair
+static std::vector<GRec> g_early(int level) {
+  std::vector<GRec> out;
+  if (level >= 1) {                              // layer 3 (4 x 2 tiles)
+    out.push_back({2, 0, 3, 0, 1});
+    out.push_back({2, 0, 3, 1, 1});
+    out.push_back({2, 3, 1, 0, 2});
+  } else {
+    g_blocks(out, 2, NB_HT2, NB_HT3, 2, 1);
+  }
+  for (int ht = 0; ht < NB_HT2; ht += 2) {       // layer 2 (7 x 4 tiles)
+    if (level >= 2 + ht / 2) {
+      for (int h = ht; h < ht + 2; ++h) {
+        out.push_back({1, 0, 3, h, 1});
+        out.push_back({1, 3, 2, h, 1});
+        out.push_back({1, 5, 2, h, 1});
+      }
+    } else {
+      for (int kt = 0; kt < NB_HT1; ++kt) out.push_back({1, kt, 1, ht, 2});
+    }
+  }
+  out.push_back({3, 0, 2, 0, 1});                // layer 4 (2 x 1 tiles)
+  return out;
+}
+
+struct GPlan {
+  std::vector<GRec> early, late;
+  std::vector<int> early_slot, late_slot;
+  double span = 1e30;
+};
+
+// the dearest late job to the workgroup that is free first, and so on
+static double g_pair(const std::vector<GRec>& late,
+                     const std::vector<std::pair<double, int>>& free_at,
+                     std::vector<int>& slot_of, int& critical) {
+  std::vector<int> idx(late.size());
+  for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
+    return g_cost(late[x].nk, late[x].nh) > g_cost(late[y].nk, late[y].nh);
+  });
+  slot_of.assign(late.size(), -1);
+  double span = 0.0;
+  critical = -1;
+  for (size_t r = 0; r < idx.size(); ++r) {
+    const int j = idx[r];
+    const double end = free_at[r].first + g_cost(late[j].nk, late[j].nh);
+    slot_of[j] = free_at[r].second;
+    if (end > span) { span = end; critical = j; }
+  }
+  return span;
+}
+
+// jobs: records of G_JOB_INTS ints; sched: (early, late) job index per
+// workgroup, -1 = none
+void g_plan(int kt1, std::vector<int>& jobs, std::vector<int>& sched) {
+  const int n_free = XCD_SLOTS - G_ROWT;
+  GPlan best;
+  const int shapes[5][2] = {{2, 1}, {1, 2}, {3, 1}, {2, 2}, {1, 1}};
+  for (int late_only = 0; late_only <= 3; ++late_only) {
+    const std::vector<GRec> early = g_early(late_only);
+    if ((int)early.size() + late_only != n_free) continue;
+    // when the workgroups are free for a late job
+    std::vector<std::pair<double, int>> free_at;
+    std::vector<int> early_slot(early.size());
+    double early_end = 0.0;
+    for (int w = 0; w < G_ROWT + late_only; ++w) free_at.push_back({0.0, w});
+    for (size_t i = 0; i < early.size(); ++i) {
+      const int w = G_ROWT + late_only + (int)i;
+      double c = g_cost(early[i].nk, early[i].nh) - G_HEAD;
+      if (c < 0.0) c = 0.0;
+      if (c > early_end) early_end = c;
+      free_at.push_back({c, w});
+      early_slot[i] = w;
+    }
+    std::stable_sort(free_at.begin(), free_at.end(),
+                     [](const std::pair<double, int>& x,
+                        const std::pair<double, int>& y) {
+                       return x.first < y.first;
+                     });
+    for (const auto& sh : shapes) {
+      std::vector<GRec> late;
+      g_blocks(late, 0, kt1, NB_HT1, sh[0], sh[1]);
+      while ((int)late.size() <= XCD_SLOTS) {
+        std::vector<int> slot_of;
+        int crit;
+        double span = g_pair(late, free_at, slot_of, crit);
+        if (early_end > span) span = early_end;
+        if (span < best.span - 1e-9) {
+          best.span = span; best.early = early; best.late = late;
+          best.early_slot = early_slot; best.late_slot = slot_of;
+        }
+        GRec& c = late[crit];
+        if (c.nk * c.nh == 1) break;
+        GRec half = c;
+        if (c.nk == 3) { c.nk = 2; half.nk = 1; half.kt0 += 2; }
+        else if (c.nk == 2) { c.nk = 1; half.nk = 1; half.kt0 += 1; }
+        else { c.nh = 1; half.nh = 1; half.ht0 += 1; }
+        late.push_back(half);
+      }
+    }
+  }
+  jobs.clear();
+  sched.clear();
+  if (best.late.empty()) return;   // (the kernel then runs g_jobs_rounds)
+  sched.assign(2 * XCD_SLOTS, -1);
+  for (size_t i = 0; i < best.early.size(); ++i) {
+    const GRec& r = best.early[i];
+    const int rec[G_JOB_INTS] = {r.layer, r.kt0, r.nk, r.ht0, r.nh};
+    sched[2 * best.early_slot[i]] = (int)jobs.size() / G_JOB_INTS;
+    jobs.insert(jobs.end(), rec, rec + G_JOB_INTS);
+  }
+  for (size_t j = 0; j < best.late.size(); ++j) {
+    const GRec& r = best.late[j];
+    const int rec[G_JOB_INTS] = {r.layer, r.kt0, r.nk, r.ht0, r.nh};
+    sched[2 * best.late_slot[j] + 1] = (int)jobs.size() / G_JOB_INTS;
+    jobs.insert(jobs.end(), rec, rec + G_JOB_INTS);
+  }
 }
 
 // transposed copy: tiles [ht][kt], element (hh, kk)
@@ -1232,6 +1584,7 @@ struct nb_trainer {
   long long t_adam = 0;
   int* sync_dev = nullptr;         // per network: counter, error, xcc mask
   int* jobs_dev = nullptr;         // job list of the G phase
+  int* sched_dev = nullptr;        // (early, late) job per workgroup, or null
   int n_jobs = 0;
   bool two_launch = false;         // fall back to two launches per step
   XcdMap xcd_map;                  // XCDs owned by this trainer's networks
@@ -1315,8 +1668,20 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   if (e == hipSuccess)
     e = hipMalloc((void**)&t->sync_dev, SYNC_INTS * sizeof(int));
   {
-    const std::vector<int> jobs = g_jobs(t->kt1);
+    const std::vector<int> jobs = g_jobs_rounds(t->kt1);
     t->n_jobs = (int)jobs.size() / G_JOB_INTS;
+    // (NB_TRAIN_NO_SCHEDULE: all jobs behind the barrier, for comparison)
+    std::vector<int> sjobs, sched;
+    g_plan(t->kt1, sjobs, sched);
+    if (!sched.empty() && getenv("NB_TRAIN_NO_SCHEDULE") == nullptr) {
+      // [sched (2 per workgroup)][its job records]
+      sched.insert(sched.end(), sjobs.begin(), sjobs.end());
+      if (e == hipSuccess)
+        e = hipMalloc((void**)&t->sched_dev, sched.size() * sizeof(int));
+      if (e == hipSuccess)
+        e = hipMemcpy(t->sched_dev, sched.data(), sched.size() * sizeof(int),
+                      hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess)
       e = hipMalloc((void**)&t->jobs_dev, jobs.size() * sizeof(int));
     if (e == hipSuccess)
@@ -1363,6 +1728,19 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
                  "NB_TRAIN_TWO_LAUNCH unset)", MAX_RESIDENT);
     nb_trainer_destroy(t);
     return NB_ERR_UNSUPPORTED;
+  }
+  if (getenv("NB_TRAIN_DEBUG") != nullptr) {
+    std::vector<int> sjobs, sched;
+    g_plan(t->kt1, sjobs, sched);
+    for (size_t w = 0; 2 * w + 1 < sched.size(); ++w)
+      for (int r = 0; r < 2; ++r) {
+        const int j = sched[2 * w + r];
+        if (j >= 0)
+          fprintf(stderr, "[trainer] workgroup %2d %s job: layer %d, k-tiles "
+                  "%d+%d, h-tiles %d+%d\n", (int)w, r == 0 ? "early" : "late ",
+                  sjobs[5 * j] + 1, sjobs[5 * j + 1], sjobs[5 * j + 2],
+                  sjobs[5 * j + 3], sjobs[5 * j + 4]);
+      }
   }
   if (getenv("NB_TRAIN_DEBUG") != nullptr)
     fprintf(stderr, "[trainer] nets=%d n=%lld two_launch=%d owned=%02x in_use=%02x\n",
@@ -1473,6 +1851,8 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
   a.nets = t->nets_dev; a.X = (const nb_gd*)t->X; a.y = (const nb_gd*)t->y;
   a.perm = (const nb_gi*)perm_dev_of[0];
   a.jobs = (const nb_gi*)t->jobs_dev; a.n_jobs = t->n_jobs;
+  a.sched = (const nb_gi*)t->sched_dev;
+  a.sched_jobs = a.sched ? a.sched + 2 * XCD_SLOTS : nullptr;
   a.n = t->n; a.n_dim = t->n_dim; a.kt1 = t->kt1; a.n_epochs = n_epochs;
   a.max_iter = t->max_iter; a.n_iter_no_change = t->n_iter_no_change;
   a.batch = (int)((t->n < t->batch) ? t->n : t->batch);
@@ -1670,6 +2050,12 @@ int nb_trainer_weights(nb_trainer* t, int32_t net, double* const* coefs,
 }
 
 #ifdef NB_TRAIN_TIMING
+int nb_dbg_train_slot_times(long long* out) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_ticks), 256 * sizeof(long long));
+  long long zero[256] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_slot_ticks), zero, sizeof zero);
+  return 0;
+}
 int nb_dbg_train_times(long long* out) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(g_train_ticks), 64 * sizeof(long long));
   long long zero[64] = {0};
@@ -1685,6 +2071,7 @@ int nb_trainer_destroy(nb_trainer* t) {
   if (t->nets_dev) (void)hipFree(t->nets_dev);
   if (t->sync_dev) (void)hipFree(t->sync_dev);
   if (t->jobs_dev) (void)hipFree(t->jobs_dev);
+  if (t->sched_dev) (void)hipFree(t->sched_dev);
   if (t->pin_scal) (void)hipHostFree(t->pin_scal);
   if (t->pin_sync) (void)hipHostFree(t->pin_sync);
   for (int i = 0; i < nb_trainer::RING; ++i)
