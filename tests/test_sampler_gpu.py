@@ -274,6 +274,7 @@ def test_device_fifo_grows_slides_and_unpops():
     buffer: order of the rows through pushes that append, slide the queue to
     the front or reallocate, pops, ``unpop`` and pickling."""
     import pickle
+    import torch
     from nautilus_amd.bounds import _Fifo
     rng = np.random.default_rng(0)
     q, ref = _Fifo(3), []
