@@ -981,9 +981,18 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 #endif
 constexpr int XCD_COUNT = 8;
 constexpr int XCD_SLOTS = 32;            // workgroups per network: one per CU
-constexpr int SYNC_WORDS = 4;            // per network: counter, error, -, -
+// per network 256 bytes: [0] barrier counter, [1] error, [32] the count of
+// reported upper stashes -- the counters of different networks (different
+// XCDs) and the two counters of one network on lines of their own.  (Sixteen
+// bytes per network put the counters of all networks into one 128-byte line,
+// on which the atomics and polls of four or eight XCDs met; which small
+// allocation landed next to which then decided between 14.7 and 16.5-17 us
+// per step from process to process, profiles/r04/second_session/
+// train_mode_shift.txt.)
+constexpr int SYNC_WORDS = 64;
+constexpr int SYNC_UPPER = 32;
 // (+ one ticket counter per XCD behind the MAX_RESIDENT network records)
-constexpr int SYNC_INTS = SYNC_WORDS * 16 + XCD_COUNT;
+constexpr int SYNC_INTS = SYNC_WORDS * 16 + 32 * XCD_COUNT;
 constexpr int SYNC_LIMIT = 1 << 23;
 
 // (split into arrive / wait so that read-only prefetches can be issued in
@@ -1133,7 +1142,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   // CUs was measured at twice the step time, i.e. no gain over training one
   // network after the other, because the phases are bound by what a CU gets
   // out of the L2 per clock.  (The CUs keep a free workgroup slot either way.)
-  int* ticket = sync + SYNC_WORDS * MAX_RESIDENT + xcd;
+  int* ticket = sync + SYNC_WORDS * MAX_RESIDENT + 32 * xcd;
   if (threadIdx.x == 0) sh_slot = atomicAdd(ticket, 1);
   __syncthreads();
   const int arrival = __builtin_amdgcn_readfirstlane(sh_slot);
@@ -1171,7 +1180,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   const nb_gi* job_list = use_sched ? a.sched_jobs : a.jobs;
   const GJob early_job = g_job_record(job_list, early_i >= 0 ? early_i : 0);
   const GJob late_job = g_job_record(job_list, late_i >= 0 ? late_i : 0);
-  int* upper = counter + 2;      // row tiles whose upper stash is in the L2
+  int* upper = counter + SYNC_UPPER;   // row tiles whose upper stash is in the L2
   int ustep = 0;                 // steps run by this launch
   int phase = 0;
   const int lane = threadIdx.x & 63;
@@ -1582,6 +1591,7 @@ struct nb_trainer {
   int max_iter = 10000, n_iter_no_change = 10, batch = 200;
   double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
   long long t_adam = 0;
+  char* block = nullptr;           // the one device allocation (see create)
   int* sync_dev = nullptr;         // per network: counter, error, xcc mask
   int* jobs_dev = nullptr;         // job list of the G phase
   int* sched_dev = nullptr;        // (early, late) job per workgroup, or null
@@ -1658,35 +1668,55 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   t->n_w = (long long)nb_net_tiles(t->kt1) * NB_TILE;
   const long long stash = (long long)MAXB * (16 * t->kt1 + 2 * (LD1 + LD2 + LD3) + LD4);
   const long long curve = (t->max_iter + 1) & ~1LL;   // 16-byte alignment
-  const long long per_net = 3 * t->n_w + WT_DOUBLES + stash + curve + 32;
+  // (a multiple of 4 KB: no line of one network's record next to another's)
+  const long long per_net =
+      (3 * t->n_w + WT_DOUBLES + stash + curve + 32 + 511) / 512 * 512;
   t->per_net = per_net;
-  const size_t bytes = (size_t)per_net * n_networks * sizeof(double);
-  hipError_t e = hipMalloc((void**)&t->pool, bytes);
-  if (e == hipSuccess) e = hipMemset(t->pool, 0, bytes);
-  if (e == hipSuccess)
-    e = hipMalloc((void**)&t->nets_dev, n_networks * sizeof(NetState));
-  if (e == hipSuccess)
-    e = hipMalloc((void**)&t->sync_dev, SYNC_INTS * sizeof(int));
-  {
-    const std::vector<int> jobs = g_jobs_rounds(t->kt1);
-    t->n_jobs = (int)jobs.size() / G_JOB_INTS;
-    // (NB_TRAIN_NO_SCHEDULE: all jobs behind the barrier, for comparison)
-    std::vector<int> sjobs, sched;
-    g_plan(t->kt1, sjobs, sched);
-    if (!sched.empty() && getenv("NB_TRAIN_NO_SCHEDULE") == nullptr) {
-      // [sched (2 per workgroup)][its job records]
-      sched.insert(sched.end(), sjobs.begin(), sjobs.end());
-      if (e == hipSuccess)
-        e = hipMalloc((void**)&t->sched_dev, sched.size() * sizeof(int));
-      if (e == hipSuccess)
-        e = hipMemcpy(t->sched_dev, sched.data(), sched.size() * sizeof(int),
-                      hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess)
-      e = hipMalloc((void**)&t->jobs_dev, jobs.size() * sizeof(int));
-    if (e == hipSuccess)
-      e = hipMemcpy(t->jobs_dev, jobs.data(), jobs.size() * sizeof(int),
+  // ONE allocation for everything the kernels touch -- [barrier counters, 8
+  // KB][network records, 4 KB][job lists, 4 KB][weights, moments, stash, loss
+  // curve and scalars of every network] -- so that the small arrays lie the
+  // same way relative to each other and to the pool in every process (as
+  // separate allocations they landed wherever the allocator had a slot, and
+  // the step time followed).
+  const std::vector<int> jobs = g_jobs_rounds(t->kt1);
+  t->n_jobs = (int)jobs.size() / G_JOB_INTS;
+  // (NB_TRAIN_NO_SCHEDULE: all jobs behind the barrier, for comparison)
+  std::vector<int> sjobs, sched;
+  g_plan(t->kt1, sjobs, sched);
+  const bool use_sched =
+      !sched.empty() && getenv("NB_TRAIN_NO_SCHEDULE") == nullptr;
+  // [sched (2 per workgroup)][its job records]
+  sched.insert(sched.end(), sjobs.begin(), sjobs.end());
+  constexpr size_t OFF_NETS = 8192, OFF_JOBS = 12288, OFF_SCHED = 13312,
+                   OFF_POOL = 16384;
+  static_assert(SYNC_INTS * sizeof(int) <= OFF_NETS &&
+                MAX_RESIDENT * sizeof(NetState) <= OFF_JOBS - OFF_NETS,
+                "trainer block layout");
+  if (jobs.size() * sizeof(int) > OFF_SCHED - OFF_JOBS ||
+      sched.size() * sizeof(int) > OFF_POOL - OFF_SCHED) {
+    nb_set_error("trainer: job lists exceed their slots");
+    delete t;
+    return NB_ERR_ARG;
+  }
+  // (whole 2 MB fragments: the mapping of a block that ends inside one was
+  // seen to cost up to a microsecond per step)
+  const size_t bytes =
+      (OFF_POOL + (size_t)per_net * n_networks * sizeof(double) +
+       (2u << 20) - 1) / (2u << 20) * (2u << 20);
+  hipError_t e = hipMalloc((void**)&t->block, bytes);
+  if (e == hipSuccess) e = hipMemset(t->block, 0, bytes);
+  if (e == hipSuccess) {
+    t->sync_dev = (int*)t->block;
+    t->nets_dev = (NetState*)(t->block + OFF_NETS);
+    t->jobs_dev = (int*)(t->block + OFF_JOBS);
+    t->pool = (double*)(t->block + OFF_POOL);
+    e = hipMemcpy(t->jobs_dev, jobs.data(), jobs.size() * sizeof(int),
+                  hipMemcpyHostToDevice);
+    if (e == hipSuccess && use_sched) {
+      t->sched_dev = (int*)(t->block + OFF_SCHED);
+      e = hipMemcpy(t->sched_dev, sched.data(), sched.size() * sizeof(int),
                     hipMemcpyHostToDevice);
+    }
   }
   // (NB_TRAIN_NO_RESIDENT: the library-side switch only, for the test of the
   // host's fallback when the resident kernel is not to be had)
@@ -2066,12 +2096,8 @@ int nb_dbg_train_times(long long* out) {
 
 int nb_trainer_destroy(nb_trainer* t) {
   if (t == nullptr) return NB_OK;
-  if (t->pool) (void)hipFree(t->pool);
+  if (t->block) (void)hipFree(t->block);
   g_xcd_in_use &= ~t->xcd_owned;
-  if (t->nets_dev) (void)hipFree(t->nets_dev);
-  if (t->sync_dev) (void)hipFree(t->sync_dev);
-  if (t->jobs_dev) (void)hipFree(t->jobs_dev);
-  if (t->sched_dev) (void)hipFree(t->sched_dev);
   if (t->pin_scal) (void)hipHostFree(t->pin_scal);
   if (t->pin_sync) (void)hipHostFree(t->pin_sync);
   for (int i = 0; i < nb_trainer::RING; ++i)
