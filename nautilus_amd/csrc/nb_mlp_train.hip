@@ -981,16 +981,19 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 #endif
 constexpr int XCD_COUNT = 8;
 constexpr int XCD_SLOTS = 32;            // workgroups per network: one per CU
-// per network 256 bytes: [0] barrier counter, [1] error, [32] the count of
-// reported upper stashes -- the counters of different networks (different
-// XCDs) and the two counters of one network on lines of their own.  (Sixteen
+// per network 512 bytes: [0] counter of the barrier behind FB (and of those
+// around the epochs), [1] error, [32] the count of reported upper stashes,
+// [64] counter of the barrier that ends a step -- the counters of different
+// networks (different XCDs) and the counters of one network on lines of
+// their own.  (Sixteen
 // bytes per network put the counters of all networks into one 128-byte line,
 // on which the atomics and polls of four or eight XCDs met; which small
 // allocation landed next to which then decided between 14.7 and 16.5-17 us
 // per step from process to process, profiles/r04/second_session/
 // train_mode_shift.txt.)
-constexpr int SYNC_WORDS = 64;
+constexpr int SYNC_WORDS = 128;
 constexpr int SYNC_UPPER = 32;
+constexpr int SYNC_LAST = 64;            // the barrier that ends a step
 // (+ one ticket counter per XCD behind the MAX_RESIDENT network records)
 constexpr int SYNC_INTS = SYNC_WORDS * 16 + 32 * XCD_COUNT;
 constexpr int SYNC_LIMIT = 1 << 23;
@@ -1181,6 +1184,13 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   const GJob early_job = g_job_record(job_list, early_i >= 0 ? early_i : 0);
   const GJob late_job = g_job_record(job_list, late_i >= 0 ? late_i : 0);
   int* upper = counter + SYNC_UPPER;   // row tiles whose upper stash is in the L2
+  // The barrier that ends a step has a counter of its own: a workgroup with an
+  // early job and no late one then never has to look at the barrier behind FB
+  // -- it arrives there when the step starts and goes from its job straight to
+  // the end of the step (a look cost it a round trip to the L2 behind the
+  // stores of its job, and the 3 x 1 early jobs were the last to arrive).
+  int* end_ctr = counter + SYNC_LAST;
+  int phase_last = 0;
   int ustep = 0;                 // steps run by this launch
   int phase = 0;
   const int lane = threadIdx.x & 63;
@@ -1305,7 +1315,11 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
           } else if (!past_fb) {
             TR_STAMP(6);
             if (use_sched && early_i >= 0) SLOT_STAMP(0);
-            xcd_wait(counter, err, phase, slots, few);
+            if (use_sched && job < 0 && slot != slots - 1) {
+              phase += 1;                  // (arrived; nothing to wait for)
+            } else {
+              xcd_wait(counter, err, phase, slots, few);
+            }
             TR_STAMP(2);
             SLOT_STAMP(1);
             // the last workgroup folds the loss
@@ -1333,7 +1347,7 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
       }
       TR_STAMP(3);
       SLOT_STAMP(2);
-      xcd_barrier(counter, err, phase, slots, few);
+      xcd_barrier(end_ctr, err, phase_last, slots, few);
       TR_STAMP(4);
       SLOT_STAMP(3);
 #ifdef NB_TRAIN_SLOT_TIMING
@@ -1672,8 +1686,8 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   const long long per_net =
       (3 * t->n_w + WT_DOUBLES + stash + curve + 32 + 511) / 512 * 512;
   t->per_net = per_net;
-  // ONE allocation for everything the kernels touch -- [barrier counters, 8
-  // KB][network records, 4 KB][job lists, 4 KB][weights, moments, stash, loss
+  // ONE allocation for everything the kernels touch -- [barrier counters, 12
+  // KB][network records, 1 KB][job lists, 1 + 2 KB][weights, moments, stash, loss
   // curve and scalars of every network] -- so that the small arrays lie the
   // same way relative to each other and to the pool in every process (as
   // separate allocations they landed wherever the allocator had a slot, and
@@ -1687,7 +1701,7 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
       !sched.empty() && getenv("NB_TRAIN_NO_SCHEDULE") == nullptr;
   // [sched (2 per workgroup)][its job records]
   sched.insert(sched.end(), sjobs.begin(), sjobs.end());
-  constexpr size_t OFF_NETS = 8192, OFF_JOBS = 12288, OFF_SCHED = 13312,
+  constexpr size_t OFF_NETS = 12288, OFF_JOBS = 13312, OFF_SCHED = 14336,
                    OFF_POOL = 16384;
   static_assert(SYNC_INTS * sizeof(int) <= OFF_NETS &&
                 MAX_RESIDENT * sizeof(NetState) <= OFF_JOBS - OFF_NETS,

@@ -19,9 +19,8 @@ ORDER = [(0, 'loop top (incl. stamp folding)'),
          (11, 'fb weights issued, input block in LDS'), (12, 'fb L1'),
          (13, 'fb L2'), (14, 'fb L3'), (15, 'fb out + d4'), (16, 'fb d3'),
          (17, 'fb d2'), (18, 'fb d1'), (19, 'fb stash stores issued'),
-         (1, 'fb return'), (33, 'arrival, upper stash seen, late job: layer decode'),
-         (2, 'late job: activation columns + old weights issued, barrier 1'),
-         (30, 'late job: delta columns issued'),
+         (1, 'fb return'), (2, 'barrier 1'),
+         (33, 'g job record + layer decode'), (30, 'g operand loads issued'),
          (31, 'g MFMA chains -> LDS'), (36, 'g LDS barrier'),
          (32, 'g reduce + Adam + stores issued'), (3, 'g return'),
          (4, 'barrier 2 + next rows prefetch')]
@@ -60,7 +59,7 @@ for d, n_row, e in CASES:
         d, e, dt / steps * 1e6, total))
     if ORDER[1][0] == 11:
         fb = sum(ticks[k] for k in (11, 12, 13, 14, 15, 16, 17, 18, 19, 1))
-        g = sum(ticks[k] for k in (30, 31, 36, 32, 3))
+        g = sum(ticks[k] for k in (33, 30, 31, 36, 32, 3))
         print('   FB %.0f   G %.0f' % (fb, g))
     for k, name in ORDER:
         print('      %-42s %8.0f' % (name, ticks[k]))
