@@ -1066,6 +1066,53 @@ struct XcdMap {
   int net[XCD_COUNT][2];
 };
 
+// per network: its barrier record (SYNC_WORDS ints) in the arena
+struct SyncTable { int* rec[MAX_RESIDENT]; };
+
+// Where should the barrier record of an XCD live?  Device-scope atomics and
+// the polls of a barrier are served at the memory side, and how far that is
+// from an XCD depends on the address: with all records in one place the step
+// time followed bit 13 of their address (12.95 against 14.2 us per step at
+// n_dim 50 from one process to the next, and either way for half of the eight
+// XCDs of an 8-network trainer; profiles/r04/second_session/
+// train_sync_shift.txt).  The arena holds ARENA_PLACES candidate places 8 KB
+// apart with a record for every (XCD, network of the XCD) in each; this
+// kernel times a chain of dependent atomics on every place from every XCD
+// (one wavefront per XCD, the first to arrive), the host takes the fastest
+// place per XCD.
+constexpr int ARENA_PLACES = 8;
+constexpr int ARENA_PLACE_INTS = 2048;          // 8 KB
+constexpr int ARENA_INTS = ARENA_PLACES * ARENA_PLACE_INTS;
+__device__ __forceinline__ int* arena_record(int* arena, int place, int xcd,
+                                             int which) {
+  return arena + place * ARENA_PLACE_INTS + (xcd * 2 + which) * SYNC_WORDS;
+}
+__global__ void nb_sync_probe_kernel(int* arena, int* tickets,
+                                     long long* ticks) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & (XCD_COUNT - 1));
+  if (threadIdx.x != 0) return;
+  if (atomicAdd(tickets + 32 * xcd, 1) != 0) return;
+  for (int rep = 0; rep < 3; ++rep)
+    for (int place = 0; place < ARENA_PLACES; ++place) {
+      int* p = arena_record(arena, place, xcd, 0);
+      int off = 0;
+      const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+      for (int i = 0; i < 48; ++i) {
+        int r = __hip_atomic_fetch_add(p + off, 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" : "+v"(r));
+        off = (r >> 30) & 1;                     // (0: the chain is dependent)
+      }
+      const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+      if (rep > 0) {
+        long long* out = ticks + xcd * ARENA_PLACES + place;
+        if (rep == 1 || t1 - t0 < *out) *out = t1 - t0;
+      }
+    }
+}
+
 __global__ void nb_xcc_probe_kernel(int* out) {
   if (threadIdx.x == 0) {
     unsigned xcc;
@@ -1120,7 +1167,8 @@ __device__ const int g_stamp_order[N_STAMPS] = {0, 1, 5, 33, 30, 31, 36, 32,
 // pass while this one is resident)
 template <int KT1>
 __global__ void __launch_bounds__(256, 2)
-nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
+nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, SyncTable tab,
+                    int* sync) {
   // concurrent trainers (the neural bounds of a multi-modal NautilusBound)
   // own disjoint XCDs; map.net[x] = network of XCD x or -1
   // The workgroup asks the hardware which XCD it runs on and takes a ticket
@@ -1157,8 +1205,12 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
   const int net = map.net[xcd][which];
   if (net < 0 || net >= n_nets) return;
   const int slot = arrival - which * slots;
-  int* counter = sync + SYNC_WORDS * net;
+  // the network's barrier record: in the process-wide arena, at the place
+  // this XCD reaches fastest (sync_arena); its error word is mirrored into
+  // the trainer's own sync array when the workgroup leaves
+  int* counter = tab.rec[net];
   int* err = counter + 1;
+  int* err_mirror = sync + SYNC_WORDS * net + 1;
   NetState st = a.nets[net];
   st.W = uniform_ptr(st.W); st.M = uniform_ptr(st.M); st.V = uniform_ptr(st.V);
   st.WT = uniform_ptr(st.WT); st.stash = uniform_ptr(st.stash);
@@ -1354,8 +1406,10 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
       if (net == 0 && threadIdx.x == 0) s_slot[4] += 1;
 #endif
       if (__hip_atomic_load(err, __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT) != 0)
+                            __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (slot == 0 && threadIdx.x == 0) *err_mirror = 1;
         return;
+      }
     }
     if (done) continue;
     if (slot == 0 && threadIdx.x == 0) epoch_body(a, st, n, t_adam);
@@ -1365,6 +1419,9 @@ nb_train_xcd_kernel(TrainArgs a, FleetData fleet, XcdMap map, int* sync) {
       s_slot[5] = (long long)__builtin_amdgcn_s_memtime();
 #endif
   }
+  if (slot == 0 && threadIdx.x == 0)
+    *err_mirror = __hip_atomic_load(err, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
 #ifdef NB_TRAIN_SLOT_TIMING
   if (net == 0 && threadIdx.x == 0)
     for (int i = 0; i < 5; ++i)
@@ -1588,6 +1645,51 @@ static bool xcd_pinning_available() {
 
 static unsigned g_xcd_in_use = 0;   // XCDs owned by live resident trainers
 
+// the process-wide arena of barrier records and the place of every XCD in it
+// (nb_sync_probe_kernel; NB_TRAIN_SYNC_PLACE=<p> forces place p for all)
+static int* g_arena = nullptr;
+static int g_place_of_xcd[XCD_COUNT];
+static bool sync_arena() {
+  static int state = 0;             // 1 = there, -1 = failed
+  if (state != 0) return state == 1;
+  state = -1;
+  int* tickets = nullptr;
+  long long* ticks = nullptr;
+  if (hipMalloc((void**)&g_arena, ARENA_INTS * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&tickets, 32 * XCD_COUNT * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&ticks, XCD_COUNT * ARENA_PLACES * sizeof(long long)) !=
+          hipSuccess)
+    return false;
+  (void)hipMemset(g_arena, 0, ARENA_INTS * sizeof(int));
+  (void)hipMemset(tickets, 0, 32 * XCD_COUNT * sizeof(int));
+  (void)hipMemset(ticks, 0, XCD_COUNT * ARENA_PLACES * sizeof(long long));
+  hipLaunchKernelGGL(nb_sync_probe_kernel, dim3(XCD_COUNT * XCD_SLOTS),
+                     dim3(64), 0, 0, g_arena, tickets, ticks);
+  long long host[XCD_COUNT * ARENA_PLACES];
+  const hipError_t e =
+      hipMemcpy(host, ticks, sizeof host, hipMemcpyDeviceToHost);
+  (void)hipFree(tickets);
+  (void)hipFree(ticks);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  const char* forced = getenv("NB_TRAIN_SYNC_PLACE");
+  for (int x = 0; x < XCD_COUNT; ++x) {
+    int best = 0;
+    for (int p = 1; p < ARENA_PLACES; ++p)
+      if (host[x * ARENA_PLACES + p] < host[x * ARENA_PLACES + best]) best = p;
+    g_place_of_xcd[x] = forced ? atoi(forced) % ARENA_PLACES : best;
+    if (getenv("NB_TRAIN_DEBUG_BLOCK") != nullptr) {
+      fprintf(stderr, "[trainer] XCD %d: ticks per 48 dependent atomics by "
+              "place:", x);
+      for (int p = 0; p < ARENA_PLACES; ++p)
+        fprintf(stderr, " %lld", host[x * ARENA_PLACES + p]);
+      fprintf(stderr, " -> place %d\n", g_place_of_xcd[x]);
+    }
+  }
+  (void)hipMemset(g_arena, 0, ARENA_INTS * sizeof(int));
+  state = 1;
+  return true;
+}
+
 struct nb_trainer {
   int n_dim = 0, E = 0, kt1 = 0, dt = 0;
   long long n = 0;
@@ -1606,6 +1708,7 @@ struct nb_trainer {
   double tol = 0.0, lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8;
   long long t_adam = 0;
   char* block = nullptr;           // the one device allocation (see create)
+  char* block_alloc = nullptr;
   int* sync_dev = nullptr;         // per network: counter, error, xcc mask
   int* jobs_dev = nullptr;         // job list of the G phase
   int* sched_dev = nullptr;        // (early, late) job per workgroup, or null
@@ -1702,7 +1805,7 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   // [sched (2 per workgroup)][its job records]
   sched.insert(sched.end(), sjobs.begin(), sjobs.end());
   constexpr size_t OFF_NETS = 12288, OFF_JOBS = 13312, OFF_SCHED = 14336,
-                   OFF_POOL = 16384;
+                   OFF_SYNC2 = 16384, OFF_POOL = 32768;
   static_assert(SYNC_INTS * sizeof(int) <= OFF_NETS &&
                 MAX_RESIDENT * sizeof(NetState) <= OFF_JOBS - OFF_NETS,
                 "trainer block layout");
@@ -1717,10 +1820,23 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   const size_t bytes =
       (OFF_POOL + (size_t)per_net * n_networks * sizeof(double) +
        (2u << 20) - 1) / (2u << 20) * (2u << 20);
-  hipError_t e = hipMalloc((void**)&t->block, bytes);
-  if (e == hipSuccess) e = hipMemset(t->block, 0, bytes);
+  // (NB_TRAIN_BLOCK_SHIFT: experiment -- the block starts that many KB into
+  // its allocation)
+  const size_t shift = getenv("NB_TRAIN_BLOCK_SHIFT")
+      ? (size_t)atol(getenv("NB_TRAIN_BLOCK_SHIFT")) * 1024 : 0;
+  const size_t slack = getenv("NB_TRAIN_BLOCK_SHIFT") ? (2u << 20) : 0;
+  hipError_t e = hipMalloc((void**)&t->block_alloc, bytes + slack);
+  if (e == hipSuccess) e = hipMemset(t->block_alloc, 0, bytes + slack);
   if (e == hipSuccess) {
+    t->block = t->block_alloc + shift;
+    if (getenv("NB_TRAIN_DEBUG_BLOCK") != nullptr)
+      fprintf(stderr, "[trainer] block at %p\n", (void*)t->block);
+    // (NB_TRAIN_SYNC_SHIFT: experiment -- the counters 16 KB + that many KB
+    // into the block instead of at its start)
     t->sync_dev = (int*)t->block;
+    if (getenv("NB_TRAIN_SYNC_SHIFT"))
+      t->sync_dev = (int*)(t->block + OFF_SYNC2 +
+                           (size_t)atol(getenv("NB_TRAIN_SYNC_SHIFT")) * 1024);
     t->nets_dev = (NetState*)(t->block + OFF_NETS);
     t->jobs_dev = (int*)(t->block + OFF_JOBS);
     t->pool = (double*)(t->block + OFF_POOL);
@@ -1914,6 +2030,20 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
       fleet.d[i].batch = (int)((t->ns[k] < t->batch) ? t->ns[k] : t->batch);
     }
     NB_HIP_CHECK(hipMemsetAsync(t->sync_dev, 0, SYNC_INTS * sizeof(int), s));
+    SyncTable tab;
+    for (int i = 0; i < MAX_RESIDENT; ++i) tab.rec[i] = t->sync_dev;
+    for (int x = 0; x < XCD_COUNT; ++x)
+      for (int w = 0; w < 2; ++w) {
+        const int net = t->xcd_map.net[x][w];
+        if (net < 0) continue;
+        tab.rec[net] = sync_arena()
+            ? g_arena + g_place_of_xcd[x] * ARENA_PLACE_INTS +
+                  (x * 2 + w) * SYNC_WORDS
+            : t->sync_dev + SYNC_WORDS * net;
+        if (tab.rec[net] != t->sync_dev + SYNC_WORDS * net)
+          NB_HIP_CHECK(hipMemsetAsync(tab.rec[net], 0,
+                                      SYNC_WORDS * sizeof(int), s));
+      }
     // 32 workgroups per XCD: all of them for its network, or 16 for each of
     // its two
     const dim3 grid(XCD_COUNT * XCD_SLOTS), blk(256);
@@ -1921,7 +2051,7 @@ int nb_trainer_run_fleet(nb_trainer* t, const int32_t* const* perm_dev_of,
 #define NB_CASE(KT1_)                                                      \
       case KT1_:                                                           \
         hipLaunchKernelGGL(nb_train_xcd_kernel<KT1_>, grid, blk, 0, s, a,  \
-                           fleet, t->xcd_map, t->sync_dev);                \
+                           fleet, t->xcd_map, tab, t->sync_dev);           \
         break;
       NB_CASE(1) NB_CASE(2) NB_CASE(3) NB_CASE(4) NB_CASE(5)
       NB_CASE(6) NB_CASE(7) NB_CASE(8) NB_CASE(9)
@@ -2110,7 +2240,7 @@ int nb_dbg_train_times(long long* out) {
 
 int nb_trainer_destroy(nb_trainer* t) {
   if (t == nullptr) return NB_OK;
-  if (t->block) (void)hipFree(t->block);
+  if (t->block_alloc) (void)hipFree(t->block_alloc);
   g_xcd_in_use &= ~t->xcd_owned;
   if (t->pin_scal) (void)hipHostFree(t->pin_scal);
   if (t->pin_sync) (void)hipHostFree(t->pin_sync);
