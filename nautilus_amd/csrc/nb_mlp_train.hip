@@ -481,7 +481,7 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
         fb_input(rows.x[j], 4 * (4 * j + wave) + lg, a.n_dim, valid);
   lds_barrier();
   FB_STAMP(11);
-  if constexpr (KT1 > 4)
+  if constexpr (KT1 == 5)
     load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
 
   // ---- layer 1: output tiles wave, wave + 4 ------------------------------
@@ -499,6 +499,17 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
           const int unit = 16 * ht + 4 * r + lg;
           if (unit == NB_H1) v = 1.0;                    // bias unit
           sA1[unit * LS + li] = v;
+        }
+      }
+      // (beyond 80 dimensions the operands of layer 2 are loaded into the
+      // registers the first tile's have left, a tile's chain ahead of their
+      // use: all at once they did not fit and the spills' reloads waited for
+      // the whole memory queue)
+      if constexpr (KT1 > 5) {
+        if (rep == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
