@@ -251,20 +251,24 @@ class DeviceBound:
             self.dense_need = float(totals.sum()) / max(1, n)
         return flags
 
-    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False):
+    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False,
+                      out_slot=None):
         """One launch of the device ``sample`` pipeline: draw, accept,
         compact.  Returns (points, counters) with counters = int64 tensor
         [n kept by the outer union, n kept in total] still on the device.
         ``reuse=True`` (the bounds' refill loops): the launch works in the
         process-wide scratch buffers and the returned rows are only valid
-        until the next such launch."""
+        until the next such launch; ``out_slot='name'``: the compacted rows go
+        to a scratch buffer of that name instead (a launch whose result is
+        collected later, ``_RejectionSampler.prefetch``)."""
         if (self.can_draw and FUSED_DRAW and self.dense_need is not None and
                 self.dense_need > 0.5):
             x, flags = self.accept_draw(seed, offset, n_draw, reuse)
         else:
             x = self.propose(seed, offset, n_draw, reuse)
             flags = self.accept(seed, offset, x, reuse)
-        out, counts, _ = compact_rows(x, flags, mask, reuse=reuse)
+        out, counts, _ = compact_rows(x, flags, mask,
+                                      reuse=out_slot if out_slot else reuse)
         return out, counts
 
     def accept_draw(self, seed, offset, n, reuse=False):
@@ -593,6 +597,8 @@ def _buffer(role, shape, dtype, reuse):
     to hipMalloc -- tens of milliseconds each -- in the middle of a run."""
     if not reuse:
         return torch.empty(shape, dtype=dtype, device='cuda')
+    if isinstance(reuse, str):       # a scratch buffer of its own (prefetch)
+        role = role + ':' + reuse
     n_bytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
     buf = _SCRATCH.get(role)
     if buf is None or buf.numel() < n_bytes:
