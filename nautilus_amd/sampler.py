@@ -543,7 +543,10 @@ class Sampler:
                     if n_s > 0 else 0.5
                 n_req = int(min(4 * device_block(), need / frac * 1.15 + 256))
             x = bound.sample_device(n_req)
-            self._last_request = (bound, n_req)
+            if self.__dict__.get('_last_request') is None:
+                # (the first request of the batch: further rounds of this
+                # loop only top up)
+                self._last_request = (bound, n_req)
             if later is not None:
                 # sampler.py:796-799 on the device: flag the points inside a
                 # later bound, compact the others in order; the source row of
