@@ -622,12 +622,16 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   FB_STAMP(17);
 
   // ---- delta 1; wavefront 3 -- one output tile here, the others two -- sends
-  // the last two upper blocks first and reports the upper stash when its tile
-  // is through (the stores have long been acknowledged by then: a round trip
-  // to the L2 is ~500 ticks) -------------------------------------------------
+  // the last two upper blocks first, waits for their acknowledgement and
+  // reports the upper stash BEFORE its tile: with the counters near (~500
+  // ticks per round trip) that fits into the time the others need for their
+  // second tile, and the early jobs start ~1.2 k ticks sooner (with the
+  // counters far away this order made wavefront 3 the last of the stage) ------
   if (wave == 3) {
     flush_wave<LD3>(sD3, sp.D3, LD3, tile, lane);
     flush_wave<LD2>(sD2, sp.D2, LD2, tile, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    upper_ready();
   }
   {
     double dout[14];
@@ -646,10 +650,6 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
         }
       }
     }
-  }
-  if (wave == 3) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    upper_ready();
   }
   lds_barrier();
   FB_STAMP(18);
