@@ -792,10 +792,19 @@ __device__ __forceinline__ void g_load_col(const nb_gd* base, int ld, int col,
                    (unsigned)(col * 2 + (wave & 1)) * 128) * 8;
 #pragma unroll
   for (int it = 0; it < G_PAIRS; ++it) {
-    const nb_d2 zero = {0.0, 0.0};
-    // (G_ROWT is odd: only the last pair of the wavefronts 2, 3 is past it)
-    if (2 * it + 1 < G_ROWT || wave < 2) v[it] = ld_xcd2(rsrc, voff, soff);
-    else v[it] = zero;
+    if (2 * it + 1 < G_ROWT) {
+      v[it] = ld_xcd2(rsrc, voff, soff);
+    } else {
+      // (G_ROWT is odd: the last pair of the wavefronts 2, 3 is past it.  They
+      // load the row tile two before it again -- an unconditional load: a
+      // branch or a select here put the wait for the whole memory queue in
+      // front of the first MFMA chain -- and scale it to zero; the values are
+      // finite, so 0 * v is 0.)
+      const unsigned back = wave < 2 ? 0u : 2u * 16 * ld * 8;
+      const double keep = wave < 2 ? 1.0 : 0.0;
+      const nb_d2 w = ld_xcd2(rsrc, voff, soff - back);
+      v[it] = nb_d2{w.x * keep, w.y * keep};
+    }
     soff += 2 * 16 * ld * 8;
   }
 }
@@ -831,11 +840,16 @@ __device__ __forceinline__ GJob g_job_record(const nb_gi* jobs, int job) {
   return j;
 }
 
-template <class Hook>
-__device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
-                                      const GJob& jb, int nb, double lr_t,
-                                      double* red, Hook&& first_loads,
-                                      bool timed = false) {
+// (NK, NH = the job's shape at compile time: one straight-line body per shape,
+// so that the wait in front of every MFMA chain is exactly for its operands --
+// with the shape as run-time conditions around the loads the first chain
+// waited for the whole memory queue)
+template <int NK, int NH, class Hook>
+__device__ __forceinline__ void g_job_shape(const TrainArgs& a,
+                                            const NetState& st,
+                                            const GJob& jb, int nb,
+                                            double lr_t, double* red,
+                                            Hook&& first_loads, bool timed) {
   int lane_ = threadIdx.x & 63;
   // (opaque to the optimiser: per-lane offsets derived from it are
   // recomputed every step instead of being kept -- and spilled -- across the
@@ -844,8 +858,8 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   const unsigned lane = lane_;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned li = lane & 15, lg = lane >> 4;
-  const int layer = jb.layer, kt0 = jb.kt0, nk = jb.nk, ht0 = jb.ht0,
-            nh = jb.nh;
+  const int layer = jb.layer, kt0 = jb.kt0, ht0 = jb.ht0;
+  constexpr int nk = NK, nh = NH;
   const GLayer g = g_layer(st, a.kt1, layer);
   G_STAMP(33);
   // (first in the memory queue: vector memory returns in order, and every
@@ -858,7 +872,7 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   // 2) or the activation block kt0 + 2 (nk = 3, nh = 1) -- one set of
   // registers for both.  Tiles of a job: t = 0: (kt0, ht0); 1: (kt0, ht0 + 1);
   // 2: (kt0 + 1, ht0); 3: (kt0 + 1, ht0 + 1), or (kt0 + 2, ht0) for nk = 3.
-  const bool three = nk == 3;
+  constexpr bool three = nk == 3;
   nb_d2 c0[G_PAIRS], c1[G_PAIRS], c2[G_PAIRS], cx[G_PAIRS];
   g_load_col(g.as, g.lda, kt0, wave, lane, c0);
   g_load_col(g.bs, g.ldb, ht0, wave, lane, c1);
@@ -871,7 +885,8 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
   const unsigned woff_e = tile_index(lg + 4 * wave, li);
   const unsigned toff_e = tile_index(li, lg + 4 * wave);
   // (wave-uniform) k-tile / output tile of tile t and whether the job has it
-  const bool has[G_MAX_TILES] = {true, nh > 1, nk > 1, three || (nk > 1 && nh > 1)};
+  constexpr bool has[G_MAX_TILES] = {true, nh > 1, nk > 1,
+                                     three || (nk > 1 && nh > 1)};
   const int tk[G_MAX_TILES] = {kt0, kt0, kt0 + 1, three ? kt0 + 2 : kt0 + 1};
   const int th[G_MAX_TILES] = {ht0, ht0 + 1, ht0, three ? ht0 : ht0 + 1};
   double w_old[G_MAX_TILES], m_old[G_MAX_TILES], v_old[G_MAX_TILES];
@@ -925,6 +940,24 @@ __device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
       }
     }
   G_STAMP(32);
+}
+
+template <class Hook>
+__device__ __forceinline__ void g_job(const TrainArgs& a, const NetState& st,
+                                      const GJob& jb, int nb, double lr_t,
+                                      double* red, Hook&& first_loads,
+                                      bool timed = false) {
+  const int shape = jb.nk * 4 + jb.nh;           // (wave-uniform)
+  if (shape == 2 * 4 + 1)
+    g_job_shape<2, 1>(a, st, jb, nb, lr_t, red, first_loads, timed);
+  else if (shape == 1 * 4 + 2)
+    g_job_shape<1, 2>(a, st, jb, nb, lr_t, red, first_loads, timed);
+  else if (shape == 3 * 4 + 1)
+    g_job_shape<3, 1>(a, st, jb, nb, lr_t, red, first_loads, timed);
+  else if (shape == 2 * 4 + 2)
+    g_job_shape<2, 2>(a, st, jb, nb, lr_t, red, first_loads, timed);
+  else
+    g_job_shape<1, 1>(a, st, jb, nb, lr_t, red, first_loads, timed);
 }
 
 __global__ void __launch_bounds__(256)
