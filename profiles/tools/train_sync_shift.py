@@ -1,7 +1,10 @@
 """Which part of the trainer's block makes the step time follow address bit
 13: the barrier counters or the pool?  (NB_TRAIN_BLOCK_SHIFT moves the whole
 block inside an allocation of fixed size, NB_TRAIN_SYNC_SHIFT the counters
-alone.)"""
+alone.)  Decisive on the tree before the per-XCD arena of barrier records
+(profiles/r04/second_session/train_sync_shift_before_arena.txt); since then
+the counters live in the arena, NB_TRAIN_SYNC_SHIFT only moves the error
+mirror, and every line of this tool reads the same (..._with_arena.txt)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
