@@ -28,6 +28,10 @@ def main():
     ap.add_argument('--n-batch', type=int, default=None,
                     help='default: the configuration\'s own batch size')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--n-live', type=int, default=None,
+                    help='default: the configuration\'s own')
+    ap.add_argument('--n-networks', type=int, default=None,
+                    help='default: the configuration\'s own')
     ap.add_argument('--timeout', type=float, default=np.inf)
     ap.add_argument('--counters', action='store_true',
                     help='point-evaluation counters of the bound kernels and '
@@ -48,8 +52,9 @@ def main():
     c = baseline_config(args.name)
     t0 = time.time()
     s = Sampler(unit_prior, c['likelihood'], n_dim=c['n_dim'],
-                n_live=c['n_live'],
-                n_networks=c['n_networks'],
+                n_live=args.n_live or c['n_live'],
+                n_networks=c['n_networks'] if args.n_networks is None
+                else args.n_networks,
                 n_batch=args.n_batch or c['n_batch'],
                 vectorized=True, seed=args.seed)
     extra = {}
@@ -117,13 +122,20 @@ def main():
              else np.zeros(len(s.log_l), dtype=int))
     offset = s.shell_log_v - np.log(np.maximum(s.shell_n, 1))
     num = torch.zeros(3, dtype=torch.float64, device='cuda')
+    sq = torch.zeros(3, dtype=torch.float64, device='cuda')
     for p, ll, st, o in zip(s._pts, s._ll_dev, start, offset):
         w = torch.exp(ll.view()[st:] + float(o) - float(s.log_z))
         num += (p.view()[st:, :3] * w[:, None]).sum(0)
+        sq += (p.view()[st:, :3]**2 * w[:, None]).sum(0)
     mean = num.cpu().numpy()
+    var = sq.cpu().numpy() - mean**2
     print(json.dumps(dict(
         config=args.name, finished=bool(ok), wall_s=round(wall, 2),
-        n_batch=args.n_batch or c['n_batch'],
+        n_batch=args.n_batch or c['n_batch'], seed=args.seed,
+        n_live=args.n_live or c['n_live'],
+        n_networks=c['n_networks'] if args.n_networks is None
+        else args.n_networks,
+        mean_x0=float(mean[0]), var_x0=float(var[0]),
         discard_exploration=discard, explored=bool(s.explored),
         log_z=float(s.log_z), analytic_log_z=c['analytic_log_z'],
         n_eff=float(s.n_eff), n_like=int(s.n_like), n_bounds=len(s.bounds),

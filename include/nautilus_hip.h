@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 4
+#define NB_ABI_VERSION 5
 
 typedef struct nb_bound nb_bound;          /* opaque bound living in HBM     */
 typedef struct nb_boundlist nb_boundlist;  /* device array of bound pointers */
@@ -152,18 +152,6 @@ int nb_propose(const nb_bound* bound, uint64_t seed, uint64_t offset,
 int nb_accept(const nb_bound* bound, uint64_t seed, uint64_t offset,
               const double* x_dev, int64_t n, uint8_t* flags_dev,
               void* stream);
-
-/* nb_propose + nb_accept in one kernel (NautilusBound.sample,
- * nautilus.py:212-222, for a bound with ONE full-ellipsoid outer member and
- * ONE neural bound, n_dim <= 64: the case the sampling phase of a unimodal
- * problem spends its time in): the acceptance kernel draws proposal offset + i
- * of the bound's stream itself -- the same streams as nb_propose, the normals
- * drawn straight into the matrix cores' operand layout, x = c + B z on the
- * matrix cores --, writes it to x_dev[i] and its flags to flags_dev[i].
- * nb_accept_draw_available: 1 if the bound carries the operands for it.      */
-int nb_accept_draw_available(const nb_bound* bound);
-int nb_accept_draw(const nb_bound* bound, uint64_t seed, uint64_t offset,
-                   int64_t n, double* x_dev, uint8_t* flags_dev, void* stream);
 
 /* Stable stream compaction (the reference's boolean indexing
  * `points[in_bound]`, `points[in_shell]`): rows with ((flags ^ flip) & mask)

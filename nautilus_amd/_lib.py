@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('NAUTILUS_HIP_LIB') or os.path.join(
     _HERE, 'lib', 'libnautilus_hip.so')
 
 # NB_ABI_VERSION of include/nautilus_hip.h this binding was written against
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -68,9 +68,6 @@ _SIGNATURES = {
                              C.c_void_p, C.c_void_p]),
     'nb_accept': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                             C.c_int64, C.c_void_p, C.c_void_p]),
-    'nb_accept_draw_available': (C.c_int, [C.c_void_p]),
-    'nb_accept_draw': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64,
-                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'nb_compact_scratch_bytes': (C.c_int64, [C.c_int64]),
     'nb_compact_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint8,
                                   C.c_uint8, C.c_int64, C.c_int32, C.c_void_p,

@@ -46,9 +46,6 @@ GUARD_LAUNCHES = 64
 GUARD_ACCEPTANCE = 1e-7
 
 
-_PENDING_OWNER = None       # the bound whose prefetched launch is in flight
-
-
 class BarrenBound(RuntimeError):
     """A bound whose rejection sampler accepts (next to) nothing."""
 
@@ -179,11 +176,8 @@ class _DeviceBoundBase(_Persistent):
         return bool(out[0]) if single else out
 
     def __getstate__(self):
-        if hasattr(self, '_harvest'):
-            self._harvest()          # a prefetched launch lands in the queue
         state = dict(self.__dict__)
         state['_dev'] = None
-        state.pop('_pending', None)
         return state
 
 
@@ -429,7 +423,6 @@ class _RejectionSampler(_DeviceBoundBase):
     @property
     def points(self):
         """The reference's ``self.points`` (numpy view of the FIFO)."""
-        self._harvest()
         q = self._queue()
         return q.buf[q.head:].cpu().numpy()
 
@@ -457,44 +450,7 @@ class _RejectionSampler(_DeviceBoundBase):
                                 inverse=True)
         self._queue().push(rows)
 
-    def prefetch(self, n_points):
-        """Enqueue the refill launch the NEXT ``sample_device(n_points)`` would
-        start with, without waiting for it: the sampling phase calls this
-        where its host-side bookkeeping begins, so that the queue of the GPU
-        is not empty while the host works (0.75 ms of idle queue per 10.5 ms
-        step otherwise).  The proposals are the next ones of the bound's
-        stream either way, and what a launch accepts beyond the demand stays
-        in the queue, so the points handed out are the same sequence with or
-        without it; the counters of the volume estimate see the proposals of a
-        launch when it is collected."""
-        global _PENDING_OWNER
-        if getattr(self, '_pending', None) is not None:
-            return
-        need = n_points - len(self._queue())
-        if need <= 0:
-            return
-        if _PENDING_OWNER is not None and _PENDING_OWNER is not self:
-            _PENDING_OWNER._harvest()   # one result buffer for all bounds
-        n_draw = self._launch(need)
-        seed, off = self._stream.take(n_draw)
-        rows, counts = self.device_bound().sample_launch(
-            seed, off, n_draw, reuse=True, out_slot='prefetch')
-        self._pending = (rows, counts, n_draw)
-        _PENDING_OWNER = self
-
-    def _harvest(self):
-        global _PENDING_OWNER
-        pending = getattr(self, '_pending', None)
-        if pending is None:
-            return
-        self._pending = None
-        if _PENDING_OWNER is self:
-            _PENDING_OWNER = None
-        rows, counts, n_draw = pending
-        self._collect(rows, counts.cpu().numpy(), n_draw)
-
     def _fill(self, n_points):
-        self._harvest()
         q = self._queue()
         barren = 0
         full_launches = full_accepted = 0
@@ -538,11 +494,6 @@ class _RejectionSampler(_DeviceBoundBase):
         return self._queue().pop(n_points)
 
     def _reset_sampling(self, rng=None):
-        global _PENDING_OWNER
-        if getattr(self, '_pending', None) is not None:
-            self._pending = None         # (its proposals are given up)
-            if _PENDING_OWNER is self:
-                _PENDING_OWNER = None
         self._queue().clear()
         self.n_sample = 0
         self.n_reject = 0
@@ -664,9 +615,6 @@ class Union(_RejectionSampler):
     def _account(self, n_draw, n_outer, n_final):
         self.n_sample += n_draw                    # union.py:322
         self.n_reject += n_draw - n_outer          # union.py:323
-
-    def prefetch(self, n_points):
-        """(a union refills through its own loop: nothing is enqueued ahead)"""
 
     def _fill(self, n_points):
         q = self._queue()

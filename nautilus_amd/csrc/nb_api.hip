@@ -43,10 +43,6 @@ int nb_launch_eval_fast_batch(const double* blob0_dev, int n_dim, int recentre,
                               long long n_upper, int out_mode,
                               unsigned char* st, int* first,
                               hipStream_t stream);
-int nb_launch_accept_draw(const double* blob_dev, int n_dim, long long n,
-                          double* x_out, unsigned char* flags,
-                          unsigned long long seed, unsigned long long offset,
-                          hipStream_t stream);
 int nb_launch_eval(int dt, const double* const* blobs_dev, int nb, int mode,
                    const double* x, long long n, unsigned char* out_u8,
                    int* out_i32, double* out_f64, unsigned long long seed,
@@ -142,7 +138,6 @@ struct nb_bound {
   bool single_full_ellipsoid = false;
   int64_t off_stream = 0;
   int64_t off_members = 0, off_neural = 0;
-  bool draw_tiles = false;     // the blob holds the matrix-core draw block
 };
 
 static inline int64_t nb_hdr_host_off_members(const nb_bound* b) {
@@ -344,13 +339,6 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   }
   const int64_t off_shift = off;
   if (d->n_periodic > 0) off += 2 * dp;
-  // draw block for the acceptance kernel that draws its own proposals
-  // (one member that is an ellipsoid over ALL dimensions: idx_ell, if given,
-  // is then the identity -- fill_ell_block checks that it is increasing)
-  const bool draw_tiles = (K == 1 && M == 1 && E >= 1 && dt <= 4 &&
-                           d->members[0].n_ell == n_dim);
-  const int64_t off_drawt = off;
-  if (draw_tiles) off += 128 + (int64_t)dt * (dt + 1) / 2 * NB_TILE;
   const int64_t total = off;
 
   std::vector<double> buf((size_t)total, 0.0);
@@ -374,27 +362,6 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   put_i64(buf, NB_H_TOTAL, total);
   put_i64(buf, NB_H_OFF_STREAM, single_full ? off_stream : 0);
   put_i64(buf, NB_H_OFF_SHIFT, d->n_periodic > 0 ? off_shift : 0);
-  put_i64(buf, NB_H_OFF_DRAWT, draw_tiles ? off_drawt : 0);
-  if (draw_tiles) {
-    const nb_member_desc& md = d->members[0];
-    for (int f = 0; f < n_dim; ++f)
-      buf[off_drawt + slot_of_feature(f)] = md.c[f];
-    double* tl = &buf[off_drawt + 128];
-    for (int ht = 0; ht < dt; ++ht)
-      for (int kt = 0; kt <= ht; ++kt)
-        for (int s4 = 0; s4 < 4; ++s4)
-          for (int lg = 0; lg < 4; ++lg)
-            for (int i = 0; i < 16; ++i) {
-              const int r = i >> 2, g = i & 3;
-              const int row = 16 * ht + 8 * (r >> 1) + 2 * g + (r & 1);
-              const int col = 16 * kt + 8 * (s4 >> 1) + 2 * lg + (s4 & 1);
-              double v = 0.0;
-              if (row < n_dim && col < n_dim && col <= row)
-                v = md.B[(size_t)row * n_dim + col];
-              tl[((size_t)(ht * (ht + 1)) / 2 + kt) * NB_TILE + s4 * 64 +
-                 lg * 16 + i] = v;
-            }
-  }
   for (int i = 0; i < d->n_periodic; ++i) {
     const int f = d->periodic[i];
     if (f < 0 || f >= n_dim) {
@@ -535,7 +502,6 @@ int nb_bound_create(const nb_bound_desc* d, nb_bound** out) {
   b->off_stream = off_stream;
   b->off_members = off_members;
   b->off_neural = off_neural;
-  b->draw_tiles = draw_tiles;
   b->off_shift = nb_hdr(buf.data(), NB_H_OFF_SHIFT);
   b->neural_stride = nb_hdr(buf.data(), NB_H_NEURAL_STRIDE);
   // (the kernels stage parts of the blob in whole 1 KB pieces -- dma_weights,
@@ -864,22 +830,6 @@ int nb_accept(const nb_bound* b, uint64_t seed, uint64_t offset,
 #endif
   return nb_launch_eval(b->dt, b->self_list_dev, 1, 2, x, n, flags, nullptr,
                         nullptr, seed, offset, as_stream(stream));
-}
-
-int nb_accept_draw_available(const nb_bound* b) {
-  return b != nullptr && b->draw_tiles ? 1 : 0;
-}
-
-int nb_accept_draw(const nb_bound* b, uint64_t seed, uint64_t offset,
-                   int64_t n, double* x, uint8_t* flags, void* stream) {
-  if (!b->draw_tiles) {
-    nb_set_error("nb_accept_draw: the bound has no matrix-core draw block "
-                 "(needs one full-ellipsoid member, one neural bound with "
-                 "networks, n_dim <= 64); use nb_propose + nb_accept");
-    return NB_ERR_UNSUPPORTED;
-  }
-  return nb_launch_accept_draw(b->blob_dev, b->n_dim, n, x, flags, seed,
-                               offset, as_stream(stream));
 }
 
 int64_t nb_compact_scratch_bytes(int64_t n) {

@@ -54,16 +54,6 @@ typedef NB_G int nb_gi;
 //   hdr[19] off_shift (0 = no periodic dimensions): shift[DP], on[DP] in slot
 //                           order; contains() tests frac(x + shift) where on
 //                           (bounds/periodic.py:50-72)
-//   hdr[20] off_drawt (0 = none; one full-ellipsoid member, one neural bound
-//                           with networks, n_dim <= 64): the draw x = c + B z
-//                           as matrix-core operands for the acceptance kernel
-//                           that draws its own proposals -- c[128] in slot
-//                           order, then DT(DT+1)/2 lower-triangular tiles of
-//                           B whose ROWS are permuted so that the product
-//                           lands in the slot layout of the points (row 4 r +
-//                           g of row tile ht = feature 16 ht + 8 (r / 2) + 2 g
-//                           + r % 2) and whose k-steps run over z in slot
-//                           order (nb_eval_fast.hip)
 //
 // Ell block (member of the outer union, or ellipsoid of a neural bound):
 //   [0]            n_ell (as int64 bits; 0 => pure cube member, no MFMA work)
@@ -88,8 +78,7 @@ enum {
   NB_H_NDIM = 0, NB_H_DT, NB_H_K, NB_H_USECUBE, NB_H_M, NB_H_E, NB_H_OFF_CDF,
   NB_H_OFF_ULO, NB_H_OFF_UHI, NB_H_OFF_MEMBERS, NB_H_ELL_STRIDE,
   NB_H_OFF_NEURAL, NB_H_NEURAL_STRIDE, NB_H_OFF_DRAW, NB_H_DRAW_STRIDE,
-  NB_H_NET_STRIDE, NB_H_KT1, NB_H_TOTAL, NB_H_OFF_STREAM, NB_H_OFF_SHIFT,
-  NB_H_OFF_DRAWT
+  NB_H_NET_STRIDE, NB_H_KT1, NB_H_TOTAL, NB_H_OFF_STREAM, NB_H_OFF_SHIFT
 };
 
 __host__ __device__ inline int64_t nb_hdr(const double* blob, int i) {

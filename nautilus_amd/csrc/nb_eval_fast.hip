@@ -37,7 +37,6 @@
 #include <type_traits>
 
 #include "nb_mlp.h"
-#include "nb_draw.h"
 
 namespace {
 
@@ -68,10 +67,6 @@ struct FastArgs {
   int out_mode;                   // 0: any, 1: first, 2: sample (nb_cand.hip)
   unsigned char* st;              // per row: status written for candidates
   int* first;                     //          whose score passes the threshold
-  // DRAW (nb_accept_draw): the kernel draws proposal offset + i itself
-  // (RNG contract of nb_draw_kernel) and writes it to x_out before judging it
-  int draw;
-  double* x_out;
 };
 
 constexpr int FAST_B_DOUBLES =
@@ -85,9 +80,8 @@ typedef void __attribute__((address_space(3))) * nbf_lptr;
 template <int DT, int T>
 __device__ __forceinline__ void ell_eval_centre(
     const double* c, const double* tiles, int n_dim,
-    const double (&xin)[T][4 * DT], int lane, double (&y)[T][4 * DT],
+    const double (&xin)[T][4 * DT], int lane, int lg, double (&y)[T][4 * DT],
     double (&r2)[T]) {
-  const int lg = lane >> 4;
   double d[T][4 * DT];
 #pragma unroll
   for (int ks = 0; ks < 4 * DT; ++ks) {
@@ -137,7 +131,11 @@ template <int DT, int T>
 __device__ __forceinline__ void load_points_raw(
     const nb_gd* __restrict__ x, const long long (&row_of)[T], int n_dim,
     int lane, double2 (&raw)[T][2 * DT]) {
-  const int lg = lane >> 4;
+  // (lg opaque: the clamped column offsets below are loop invariants of the
+  // pass loop; hoisted, they are 6 DT 64-bit registers that lived through the
+  // whole pass -- the 300-500 bytes of scratch this kernel had beyond n_dim 64)
+  int lg = lane >> 4;
+  asm volatile("" : "+v"(lg));
   asm volatile("" : "+s"(x));
   if ((n_dim & 1) == 0) {
 #pragma unroll
@@ -166,8 +164,7 @@ __device__ __forceinline__ void load_points_raw(
 template <int DT, int T>
 __device__ __forceinline__ void points_from_raw(
     const double2 (&raw)[T][2 * DT], const bool (&valid)[T], int n_dim,
-    int lane, double (&xin)[T][4 * DT]) {
-  const int lg = lane >> 4;
+    int lg, double (&xin)[T][4 * DT]) {
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -180,9 +177,8 @@ __device__ __forceinline__ void points_from_raw(
 
 constexpr int FAST_REGION = 38 * NB_TILE;            // doubles per region
 
-template <int DT, int KT1, bool BATCH, bool DRAW>
+template <int DT, int KT1, bool BATCH>
 __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
-  static_assert(!(BATCH && DRAW), "the batched form reads its rows");
   constexpr int T = 1, NW = 8, DP = 16 * DT;
   constexpr int KS1 = 4 * KT1;
   // layer 1 in one stage if it fits a region, else in two K chunks
@@ -196,15 +192,8 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   constexpr int TAIL = HEAD + NT * NB_TILE;
   constexpr int TC = (2 + 2 * DP + 127) / 128;     // 1 KB pieces of the tail
   constexpr int ELL_CHUNKS = 1 + 2 * NT + TC;
-  // DRAW: the draw block (centre, then the lower-triangular tiles of B,
-  // nb_common.h hdr[20]) rides behind the ellipsoid block: one linear run
-  constexpr int DRAW_C = TAIL + TC * 128;
-  constexpr int DRAW_T = DRAW_C + 128;
-  constexpr int DRAW_CHUNKS = DRAW ? 1 + 2 * NT : 0;
   static_assert(DP <= HEAD, "centre fits the head");
   static_assert(TAIL + TC * 128 <= FAST_REGION, "ellipsoid block fits a region");
-  static_assert(!DRAW || DRAW_T + NT * NB_TILE <= FAST_REGION,
-                "ellipsoid block + draw block fit a region");
   static_assert(KA * NB_HT1 * NB_TILE <= FAST_REGION, "layer-1 chunk fits");
   constexpr int NA_D = KA * NB_HT1 * NB_TILE;               // chunk a
   constexpr int NB1_D = (KT1 - KA) * NB_HT1 * NB_TILE;      // chunk b
@@ -305,11 +294,10 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
     dma_src = src; dma_dst = dst; dma_c = wave; dma_n = n_doubles >> 7;
     dma_ell = false;
   };
-  const double* draw_blk = DRAW ? blob + nb_hdr(blob, NB_H_OFF_DRAWT) : nullptr;
   auto dma_begin_ell = [&](const double* nb_blk, double* dst)
       __attribute__((always_inline)) {
     dma_src = nb_blk; dma_dst = dst; dma_c = wave;
-    dma_n = ELL_CHUNKS + DRAW_CHUNKS;
+    dma_n = ELL_CHUNKS;
     dma_ell = true;
   };
   auto dma_one = [&]() __attribute__((always_inline)) {
@@ -326,17 +314,10 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       const int kt = p - ht * (ht + 1) / 2;
       s_off = 2 + 3 * DP + (kt * DT + ht) * NB_TILE + half * 128;
       d_off = HEAD + p * NB_TILE + half * 128;
-    } else if (!DRAW || dma_c < ELL_CHUNKS) {       // threshold, mean, 1/scale
+    } else {                                        // threshold, mean, 1/scale
       const int i = dma_c - 1 - 2 * NT;
       s_off = nb_ell_block_size(DT) + i * 128;
       d_off = TAIL + i * 128;
-    } else {                                        // draw block (linear)
-      const int i = dma_c - ELL_CHUNKS;
-      __builtin_amdgcn_global_load_lds(
-          (nbf_gptr)(draw_blk + i * 128 + 2 * lane),
-          (nbf_lptr)(dma_dst + DRAW_C + i * 128), 16, 0, 0);
-      dma_c += NW;
-      return;
     }
     __builtin_amdgcn_global_load_lds(
         (nbf_gptr)(dma_src + s_off + 2 * lane),
@@ -374,7 +355,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
     if constexpr (BATCH) nrow[t] = row_in(cur_p, t);
     else nrow[t] = row_of(pt[t]);
   }
-  if constexpr (!DRAW) load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
+  load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
 
   for (; sup < n_super; sup += gridDim.x) {
     const double* nb_m = cur_p.nb;
@@ -383,6 +364,12 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
     const double* nets = nb_m + nb_ell_block_size(DT) + 2 + 2 * DP;
     // (BATCH: the group of the next pass, a pass ahead of its block and rows)
     const Pass next_p = pass_of(sup + gridDim.x);
+    // lane group, opaque per pass: everything indexed by 4 ks + lg below (the
+    // centre, mean and scale slots, the cube and padding predicates) is a loop
+    // invariant of the pass loop, and hoisted out of it those are ~6 DT
+    // registers and as many saved predicates held across the network stages
+    int lgp = lg;
+    asm volatile("" : "+v"(lgp));
     long long crow[T];             // BATCH: the rows this pass evaluates
     // layer 1 (chunk a) of the first network -> the other region, under the
     // prologue; the ellipsoid block and the points are waited for here
@@ -393,9 +380,6 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
     __syncthreads();
     const double* blk = reg(q);
     const double thr = blk[TAIL];
-    auto blk_draw = [&](const double* region) __attribute__((always_inline)) {
-      return region + DRAW_C;
-    };
 
     bool in_cube[T], acc_outer[T], want[T];
     double xin[T][4 * DT];
@@ -414,88 +398,14 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
                          (lane & 15));
       }
     }
-    if constexpr (DRAW) {
-      // ---- the proposals of this pass, drawn where the matrix cores want
-      // them (nb_draw_kernel's streams: basic.py:376-381, z ~ N(0, I), z /=
-      // |z|, z *= u^(1/D), x = B z + c).  Slot pair (2 j, 2 j + 1) of lane
-      // group g holds the coordinates 8 j + 2 g, + 1: Box-Muller pair p = 4 j
-      // + g, i.e. half of block p / 2 of the normal stream.
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const unsigned long long g = a.offset + (unsigned long long)pt[t];
-        double zv[4 * DT], part = 0.0;
-#pragma unroll
-        for (int j = 0; j < 2 * DT; ++j) {
-          zv[2 * j] = 0.0;
-          zv[2 * j + 1] = 0.0;
-          if (8 * j < n_dim) {
-            const int p = 4 * j + lg;
-            const nb_u4 w = nb_philox((uint32_t)g, (uint32_t)(g >> 32),
-                                      (uint32_t)(p >> 1), NB_TAG_NORMAL,
-                                      (uint32_t)a.seed,
-                                      (uint32_t)(a.seed >> 32));
-            double z0, z1;
-            draw_normal_pair((p & 1) ? w.z : w.x, (p & 1) ? w.w : w.y, z0,
-                             z1);
-            if (2 * p < n_dim) { zv[2 * j] = z0; part = fma(z0, z0, part); }
-            if (2 * p + 1 < n_dim) {
-              zv[2 * j + 1] = z1;
-              part = fma(z1, z1, part);
-            }
-          }
-        }
-        double u_radius, u_spare;
-        nb_uniform_pair(a.seed, g, 1u, NB_TAG_CTRL, u_radius, u_spare);
-        const double scale = pow(u_radius, 1.0 / (double)n_dim) /
-                             sqrt(lane_group_sum(part));
-        const double* dc = blk_draw(reg(q)) + 0;
-        const double* dtl = dc + 128;
-#pragma unroll
-        for (int ht = 0; ht < DT; ++ht) {
-          nb_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < 4 * (ht + 1); ++ks) {
-            const double av =
-                dtl[(ht * (ht + 1) / 2 + (ks >> 2)) * NB_TILE + (ks & 3) * 64 +
-                    lane];
-            acc = MFMA(av, zv[ks] * scale, acc);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            xin[t][4 * ht + r] = acc[r] + dc[4 * (4 * ht + r) + lg];
-        }
-        // the proposal goes to memory as nb_draw_kernel would have left it
-        // (the compaction behind this kernel copies the accepted rows)
-        if (valid[t]) {
-          double* row = a.x_out + pt[t] * n_dim;
-          if ((n_dim & 1) == 0) {
-#pragma unroll
-            for (int j = 0; j < 2 * DT; ++j) {
-              const int f = 8 * j + 2 * lg;
-              if (f < n_dim)
-                *(double2*)(row + f) =
-                    double2{xin[t][2 * j], xin[t][2 * j + 1]};
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 2 * DT; ++j) {
-              const int f = 8 * j + 2 * lg;
-              if (f < n_dim) row[f] = xin[t][2 * j];
-              if (f + 1 < n_dim) row[f + 1] = xin[t][2 * j + 1];
-            }
-          }
-        }
-      }
-    } else {
-      points_from_raw<DT, T>(xraw, valid, n_dim, lane, xin);
-    }
+    points_from_raw<DT, T>(xraw, valid, n_dim, lgp, xin);
     if (shift != nullptr) {
       // periodic dimensions are recentred before the test (nautilus.py:
       // 162-163, periodic.py:69-71): x <- (x + (0.5 - centre)) mod 1
 #pragma unroll
       for (int ks = 0; ks < 4 * DT; ++ks) {
-        const double sv = shift[4 * ks + lg];
-        const bool on = shift[DP + 4 * ks + lg] != 0.0;
+        const double sv = shift[4 * ks + lgp];
+        const bool on = shift[DP + 4 * ks + lgp] != 0.0;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const double v = xin[t][ks] + sv;
@@ -509,7 +419,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       for (int t = 0; t < T; ++t) cbad[t] = false;
 #pragma unroll
       for (int ks = 0; ks < 4 * DT; ++ks) {
-        const int f = 8 * (ks >> 1) + 2 * lg + (ks & 1);
+        const int f = 8 * (ks >> 1) + 2 * lgp + (ks & 1);
         const bool boxed = use_cube && f < n_dim;
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -531,7 +441,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
 
     double y[T][4 * DT], r2[T];
     bool box_bad[T], inside_e[T], need[T];
-    ell_eval_centre<DT, T>(blk, blk + HEAD, n_dim, xin, lane, y, r2);
+    ell_eval_centre<DT, T>(blk, blk + HEAD, n_dim, xin, lane, lgp, y, r2);
 #pragma unroll
     for (int t = 0; t < T; ++t) box_bad[t] = false;
     bool wave_mlp = false;
@@ -551,13 +461,17 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       const double* r_isc = r_mean + DP;
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
-        const int f = 4 * ks + lg;
+        const int f = 4 * ks + lgp;
         if (ks < 4 * DT) {
+          // (slots up to 16 DT exist in the block; what the padding holds is
+          // discarded by the select)
           const double mv = r_mean[f], sv = r_isc[f];
+          const double pad = (f == n_dim) ? 1.0 : 0.0;
 #pragma unroll
-          for (int t = 0; t < T; ++t)
-            tin[t][ks] = (f < n_dim) ? (y[t][ks] - mv) * sv
-                                     : ((f == n_dim) ? 1.0 : 0.0);
+          for (int t = 0; t < T; ++t) {
+            const double v = (y[t][ks] - mv) * sv;
+            tin[t][ks] = (f < n_dim) ? v : pad;
+          }
         } else {
 #pragma unroll
           for (int t = 0; t < T; ++t) tin[t][ks] = (f == n_dim) ? 1.0 : 0.0;
@@ -618,8 +532,7 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
       // -- layers 2-4; next network's chunk a, or the ellipsoid block of the
       // next pass, -> other region
       if constexpr (LAST) {
-        if constexpr (!DRAW)
-          load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
+        load_points_raw<DT, T>(a.x, nrow, n_dim, lane, xraw);
         dma_begin_ell(next_p.nb, reg(cur ^ 1));
       } else {
         dma_begin(nets + (e + 1) * net_stride, reg(cur ^ 1), NA_D);
@@ -688,14 +601,14 @@ __global__ void __launch_bounds__(512) nb_eval_fast_kernel(FastArgs a) {
   }
 }
 
-template <int DT, int KT1, bool BATCH, bool DRAW = false>
+template <int DT, int KT1, bool BATCH>
 int launch_fast_impl(const FastArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * FAST_REGION * sizeof(double) +
                      (BATCH ? (FAST_MAX_GROUPS + 1) * sizeof(int) : 0);
   static bool configured = false;
   if (!configured) {
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)nb_eval_fast_kernel<DT, KT1, BATCH, DRAW>,
+        (const void*)nb_eval_fast_kernel<DT, KT1, BATCH>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed: %s", lds,
@@ -708,16 +621,13 @@ int launch_fast_impl(const FastArgs& a, hipStream_t stream) {
   // without a pass leave at once
   const long long n_super = (a.n + 127) / 128;
   long long blocks = n_super < 256 ? n_super : 256;
-  hipLaunchKernelGGL((nb_eval_fast_kernel<DT, KT1, BATCH, DRAW>),
+  hipLaunchKernelGGL((nb_eval_fast_kernel<DT, KT1, BATCH>),
                      dim3((unsigned)blocks), dim3(512), lds, stream, a);
   return NB_OK;
 }
 
 template <int DT, int KT1>
 int launch_fast(const FastArgs& a, hipStream_t stream) {
-  if constexpr (DT <= 4) {
-    if (a.draw != 0) return launch_fast_impl<DT, KT1, false, true>(a, stream);
-  }
   return a.groups != nullptr ? launch_fast_impl<DT, KT1, true>(a, stream)
                              : launch_fast_impl<DT, KT1, false>(a, stream);
 }
@@ -806,26 +716,5 @@ int nb_launch_eval_fast_batch(const double* blob0_dev, int n_dim, int recentre,
   a.groups = (const FastGroup*)groups_dev; a.n_groups = n_groups;
   a.totals = totals_dev; a.dense = dense_dev; a.n_pad = n_pad;
   a.out_mode = out_mode; a.st = st; a.first = first;
-  return dispatch_fast(a, n_dim, stream);
-}
-
-// nb_accept with the draw inside: proposals offset .. offset + n - 1 of the
-// bound's stream are drawn by the acceptance kernel itself, written to x_out
-// and judged (blob with a draw block, nb_common.h hdr[20]).
-int nb_launch_accept_draw(const double* blob_dev, int n_dim, long long n,
-                          double* x_out, unsigned char* flags,
-                          unsigned long long seed, unsigned long long offset,
-                          hipStream_t stream) {
-  if (n <= 0) return NB_OK;
-  if (n_dim > 64) {
-    nb_set_error("nb_launch_accept_draw: n_dim=%d (the draw block fits the "
-                 "staging regions up to 64)", n_dim);
-    return NB_ERR_UNSUPPORTED;
-  }
-  FastArgs a = {};
-  a.blob = blob_dev; a.sample = 1; a.n = n; a.draw = 1; a.x_out = x_out;
-  a.x = (const nb_gd*)x_out;
-  a.out_u8 = flags; a.seed = seed; a.offset = offset;
-  a.counters = nb_eval_counters();
   return dispatch_fast(a, n_dim, stream);
 }

@@ -148,9 +148,6 @@ class DeviceBound:
         _lib.check(lib.nb_bound_create(C.byref(desc), C.byref(handle)))
         self._h = handle
         self._lib = lib
-        # the blob carries the operands of nb_accept_draw (one full-ellipsoid
-        # member, one neural bound with networks, n_dim <= 64)
-        self.can_draw = bool(lib.nb_accept_draw_available(handle))
         del keep
 
     def __del__(self):
@@ -251,36 +248,17 @@ class DeviceBound:
             self.dense_need = float(totals.sum()) / max(1, n)
         return flags
 
-    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False,
-                      out_slot=None):
+    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False):
         """One launch of the device ``sample`` pipeline: draw, accept,
         compact.  Returns (points, counters) with counters = int64 tensor
         [n kept by the outer union, n kept in total] still on the device.
         ``reuse=True`` (the bounds' refill loops): the launch works in the
         process-wide scratch buffers and the returned rows are only valid
-        until the next such launch; ``out_slot='name'``: the compacted rows go
-        to a scratch buffer of that name instead (a launch whose result is
-        collected later, ``_RejectionSampler.prefetch``)."""
-        if (self.can_draw and FUSED_DRAW and self.dense_need is not None and
-                self.dense_need > 0.5):
-            x, flags = self.accept_draw(seed, offset, n_draw, reuse)
-        else:
-            x = self.propose(seed, offset, n_draw, reuse)
-            flags = self.accept(seed, offset, x, reuse)
-        out, counts, _ = compact_rows(x, flags, mask,
-                                      reuse=out_slot if out_slot else reuse)
+        until the next such launch."""
+        x = self.propose(seed, offset, n_draw, reuse)
+        flags = self.accept(seed, offset, x, reuse)
+        out, counts, _ = compact_rows(x, flags, mask, reuse=reuse)
         return out, counts
-
-    def accept_draw(self, seed, offset, n, reuse=False):
-        """``propose`` + ``accept`` in one kernel (``nb_accept_draw``): the
-        acceptance kernel draws the proposals itself.  Returns (proposals,
-        flags)."""
-        x = _buffer('propose', (n, self.n_dim), torch.float64, reuse)
-        flags = _buffer('accept', (n,), torch.uint8, reuse)
-        _lib.check(self._lib.nb_accept_draw(self._h, seed, offset, n, _ptr(x),
-                                            _ptr(flags), _stream()))
-        DISPATCHES['nb_eval_fast_kernel'] += 1
-        return x, flags
 
 
 class DeviceBoundList:
@@ -360,14 +338,6 @@ class DeviceBoundList:
                            first)
 
 
-# NB_FUSED_DRAW=1: sample_launch lets the acceptance kernel draw its own
-# proposals (nb_accept_draw) where the bound allows it.  Off by default: built,
-# parity-green and measured -- 11.11 against 11.04 ms per step of the headline
-# bench with nb_propose + nb_accept (profiles/r04/fused_draw_ab.txt): the
-# wavefronts of a workgroup run their per-pass prologues in lockstep behind
-# the stage barriers, so the draw's VALU work finds no MFMA stream of a
-# neighbour to hide in and costs what the separate kernel cost.
-FUSED_DRAW = os.environ.get('NB_FUSED_DRAW', '0') == '1'
 GEOM_ANY, GEOM_FIRST, GEOM_SAMPLE = 0, 1, 2
 NO_BOUND = 2**31 - 1       # nb_list_eval: no bound of the list contains the row
 WORK_BYTES = 256 << 20     # candidate lists of one slab of rows
@@ -597,8 +567,6 @@ def _buffer(role, shape, dtype, reuse):
     to hipMalloc -- tens of milliseconds each -- in the middle of a run."""
     if not reuse:
         return torch.empty(shape, dtype=dtype, device='cuda')
-    if isinstance(reuse, str):       # a scratch buffer of its own (prefetch)
-        role = role + ':' + reuse
     n_bytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
     buf = _SCRATCH.get(role)
     if buf is None or buf.numel() < n_bytes:
@@ -832,7 +800,6 @@ def _timed(name):
 # emulator scores behind it.
 DeviceBound.contains = _timed('bound_eval')(DeviceBound.contains)
 DeviceBound.accept = _timed('bound_eval')(DeviceBound.accept)
-DeviceBound.accept_draw = _timed('bound_eval')(DeviceBound.accept_draw)
 DeviceBound.neural_score = _timed('bound_eval')(DeviceBound.neural_score)
 DeviceBound.propose = _timed('nb_draw_kernel')(DeviceBound.propose)
 DeviceBound.contains_stream = _timed('nb_ell_stream_kernel')(

@@ -90,14 +90,6 @@ class _RowsInFlight:
 
 
 MAX_IN_FLIGHT = 4        # gathers of points a rank keeps pending
-# sampling phase: enqueue the next batch's refill launch before the host-side
-# bookkeeping of the current one (NB_PREFETCH=1).  Off by default: measured on
-# the bench it hides the idle queue of the bookkeeping (0.75 -> 0.55 ms per
-# step) but, sized before the batch's consumption is known and topped up with
-# the refill's 1.2 safety factor, it leaves a growing surplus in the queue --
-# 13.0 instead of 10.55 ms per step over the 20 timed steps
-# (profiles/r04/second_session/bench_prefetch_ab.txt).
-PREFETCH = bool(os.environ.get('NB_PREFETCH'))
 
 
 class Sampler:
@@ -543,10 +535,6 @@ class Sampler:
                     if n_s > 0 else 0.5
                 n_req = int(min(4 * device_block(), need / frac * 1.15 + 256))
             x = bound.sample_device(n_req)
-            if self.__dict__.get('_last_request') is None:
-                # (the first request of the batch: further rounds of this
-                # loop only top up)
-                self._last_request = (bound, n_req)
             if later is not None:
                 # sampler.py:796-799 on the device: flag the points inside a
                 # later bound, compact the others in order; the source row of
@@ -732,14 +720,6 @@ class Sampler:
                 log_l, log_l_dev = self._sharded_likelihood(pts)
             else:
                 log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
-        if (PREFETCH and self.explored and self.comm is None and
-                shell != -1 and self.__dict__.get('_last_request')):
-            # sampling phase: the refill launch of the next batch of this
-            # shell goes to the GPU before the host-side bookkeeping starts
-            bound, n_req = self._last_request
-            if hasattr(bound, 'prefetch'):
-                bound.prefetch(n_req)
-        self._last_request = None
         t2 = time()
         if isinstance(pts, _RowsInFlight):
             # sharded sampling phase: the rows are on their way to this rank

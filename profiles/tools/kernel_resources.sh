@@ -1,7 +1,7 @@
 #!/bin/bash
 # Registers / spills / LDS of every kernel of one source file (compile only):
 #   profiles/tools/kernel_resources.sh nautilus_amd/csrc/nb_eval_fast.hip [filter]
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -c "$1" -o /tmp/nb_res.o \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Iinclude -Inautilus_amd/csrc -c "$1" -o /tmp/nb_res.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys, re, subprocess
 flt = sys.argv[1] if len(sys.argv) > 1 else ''

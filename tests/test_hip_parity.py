@@ -418,67 +418,6 @@ def test_accept_routes_agree(dev):
     assert 0.0 <= b.dense_need <= 1.0
 
 
-@pytest.mark.parametrize('d', [4, 20, 33, 50, 64])
-def test_accept_draw_equals_propose_plus_accept(dev, d, monkeypatch):
-    """nb_accept_draw (the acceptance kernel draws its own proposals: normals
-    straight into the matrix cores' operand layout, x = c + B z as MFMAs)
-    against nb_propose + nb_accept on the same stream positions: the same
-    proposals to rounding (1e-12; the triangular product is summed in a
-    different order) and the same flags, except for proposals whose decision
-    flips with that rounding."""
-    from nautilus_amd import bounds as nbd, device
-    from nautilus_amd.emulator import NeuralNetworkEmulator, Network
-    rs = np.random.RandomState(d)
-    a = rs.normal(size=(d, d)) * 0.05 / np.sqrt(d) + 0.12 * np.eye(d)
-    cov = a @ a.T
-    B = np.linalg.cholesky(cov)
-    c = 0.5 + 0.02 * rs.normal(size=d)
-    ell = nbd.Ellipsoid.from_params(c, B, np.linalg.inv(B),
-                                    np.linalg.inv(cov))
-    units = [d, 100, 50, 20, 1]
-    nets = []
-    for _ in range(2):
-        coefs, icpts = [], []
-        for fi, fo in zip(units[:-1], units[1:]):
-            lim = np.sqrt(6.0 / (fi + fo))
-            coefs.append(rs.uniform(-lim, lim, (fi, fo)))
-            icpts.append(rs.uniform(-lim, lim, fo))
-        nets.append(Network(coefs, icpts))
-    emu = NeuralNetworkEmulator.from_weights(np.zeros(d), np.ones(d), nets)
-
-    def make(threshold):
-        neural = nbd.NeuralBound.from_parts(
-            nbd.Ellipsoid.from_params(c, 0.99 * B, np.linalg.inv(0.99 * B),
-                                      np.linalg.inv(0.9801 * cov)), emu,
-            threshold)
-        outer = nbd.Union.from_members([ell], unit=True)
-        outer.log_v_all = np.array([ell.log_v])
-        return nbd.NautilusBound.from_parts(
-            outer, [neural], rng=np.random.default_rng(1)).device_bound()
-    # the emulator's threshold at the median score of the bound's proposals
-    probe = make(0.0)
-    score = probe.neural_score(probe.propose(3, 0, 20000))[1]
-    b = make(float(score.median()))
-    assert b.can_draw
-    seed, offset, n = 1234567 + d, 10**11 + 3, 70001
-    x_ref = b.propose(seed, offset, n)
-    b.dense_need = 1.0                                   # fused acceptance
-    f_ref = b.accept(seed, offset, x_ref).cpu().numpy()
-    x, f = b.accept_draw(seed, offset, n)
-    assert np.allclose(x.cpu().numpy(), x_ref.cpu().numpy(), rtol=0,
-                       atol=1e-12)
-    f = f.cpu().numpy()
-    assert 50 < (f_ref >> 1).sum() < n - 50 and (f_ref & 1).mean() > 0.5
-    assert int(np.sum(f != f_ref)) <= 2
-    # ... and through the sampling pipeline
-    monkeypatch.setattr(device, 'FUSED_DRAW', True)
-    rows, counts = b.sample_launch(seed, offset, n)
-    k = int(counts[1])
-    keep = (f & 2) != 0
-    assert k == int(keep.sum())
-    assert torch.equal(rows[:k], x[torch.from_numpy(keep).cuda()])
-
-
 def test_list_eval_matches_the_one_kernel_form(dev):
     """nb_list_eval (candidate lists + one batched emulator launch; exclusion
     = any bound, association = first bound) against the one-kernel form that

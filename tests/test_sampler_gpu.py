@@ -781,56 +781,3 @@ def test_measured_barren_bound_is_dropped(monkeypatch):
     assert s.run(n_eff=2000, discard_exploration=True) is True
     assert s.n_dead_bounds == 1
     assert abs(s.log_z - analytic) < max(0.03, 4 * np.std(ref_lz))
-
-
-def test_prefetched_refill_hands_out_the_same_points():
-    """``_RejectionSampler.prefetch`` (a refill launch enqueued ahead of the
-    demand, collected by the next ``sample_device``; NB_PREFETCH=1 in the
-    sampler): the proposals are the next ones of the bound's stream and the
-    queue keeps what a launch accepts beyond the demand, so the points handed
-    out are the same sequence with and without it; a pickled bound carries the
-    collected launch in its queue."""
-    import pickle
-    import torch
-    from nautilus_amd import bounds as nb
-    from nautilus_amd.emulator import NeuralNetworkEmulator, Network
-    d = 6
-
-    def build():
-        rs = np.random.RandomState(3)
-        a = rs.normal(size=(d, d)) * 0.02 / np.sqrt(d) + 0.08 * np.eye(d)
-        cov = a @ a.T
-        B = np.linalg.cholesky(cov)
-        c = np.full(d, 0.5)
-        ell = nb.Ellipsoid.from_params(c, B, np.linalg.inv(B),
-                                       np.linalg.inv(cov))
-        units = [d, 100, 50, 20, 1]
-        coefs, icpts = [], []
-        for u, v in zip(units[:-1], units[1:]):
-            lim = np.sqrt(6.0 / (u + v))
-            coefs.append(rs.uniform(-lim, lim, (u, v)))
-            icpts.append(rs.uniform(-lim, lim, v))
-        emu = NeuralNetworkEmulator.from_weights(
-            np.zeros(d), np.ones(d), [Network(coefs, icpts)])
-        neural = nb.NeuralBound.from_parts(
-            nb.Ellipsoid.from_params(c, B, np.linalg.inv(B),
-                                     np.linalg.inv(cov)), emu, 0.0)
-        outer = nb.Union.from_members([ell], unit=True)
-        outer.log_v_all = np.array([ell.log_v])
-        return nb.NautilusBound.from_parts(outer, [neural],
-                                           rng=np.random.default_rng(1))
-
-    out = []
-    for use in (False, True):
-        b = build()
-        got = []
-        for n in (1000, 3000, 500, 20000, 7):
-            if use:
-                b.prefetch(n)
-            got.append(b.sample_device(n).clone())
-            if use and n == 3000:
-                b.prefetch(4000)
-                b = pickle.loads(pickle.dumps(b))
-        out.append(torch.cat(got).cpu().numpy())
-    assert out[0].shape == (24507, d)
-    assert np.array_equal(out[0], out[1])
