@@ -36,7 +36,6 @@
 #include <limits.h>
 
 #include "nb_common.h"
-#include <cstdlib>
 
 #include "nb_tile.h"
 
@@ -93,7 +92,7 @@ struct StepTable {
 template <int DT, int T, int PD, class XF>
 __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
                                             bool has_box, XF&& X, int lane,
-                                            bool (&inside)[T]) {
+                                            int lg, bool (&inside)[T]) {
   constexpr int DP = 16 * DT;
   constexpr StepTable<DT> TAB{};
   constexpr int N = StepTable<DT>::N;
@@ -101,7 +100,6 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
   const nb_gd* hi = lo + DP;
   const nb_gd* c = hi + DP;
   const nb_gd* tiles = c + DP;
-  const int lg = lane >> 4;
   bool bad[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) bad[t] = false;
@@ -175,7 +173,9 @@ template <int DT, int T, int OCC, bool SAMPLE>
 __global__ void __launch_bounds__(64 * CD_WPB)
 __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   constexpr int DP = 16 * DT;
-  constexpr int PD = OCC >= 4 ? 6 : 10;   // k-steps the operands run ahead
+  // k-steps the operands run ahead (two tiles at n_dim > 112 have the
+  // registers for six)
+  constexpr int PD = OCC >= 4 ? 6 : ((DT == 8 && T == 2) ? 6 : 10);
   extern __shared__ int cur[];           // [n_groups][CD_WPB] fill counts
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -232,6 +232,12 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
 
     bool reload = false;
     for (int b = 0; b < a.nb; ++b) {
+      // lane group, opaque per bound: what is indexed by 4 ks + lg below
+      // (offsets of the centre / limit / shift slots, padding predicates of
+      // the cube clip) would otherwise be hoisted out of both loops and held
+      // in registers for the whole kernel
+      int lgb = lg;
+      asm volatile("" : "+v"(lgb));
       if (reload) {
         load_points<DT, T>(a.x, row, valid, n_dim, a.n, lane, xin);
         reload = false;
@@ -260,8 +266,8 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         const nb_gd* shift = blob + off_shift;
 #pragma unroll
         for (int ks = 0; ks < 4 * DT; ++ks) {
-          const double sv = shift[4 * ks + lg];
-          const bool on = shift[DP + 4 * ks + lg] != 0.0;
+          const double sv = shift[4 * ks + lgb];
+          const bool on = shift[DP + 4 * ks + lgb] != 0.0;
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const double u = xin[t][ks] + sv;
@@ -292,7 +298,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
           for (int t = 0; t < T; ++t) d2[t] = 0.0;
 #pragma unroll
           for (int ks = 0; ks < 4 * DT; ++ks) {
-            const double cv = cc[4 * ks + lg];
+            const double cv = cc[4 * ks + lgb];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
               const double dv = X(t, ks) - cv;
@@ -316,7 +322,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         bool cbad = false;
 #pragma unroll
         for (int ks = 0; ks < 4 * DT; ++ks) {
-          const int f = 8 * (ks >> 1) + 2 * lg + (ks & 1);
+          const int f = 8 * (ks >> 1) + 2 * lgb + (ks & 1);
           const double xv = X(t, ks);
           cbad |= use_cube && f < n_dim && !(xv >= 0.0 && xv < 1.0);
         }
@@ -341,7 +347,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
           const bool has_ell = ((const NB_G long long*)blk)[0] > 0;
           const bool has_box = ((const NB_G long long*)blk)[1] != 0;
           bool ins[T];
-          cand_inside<DT, T, PD>(blk, has_ell, has_box, X, lane, ins);
+          cand_inside<DT, T, PD>(blk, has_ell, has_box, X, lane, lgb, ins);
 #pragma unroll
           for (int t = 0; t < T; ++t) k_cnt[t] += ins[t] ? 1 : 0;
         }
@@ -387,7 +393,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         if (!__any(any_want)) break;
         const nb_gd* nb_m = nblk0 + m * neural_stride;
         bool ins[T];
-        cand_inside<DT, T, PD>(nb_m, true, false, X, lane, ins);
+        cand_inside<DT, T, PD>(nb_m, true, false, X, lane, lgb, ins);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const bool test = want[t] && !decided[t];
@@ -496,34 +502,25 @@ int launch_cand_t(const CandArgs& a, hipStream_t stream) {
 
 unsigned long long* nb_eval_counters();
 
-// tiles per wavefront (see nb_cand_shape)
-static bool cand_two_tiles_experiment() {
-  // NB_CAND_TWO_TILES=1: two tiles per wavefront at n_dim 97-112 (the
-  // spilling instantiation of the scratch experiment, see nb_cand_shape)
-  static const bool on = getenv("NB_CAND_TWO_TILES") != nullptr;
-  return on;
-}
+// Tiles per wavefront: two share every A operand.  Proposals: two at any
+// n_dim; lists (first-hit bookkeeping, sphere pre-test, periodic shift next to
+// the points): two up to n_dim 80, one beyond -- the shapes that need no
+// scratch (profiles/tools/kernel_resources.sh: 0 bytes for every shipped
+// instantiation; a kernel WITH scratch at n_dim ~ 100 ran three times slower
+// for the rest of a process's life in 2 of 5 processes, profiles/r04/
+// second_session/scratch_experiment_2.txt).  Until round 5 the kernels held
+// ~6 DT registers of loop-invariant slot offsets and padding predicates across
+// the bound loop; with the lane group opaque per bound they are recomputed
+// where they are used.
 static int cand_tiles(int dt, int mode) {
-  (void)mode;
-  if (dt == 7 && cand_two_tiles_experiment()) return 2;
-  return dt <= 4 ? 2 : 1;
+  if (mode == CM_SAMPLE) return 2;
+  return dt <= 5 ? 2 : 1;
 }
 
 // Geometry of the candidate lists for n points: points per wavefront, number
 // of wavefronts, padded list length (all multiples the kernels rely on).
 void nb_cand_shape(int dt, int mode, long long n, int* chunk, int* n_waves,
                    long long* n_pad) {
-  // Tiles per wavefront: two up to n_dim 64, ONE beyond.  Two are faster there
-  // in a process of their own (5.0 against 6.1 ms per 2^20 proposals at n_dim
-  // 100, K = M = 4) but spill (440 bytes of scratch per lane), and a kernel
-  // with that much scratch made the queue idle between the dispatches of a
-  // call whenever smaller-n_dim kernels had run in the process before: 9.8 to
-  // 17.5 ms per call (profiles/r04/accept_bench_50_then_100_one_process.txt;
-  // under rocprofv3 the gaps vanish, profiles/r04/trace_50_then_100.txt; a
-  // smaller grid did not help; the proposals' instantiation alone, 244 bytes
-  // of scratch, showed the same: 4.9 ms on its own or behind n_dim = 20
-  // kernels, 14.3 ms behind n_dim = 50 kernels).  One tile per wavefront needs
-  // no scratch up to n_dim 112 and runs the same 6.1 ms in all of these.
   const int tile = 16 * cand_tiles(dt, mode);
   // wavefronts of the grid: what the chip holds at once at the kernel's
   // register budget (two per SIMD from n_dim 33 on: 2048), twice that for the
@@ -586,13 +583,10 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
     case 2: rc = launch_cand_t<2, 2, 2, 3>(a, stream); break;
     case 3: rc = launch_cand_t<3, 2, 2, 2>(a, stream); break;
     case 4: rc = launch_cand_t<4, 2, 2, 2>(a, stream); break;
-    case 5: rc = launch_cand_t<5, 1, 1, 2>(a, stream); break;
-    case 6: rc = launch_cand_t<6, 1, 1, 2>(a, stream); break;
-    case 7:
-      if (cand_two_tiles_experiment()) rc = launch_cand_t<7, 2, 2, 2>(a, stream);
-      else rc = launch_cand_t<7, 1, 1, 2>(a, stream);
-      break;
-    case 8: rc = launch_cand_t<8, 1, 1, 2>(a, stream); break;
+    case 5: rc = launch_cand_t<5, 2, 2, 2>(a, stream); break;
+    case 6: rc = launch_cand_t<6, 2, 1, 2>(a, stream); break;
+    case 7: rc = launch_cand_t<7, 2, 1, 2>(a, stream); break;
+    case 8: rc = launch_cand_t<8, 2, 1, 2>(a, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;

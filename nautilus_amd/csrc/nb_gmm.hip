@@ -92,6 +92,16 @@ nb_gmm_kernel(GmmArgs a) {
 
   if (tid == 0) sh_bad = 0;
   __syncthreads();
+#ifdef NB_GMM_TIMING
+  // cycle counts per phase of restart 0 (debug build, make debug
+  // DEFS=-DNB_GMM_TIMING): S_all, seeding + Lloyd, then per EM phase
+  long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_last = wall_clock64();
+#define GM_STAMP(i) do { const long long t_now = wall_clock64(); \
+    tk[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define GM_STAMP(i) do {} while (0)
+#endif
 
   // weighted second moments of all points into `part` (every wave of a
   // sub-group owns two tile rows)
@@ -122,6 +132,7 @@ nb_gmm_kernel(GmmArgs a) {
     mean_var += sall[f * m + f] / n - mu * mu;
   }
   mean_var /= d;
+  GM_STAMP(0);
 
   // ---- initial hard assignment ---------------------------------------------
   if (a.init_labels != nullptr) {
@@ -274,6 +285,7 @@ nb_gmm_kernel(GmmArgs a) {
   }
   __threadfence_block();
   __syncthreads();
+  GM_STAMP(1);
 
   // the entries (r >= c) of the lower triangle this thread owns in the sweeps
   int sw_r[GM_SWEEP_EPT], sw_c[GM_SWEEP_EPT], sw_p[GM_SWEEP_EPT];
@@ -316,6 +328,7 @@ nb_gmm_kernel(GmmArgs a) {
       for (int f = tid; f < DP; f += GM_THREADS)
         mus[mv_slot(f)] = (f < d) ? mean[f] : 0.0;
       __syncthreads();
+      GM_STAMP(3);
       // symmetric sweep operator over all pivots: T <- -Sigma^-1, the pivots
       // are those of the L D L^T factorisation (log det = sum log d_p)
       double logdet = 0.0;
@@ -342,6 +355,7 @@ nb_gmm_kernel(GmmArgs a) {
         }
         __syncthreads();
       }
+      GM_STAMP(4);
       // -> T form: -(...) and doubled off-diagonal entries
 #pragma unroll
       for (int q = 0; q < GM_SWEEP_EPT; ++q)
@@ -364,11 +378,13 @@ nb_gmm_kernel(GmmArgs a) {
       }
       __threadfence_block();
       __syncthreads();
+      GM_STAMP(5);
     }
   };
   for (int it = 0; it <= a.max_iter && !failed; ++it) {
     // M-step (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters)
     moments(r0);
+    GM_STAMP(2);
     const double s00 = moment(d, d);
     const double nk0 = s00 + eps10;
     const double nk1 = ((double)n - s00) + eps10;
@@ -398,6 +414,7 @@ nb_gmm_kernel(GmmArgs a) {
     }
     __threadfence_block();
     __syncthreads();
+    GM_STAMP(3);
     if (it == a.max_iter || converged) break;
 
     // E-step (mixture/_base.py:_estimate_log_prob_resp)
@@ -414,6 +431,7 @@ nb_gmm_kernel(GmmArgs a) {
     __threadfence_block();
     const double lb = block_sum(lse_part, red, wave, lane) / n;
     __syncthreads();
+    GM_STAMP(6);
     n_iter = it + 1;
     if (fabs(lb - lower) < a.tol) converged = 1;
     lower = lb;
@@ -425,6 +443,12 @@ nb_gmm_kernel(GmmArgs a) {
     log_prob();
     failed = sh_bad != 0;
   }
+#ifdef NB_GMM_TIMING
+  if (tid == 0 && init == 0)
+    printf("[gmm] n=%d d=%d iters=%d  ticks(100MHz): s_all %lld seed+lloyd %lld "
+           "moments %lld mstep/build %lld sweeps %lld quadform %lld estep %lld\n",
+           n, d, n_iter, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
+#endif
   if (tid == 0) {
     out[0] = failed ? -inf : lower;
     out[1] = n_iter;

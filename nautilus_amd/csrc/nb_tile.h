@@ -116,7 +116,11 @@ __device__ __forceinline__ void load_points(const nb_gd* __restrict__ x,
                                             int n_dim, long long n, int lane,
                                             double (&xin)[TPW][4 * DT],
                                             const double* shift = nullptr) {
-  const int lg = lane >> 4;
+  // (opaque: the clamped column offsets and padding predicates below are
+  // invariants of the callers' loops; hoisted out of them they are 6 DT
+  // registers held for the whole kernel)
+  int lg = lane >> 4;
+  asm volatile("" : "+v"(lg));
   const bool even = (n_dim & 1) == 0;
   // the loads are loop invariant across the bounds of a list; laundering the
   // base pointer keeps the compiler from hoisting them (and the registers

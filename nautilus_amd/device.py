@@ -117,7 +117,9 @@ class DeviceBound:
             md.mean, md.scale = _dp(mean), _dp(scale)
             cp = (_lib.c_double_p * (4 * e))()
             ip = (_lib.c_double_p * (4 * e))()
+            from .emulator import pad_network
             for i, (coefs, intercepts) in enumerate(mlp['nets']):
+                coefs, intercepts = pad_network(coefs, intercepts, self.n_dim)
                 for k in range(4):
                     w, b = _f64(coefs[k]), _f64(intercepts[k])
                     keep += [w, b]

@@ -37,9 +37,59 @@ class Network:
         self.n_layers_ = 5
 
 
-def _glorot(n_in, rs):
+def check_hidden(hidden):
+    """The architectures the device kernels hold: three hidden layers of at
+    most (100, 50, 20) units -- the reference's default
+    (nautilus/neural.py:79-81) and anything narrower.  The kernels' tiles are
+    those of the default; a narrower layer is the default with zero weights
+    for the missing units, which is exact for prediction AND for training: a
+    missing unit has pre-activation 0, ReLU derivative 0 and feeds zero
+    weights, so every gradient and every Adam moment of its weights stays 0
+    (emulator.pad_network).  Anything else -- other depths, wider layers --
+    raises ValueError (the reference passes any MLPRegressor option
+    through, neural.py:79-83)."""
+    try:
+        hidden = tuple(int(h) for h in np.atleast_1d(hidden))
+    except (TypeError, ValueError):
+        raise ValueError('hidden_layer_sizes=%r is not a sequence of '
+                         'integers' % (hidden,))
+    if len(hidden) != 3 or any(h < 1 or h > m for h, m in zip(hidden, HIDDEN)):
+        raise ValueError(
+            'nautilus_amd holds emulators with three hidden layers of at most '
+            '%r units on the device (the reference default and anything '
+            'narrower); hidden_layer_sizes=%r is not supported' %
+            (HIDDEN, hidden))
+    return hidden
+
+
+def pad_network(coefs, intercepts, n_dim):
+    """Weights of a (narrower) network in the device's default shapes: zero
+    rows / columns for the missing units."""
+    units = [n_dim, *HIDDEN, 1]
+    cs, bs = [], []
+    for k, (a, b) in enumerate(zip(units[:-1], units[1:])):
+        w = np.asarray(coefs[k], dtype=np.float64)
+        v = np.asarray(intercepts[k], dtype=np.float64)
+        if w.shape == (a, b):
+            cs.append(w)
+            bs.append(v)
+            continue
+        full = np.zeros((a, b))
+        full[:w.shape[0], :w.shape[1]] = w
+        fb = np.zeros(b)
+        fb[:v.shape[0]] = v
+        cs.append(full)
+        bs.append(fb)
+    return cs, bs
+
+
+def hidden_of(coefs):
+    return tuple(int(c.shape[1]) for c in coefs[:-1])
+
+
+def _glorot(n_in, rs, hidden=HIDDEN):
     """sklearn/_multilayer_perceptron.py:441-456."""
-    units = [n_in, *HIDDEN, 1]
+    units = [n_in, *hidden, 1]
     coefs, intercepts = [], []
     for fan_in, fan_out in zip(units[:-1], units[1:]):
         bound = np.sqrt(6.0 / (fan_in + fan_out))
@@ -54,6 +104,8 @@ def _weight_pointers(nets):
     ip = (_lib.c_double_p * (4 * e))()
     keep = []
     for i, (coefs, intercepts) in enumerate(nets):
+        coefs, intercepts = pad_network(coefs, intercepts,
+                                        np.shape(coefs[0])[0])
         for k in range(4):
             w = np.ascontiguousarray(coefs[k], dtype=np.float64)
             b = np.ascontiguousarray(intercepts[k], dtype=np.float64)
@@ -189,8 +241,8 @@ def _hparams_from_kwargs(kwargs):
     known = dict(learning_rate_init='lr', beta_1='beta1', beta_2='beta2',
                  epsilon='epsilon', batch_size='batch', max_iter='max_iter',
                  n_iter_no_change='n_iter_no_change', tol='tol')
-    fixed = dict(hidden_layer_sizes=HIDDEN, alpha=0, activation='relu',
-                 solver='adam', shuffle=True, early_stopping=False)
+    fixed = dict(alpha=0, activation='relu', solver='adam', shuffle=True,
+                 early_stopping=False)
     hp = {}
     for key, val in kwargs.items():
         if key == 'random_state':
@@ -198,16 +250,27 @@ def _hparams_from_kwargs(kwargs):
                           " neural network is ignored.", Warning, stacklevel=3)
         elif key in known:
             hp[known[key]] = val
+        elif key == 'hidden_layer_sizes':
+            hp['hidden'] = check_hidden(val)
         elif key in fixed:
-            if (tuple(val) if key == 'hidden_layer_sizes' else val) != \
-                    fixed[key]:
-                raise NotImplementedError(
-                    'nautilus_amd trains the reference default architecture '
-                    'only; %s=%r is not supported on the device' % (key, val))
+            if val != fixed[key]:
+                raise ValueError(
+                    'nautilus_amd trains ReLU networks with Adam and no '
+                    'weight decay on the device (the reference default); '
+                    '%s=%r is not supported' % (key, val))
         else:
-            raise NotImplementedError(
+            raise ValueError(
                 'MLPRegressor option %r is not supported on the device' % key)
     return hp
+
+
+def check_network_kwargs(kwargs):
+    """Raise ValueError for options the device trainer does not hold
+    (``Sampler.__init__`` calls this, so that a run does not fail at its
+    first ``add_bound``)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        _hparams_from_kwargs(dict(kwargs))
 
 
 class NeuralNetworkEmulator:
@@ -349,6 +412,7 @@ class _TrainJob:
         per ensemble."""
         self.members = members
         self.stream = stream
+        self.hidden = tuple((hparams or {}).get('hidden', HIDDEN))
         d = members[0]['xs'].shape[1]
         self.owner, states, self.perm_src = [], [], []
         xs, ys, nets0 = [], [], []
@@ -358,7 +422,7 @@ class _TrainJob:
                 init = m.get('init')
                 # (the Glorot draw always advances the stream, as in
                 # scikit-learn, also when the weights are then replaced)
-                drawn = _glorot(d, rs)
+                drawn = _glorot(d, rs, (hparams or {}).get('hidden', HIDDEN))
                 nets0.append(drawn if init is None else init[j])
                 self.owner.append(k)
                 states.append(rs)
@@ -464,6 +528,12 @@ class _TrainJob:
             for i in range(self.e):
                 n_iter = abs(int(self.status[i]))
                 coefs, intercepts = self.trainer.weights(i)
+                if self.hidden != HIDDEN:
+                    units = [coefs[0].shape[0], *self.hidden, 1]
+                    coefs = [np.ascontiguousarray(c[:a, :b]) for c, a, b in
+                             zip(coefs, units[:-1], units[1:])]
+                    intercepts = [np.ascontiguousarray(v[:b]) for v, b in
+                                  zip(intercepts, units[1:])]
                 net = Network(coefs, intercepts, n_iter,
                               self.trainer.loss_curve(i, n_iter))
                 # scikit-learn's sample counter (_multilayer_perceptron.py:728)
@@ -563,20 +633,22 @@ def _pack_network(net, n_dim):
     """[n_iter, final loss, coefs..., intercepts...] as one float64 row."""
     parts = [np.array([net.n_iter_, net.loss_curve_[-1]
                        if len(net.loss_curve_) else 0.0])]
-    parts += [np.ravel(c) for c in net.coefs_]
-    parts += [np.ravel(b) for b in net.intercepts_]
+    coefs, intercepts = pad_network(net.coefs_, net.intercepts_, n_dim)
+    parts += [np.ravel(c) for c in coefs]
+    parts += [np.ravel(b) for b in intercepts]
     return np.concatenate(parts)
 
 
-def _unpack_network(row, n_dim):
+def _unpack_network(row, n_dim, hidden=HIDDEN):
     units = [n_dim, *HIDDEN, 1]
+    real = [n_dim, *hidden, 1]
     pos = 2
     coefs, intercepts = [], []
-    for a, b in zip(units[:-1], units[1:]):
-        coefs.append(row[pos:pos + a * b].reshape(a, b).copy())
+    for a, b, ra, rb in zip(units[:-1], units[1:], real[:-1], real[1:]):
+        coefs.append(row[pos:pos + a * b].reshape(a, b)[:ra, :rb].copy())
         pos += a * b
-    for b in units[1:]:
-        intercepts.append(row[pos:pos + b].copy())
+    for b, rb in zip(units[1:], real[1:]):
+        intercepts.append(row[pos:pos + b][:rb].copy())
         pos += b
     return Network(coefs, intercepts, int(row[0]), [float(row[1])])
 
@@ -624,7 +696,9 @@ def train_ensembles_sharded(jobs, comm):
     for job in jobs:
         nets = []
         for _ in job['seeds']:
-            nets.append(_unpack_network(rows[g], n_dim))
+            nets.append(_unpack_network(
+                rows[g], n_dim,
+                tuple((job.get('hparams') or {}).get('hidden', HIDDEN))))
             g += 1
         out.append((nets, dict(n_iter=[n.n_iter_ for n in nets],
                                n_rows=job['xs'].shape[0])))

@@ -148,6 +148,11 @@ class Sampler:
         self.periodic = periodic
         self.n_networks = n_networks
         self.neural_network_kwargs = neural_network_kwargs
+        if n_networks > 0:
+            # ValueError here, not at the first add_bound, for MLPRegressor
+            # options the device trainer does not hold (emulator.check_hidden)
+            from .emulator import check_network_kwargs
+            check_network_kwargs(neural_network_kwargs)
         self.vectorized = vectorized
         self.pass_dict = pass_dict
 

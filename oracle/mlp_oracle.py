@@ -120,7 +120,7 @@ class Network:
 @threadpool_limits.wrap(limits=1)                       # neural.py:10
 def fit_network(x, y, random_state, max_iter=10000, n_iter_no_change=10,
                 tol=0.0, batch_size=200, lr=1e-2, permutations=None,
-                init=None):
+                init=None, hidden=HIDDEN):
     """``MLPRegressor(random_state=i, ...).fit(x, y)`` restated
     (sklearn/_multilayer_perceptron.py:620-760).
 
@@ -128,10 +128,11 @@ def fit_network(x, y, random_state, max_iter=10000, n_iter_no_change=10,
         replace the MT19937 shuffles (used to drive the HIP kernel and the
         oracle with the same minibatch order).
     init : optional (coefs, intercepts) replacing the Glorot draw.
+    hidden : ``hidden_layer_sizes`` (neural.py:79-83 passes it through).
     """
     n, d = x.shape
     y2 = y.reshape(-1, 1)
-    coefs, intercepts, rs = glorot_init(d, random_state)
+    coefs, intercepts, rs = glorot_init(d, random_state, hidden)
     if init is not None:
         coefs = [np.array(c, float) for c in init[0]]
         intercepts = [np.array(c, float) for c in init[1]]
@@ -180,6 +181,8 @@ class Emulator:
         for key, val in neural_network_kwargs.items():
             if key == 'learning_rate_init':
                 kw['lr'] = val
+            elif key == 'hidden_layer_sizes':
+                kw['hidden'] = tuple(val)
             elif key in kw:
                 kw[key] = val
             elif key != 'random_state':

@@ -418,6 +418,65 @@ def test_accept_routes_agree(dev):
     assert 0.0 <= b.dense_need <= 1.0
 
 
+def test_list_eval_against_the_oracle(dev):
+    """nb_list_eval (geometric stage + candidate lists + one batched emulator
+    launch) on a list of SEVEN nested NautilusBounds with emulators against
+    the oracle's ``contains`` of every bound: exclusion = any bound
+    (sampler.py:797-798), association = first bound of the list
+    (sampler.py:1213-1219) -- at once, through the slab path (small work
+    space) and through the group-slice path (two groups per slice)."""
+    from nautilus_amd import device
+    g = load_golden('nautilusbound_D4')
+    obs = []
+    for k in range(7):
+        ob = nautilus_from_golden(g)
+        for n_b in ob.neural_bounds:
+            # nested: the same bound with rising emulator thresholds
+            n_b.score_predict_min = n_b.score_predict_min + 0.03 * k
+        obs.append(ob)
+    devs = [upload(ob) for ob in obs]
+    x = devs[0].propose(5, 0, 60000)
+    xh = x.cpu().numpy()
+    inside = np.array([ob.contains(xh) for ob in obs])
+    # rows whose decision lies within rounding of an edge (fp64 sums are
+    # associated differently on the matrix cores)
+    edge = np.zeros(len(xh), dtype=bool)
+    for ob in obs:
+        for n_b in ob.neural_bounds:
+            y = n_b.outer_bound.transform(xh)
+            edge |= near_boundary(np.sum(y**2, axis=1), 1.0, 1e-12)
+            edge |= near_boundary(n_b.emulator.predict(y),
+                                  n_b.score_predict_min, 1e-9)
+    assert edge.mean() < 1e-3
+    # the list in sampler order and in reverse (the innermost bound first)
+    for order in (list(range(7)), list(range(6, -1, -1)), [3, 0, 6, 1]):
+        lst = device.DeviceBoundList([devs[i] for i in order])
+        want_any = inside[order].any(axis=0)
+        want_first = np.full(len(xh), -1)
+        for pos in range(len(order) - 1, -1, -1):
+            want_first[inside[order[pos]]] = pos
+        assert 0.01 < want_any.mean() < 0.99
+        assert len(np.unique(want_first)) >= min(4, len(order))
+
+        def check():
+            got_any = lst.contains_any(x).cpu().numpy()
+            got_first = lst.first_containing(x).cpu().numpy()
+            assert np.array_equal(got_any[~edge], want_any[~edge])
+            assert np.array_equal(got_first[~edge], want_first[~edge])
+        check()
+        old = device.WORK_BYTES
+        device.WORK_BYTES = 1 << 20
+        try:
+            check()
+        finally:
+            device.WORK_BYTES = old
+        os.environ['NB_LIST_SLICE_GROUPS'] = '2'
+        try:
+            check()
+        finally:
+            del os.environ['NB_LIST_SLICE_GROUPS']
+
+
 def test_list_eval_matches_the_one_kernel_form(dev):
     """nb_list_eval (candidate lists + one batched emulator launch; exclusion
     = any bound, association = first bound) against the one-kernel form that
@@ -925,6 +984,44 @@ def test_emulator_training_matches_oracle(dev):
             assert np.allclose(net.coefs_[k], ref.coefs[k], rtol=0, atol=1e-8)
             assert np.allclose(net.intercepts_[k], ref.intercepts[k], rtol=0,
                                atol=1e-8)
+
+
+@pytest.mark.parametrize('hidden', [(64, 32, 16), (100, 17, 3), (5, 50, 20)])
+def test_emulator_narrow_architectures(dev, hidden):
+    """``neural_network_kwargs=dict(hidden_layer_sizes=...)`` (neural.py:79-83
+    passes it to MLPRegressor): three hidden layers narrower than the default
+    train and predict in the default's tiles with zero weights for the
+    missing units -- against the oracle's fit of that architecture (same
+    Glorot draw for ITS shapes, same shuffles), a full fit to its stopping
+    epoch, and the prediction of the trained emulator."""
+    import torch
+    from nautilus_amd import emulator
+    from oracle import mlp_oracle as mo
+    g = load_golden('emulator_D5_E1')
+    x, y = g['x'], g['y']
+    kw = dict(hidden_layer_sizes=hidden, max_iter=40)
+    emu = emulator.NeuralNetworkEmulator.train(x, y, n_networks=2,
+                                               neural_network_kwargs=kw)
+    ref = mo.Emulator.train(x, y, n_networks=2, neural_network_kwargs=kw)
+    units = [5, *hidden, 1]
+    for net, rnet in zip(emu.neural_networks, ref.networks):
+        assert [c.shape for c in net.coefs_] == list(zip(units[:-1],
+                                                         units[1:]))
+        assert net.n_iter_ == rnet.n_iter
+        assert np.allclose(net.loss_curve_, rnet.loss_curve, rtol=1e-8, atol=0)
+        for k in range(4):
+            assert np.allclose(net.coefs_[k], rnet.coefs[k], rtol=0, atol=1e-7)
+            assert np.allclose(net.intercepts_[k], rnet.intercepts[k], rtol=0,
+                               atol=1e-7)
+    probe = np.random.default_rng(1).random((3000, 5))
+    want = ref.predict(probe)
+    assert np.allclose(emu.predict(probe), want, rtol=0, atol=1e-7)
+    # the trained weights through the oracle's forward pass: the device
+    # prediction itself to rounding
+    exact = mo.Emulator.from_weights(
+        emu.mean, emu.scale, [(n.coefs_, n.intercepts_)
+                              for n in emu.neural_networks]).predict(probe)
+    assert np.allclose(emu.predict(probe), exact, rtol=0, atol=1e-11)
 
 
 def test_emulator_training_ragged_batches(dev):

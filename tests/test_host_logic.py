@@ -115,11 +115,29 @@ def test_emulator_kwargs_translation():
                                             max_iter=50, tol=1e-4))
     assert hp == dict(lr=1e-3, max_iter=50, tol=1e-4)
     assert emulator._hparams_from_kwargs(
-        dict(hidden_layer_sizes=(100, 50, 20), alpha=0)) == {}
-    with pytest.raises(NotImplementedError):
-        emulator._hparams_from_kwargs(dict(hidden_layer_sizes=(10, 10)))
-    with pytest.raises(NotImplementedError):
+        dict(hidden_layer_sizes=(100, 50, 20), alpha=0)) == \
+        dict(hidden=(100, 50, 20))
+    # narrower three-layer networks ride in the default's tiles (zero padded)
+    assert emulator._hparams_from_kwargs(
+        dict(hidden_layer_sizes=[64, 32, 16])) == dict(hidden=(64, 32, 16))
+    for bad in ((10, 10), (128, 50, 20), (100, 50, 20, 5), (100, 50, 0)):
+        with pytest.raises(ValueError):
+            emulator._hparams_from_kwargs(dict(hidden_layer_sizes=bad))
+    with pytest.raises(ValueError):
         emulator._hparams_from_kwargs(dict(momentum=0.5))
+    with pytest.raises(ValueError):
+        emulator._hparams_from_kwargs(dict(activation='tanh'))
+    # the Glorot draw of a narrower network consumes the stream as
+    # scikit-learn does for that architecture; padding adds exact zeros
+    from oracle import mlp_oracle as mo
+    c1, i1 = emulator._glorot(7, np.random.RandomState(2), (64, 32, 16))
+    c2, i2, _ = mo.glorot_init(7, 2, (64, 32, 16))
+    for a, b in zip(c1 + i1, c2 + i2):
+        assert np.array_equal(a, b)
+    pc, pi = emulator.pad_network(c1, i1, 7)
+    assert [w.shape for w in pc] == [(7, 100), (100, 50), (50, 20), (20, 1)]
+    assert np.array_equal(pc[1][:64, :32], c1[1]) and pc[1][64:].max() == 0 \
+        and np.abs(pc[1][:, 32:]).max() == 0 and pi[2][16:].max() == 0
     with pytest.warns(Warning):
         emulator._hparams_from_kwargs(dict(random_state=1))
 
@@ -196,6 +214,16 @@ def test_sampler_argument_errors():
         Sampler(lambda x: x, dev_like, n_dim=2)          # host prior
     assert unit_prior.device is True
     assert isinstance(Prior(), Prior)
+    # emulator options the device trainer does not hold: at construction, not
+    # at the first add_bound (neural.py:79-83 passes them to MLPRegressor)
+    for kw in (dict(hidden_layer_sizes=(10, 10)), dict(solver='lbfgs'),
+               dict(hidden_layer_sizes=(200, 50, 20))):
+        with pytest.raises(ValueError):
+            Sampler(unit_prior, dev_like, n_dim=2, neural_network_kwargs=kw)
+    Sampler(unit_prior, dev_like, n_dim=2, n_networks=0,
+            neural_network_kwargs=dict(solver='lbfgs'))   # no emulators
+    Sampler(unit_prior, dev_like, n_dim=2,
+            neural_network_kwargs=dict(hidden_layer_sizes=(64, 32, 16)))
 
 
 def test_shell_batch_prefix_rule_is_negative_binomial():
