@@ -220,10 +220,7 @@ def test_sampler_argument_errors():
                dict(hidden_layer_sizes=(200, 50, 20))):
         with pytest.raises(ValueError):
             Sampler(unit_prior, dev_like, n_dim=2, neural_network_kwargs=kw)
-    Sampler(unit_prior, dev_like, n_dim=2, n_networks=0,
-            neural_network_kwargs=dict(solver='lbfgs'))   # no emulators
-    Sampler(unit_prior, dev_like, n_dim=2,
-            neural_network_kwargs=dict(hidden_layer_sizes=(64, 32, 16)))
+    # (accepted options: tests/test_sampler_behaviour_gpu.py)
 
 
 def test_shell_batch_prefix_rule_is_negative_binomial():

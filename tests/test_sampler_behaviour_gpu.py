@@ -197,3 +197,24 @@ def test_blob_conventions(case, vectorized, discard):
     else:
         assert np.all(pts[:, 0].astype(f32) == blobs[:, 0])
         assert np.all(pts[:, 1].astype(f32) == blobs[:, 1])
+
+
+def test_run_with_a_narrower_emulator_architecture():
+    """``neural_network_kwargs=dict(hidden_layer_sizes=(64, 32, 16))`` (the
+    reference passes it to MLPRegressor, neural.py:79-83): the run's emulators
+    have that architecture and the evidence of the README Gaussian comes out
+    as with the default one."""
+    from nautilus_amd import GaussianLikelihood, Sampler, unit_prior
+    like = GaussianLikelihood([0.4, 0.5, 0.6], 0.01 * np.eye(3))
+    s = Sampler(unit_prior, like, n_dim=3, n_live=500, seed=1,
+                neural_network_kwargs=dict(hidden_layer_sizes=(64, 32, 16)))
+    assert s.run(n_eff=2000, discard_exploration=True) is True
+    nets = [net for b in s.bounds[1:] for nb in b.neural_bounds
+            if nb.emulator is not None for net in nb.emulator.neural_networks]
+    assert len(nets) >= 4
+    assert all([c.shape for c in net.coefs_] ==
+               [(3, 64), (64, 32), (32, 16), (16, 1)] for net in nets)
+    assert abs(s.log_z - (-6.4e-5)) < 0.05
+    # no emulators: the options are not looked at
+    Sampler(unit_prior, like, n_dim=3, n_networks=0,
+            neural_network_kwargs=dict(solver='lbfgs'))
