@@ -221,7 +221,18 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+ERR_ARG, ERR_HIP, ERR_UNSUPPORTED = 1, 2, 3     # nb_common.h
+
+
+class NativeError(RuntimeError):
+    """A nonzero status of the C ABI; ``code`` is the status."""
+
+    def __init__(self, code, message):
+        super().__init__('nautilus_hip: ' + message)
+        self.code = code
+
+
 def check(status):
     if status != 0:
-        raise RuntimeError('nautilus_hip: ' +
-                           load().nb_last_error().decode('utf-8', 'replace'))
+        raise NativeError(status, load().nb_last_error().decode(
+            'utf-8', 'replace'))

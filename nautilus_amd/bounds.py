@@ -114,6 +114,9 @@ class _Fifo:
         self.tail += k
 
     def pop(self, n):
+        """The next ``n`` rows as a VIEW of the queue's buffer: valid until
+        the next ``push`` (a refill may slide the queue to the front or
+        replace the buffer) -- copy what has to live longer."""
         out = self.data[self.head:self.head + n]
         self.head += n
         return out
@@ -433,8 +436,8 @@ class _RejectionSampler(_DeviceBoundBase):
         raise NotImplementedError
 
     def _launch(self, need):
-        """One refill launch for ``need`` more points: (rows, counts on the
-        device, n_draw)."""
+        """Number of proposals of one refill launch for ``need`` more
+        points."""
         acc = max(self._acceptance(), 1e-7)
         n_draw = int(min(MAX_DRAW, max(MIN_DRAW, 1.2 * need / acc)))
         n_draw = (n_draw + 63) // 64 * 64
@@ -450,7 +453,12 @@ class _RejectionSampler(_DeviceBoundBase):
                                 inverse=True)
         self._queue().push(rows)
 
-    def _fill(self, n_points):
+    def _fill(self, n_points, guard=False):
+        """Refill the queue to ``n_points``.  ``guard`` (the pre-fill of a
+        new bound, Sampler.add_bound): give up with BarrenBound once
+        GUARD_LAUNCHES full launches have accepted next to nothing -- there
+        the caller drops the bound; inside a run the reference's loop is kept
+        (only a bound that accepts NOTHING over MAX_BARREN launches ends it)."""
         q = self._queue()
         barren = 0
         full_launches = full_accepted = 0
@@ -473,7 +481,8 @@ class _RejectionSampler(_DeviceBoundBase):
             if n_draw == MAX_DRAW:
                 full_launches += 1
                 full_accepted += int(c[1])
-                if full_launches >= GUARD_LAUNCHES and full_accepted < \
+                if guard and full_launches >= GUARD_LAUNCHES and \
+                        full_accepted < \
                         GUARD_ACCEPTANCE * full_launches * MAX_DRAW:
                     raise BarrenBound(
                         'the bound accepted %d of %d proposals: its emulators '
@@ -927,12 +936,13 @@ class NautilusBound(_RejectionSampler):
         self.n_sample += n_outer                   # nautilus.py:221-222
         self.n_reject += n_outer - n_final
 
-    def sample(self, n_points=100, return_points=True, pool=None):
+    def sample(self, n_points=100, return_points=True, pool=None,
+               guard=False):
         """nautilus.py:193-244.  ``pool`` is accepted for compatibility: the
         proposals of one launch are already spread over the whole GPU (and
-        over all GPUs of a ``DevicePool``)."""
+        over all GPUs of a ``DevicePool``).  ``guard``: see ``_fill``."""
         if not return_points:
-            self._fill(n_points)
+            self._fill(n_points, guard=guard)
             return None
         return self.sample_device(n_points).cpu().numpy()
 

@@ -23,11 +23,6 @@ int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
                         unsigned char* out_u8, double* out_f64,
                         unsigned long long seed, unsigned long long offset,
                         hipStream_t stream);
-int nb_launch_geom(int dt, const double* const* blobs_dev, int nb, int mode,
-                   int n_blocks, const double* x, long long n_rows,
-                   const long long* idx, long long n, int* pos,
-                   unsigned char* st, unsigned long long seed,
-                   unsigned long long offset, hipStream_t stream);
 int nb_launch_cand(int dt, const double* const* blobs_dev,
                    const int* group_base_dev, int nb, int n_groups, int b_off,
                    int g_off, int accumulate, int mode, const double* x,
@@ -739,8 +734,8 @@ int nb_list_eval(const nb_boundlist* l, int32_t mode, const double* x,
   if (l->n == 0) {
     NB_HIP_CHECK(hipMemsetAsync(st, 0, (size_t)n, as_stream(stream)));
     if (first != nullptr)
-      NB_HIP_CHECK(hipMemsetAsync(first, 0x7f, (size_t)n * 4,
-                                  as_stream(stream)));
+      NB_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7fffffff,
+                                     (size_t)n, as_stream(stream)));
     return NB_OK;
   }
   if (work_bytes < nb_list_eval_work_bytes(l, n)) {

@@ -1853,8 +1853,12 @@ int nb_trainer_create_fleet(int32_t n_dim, int32_t n_networks,
   static_assert(SYNC_INTS * sizeof(int) <= OFF_NETS &&
                 MAX_RESIDENT * sizeof(NetState) <= OFF_JOBS - OFF_NETS,
                 "trainer block layout");
+  // (with the NB_TRAIN_SYNC_SHIFT experiment the counters sit at OFF_SYNC2,
+  // inside the schedule's slot: the schedule then has to end in front of them)
+  const size_t sched_end =
+      getenv("NB_TRAIN_SYNC_SHIFT") != nullptr ? OFF_SYNC2 : OFF_POOL;
   if (jobs.size() * sizeof(int) > OFF_SCHED - OFF_JOBS ||
-      sched.size() * sizeof(int) > OFF_POOL - OFF_SCHED) {
+      sched.size() * sizeof(int) > sched_end - OFF_SCHED) {
     nb_set_error("trainer: job lists exceed their slots");
     delete t;
     return NB_ERR_ARG;

@@ -306,7 +306,11 @@ class DeviceBoundList:
         while slab > 4096 and self._lib.nb_list_eval_work_bytes(
                 self._h, slab) > WORK_BYTES:
             slab = (slab + 1) // 2
-        need = self._lib.nb_list_eval_work_bytes(self._h, slab)
+        # (the work space is not monotone in the row count: the last, shorter
+        # slab may need more than a full one)
+        need = max(self._lib.nb_list_eval_work_bytes(self._h, slab),
+                   self._lib.nb_list_eval_work_bytes(
+                       self._h, n - (n - 1) // slab * slab))
         work = _buffer('staged_work', (need,), torch.uint8, True)
         for lo in range(0, n, slab):
             k = min(slab, n - lo)

@@ -609,7 +609,8 @@ def train_ensembles(jobs):
             # placement probe fails on this GPU / partition mode, or other
             # live trainers hold the XCDs -- every ensemble gets a trainer of
             # its own, which can fall back to two launches per step.
-            if len(keys) == 1 or 'different training sets' not in str(err):
+            if len(keys) == 1 or getattr(err, 'code', None) != \
+                    _lib.ERR_UNSUPPORTED:
                 raise
             for k in keys:
                 finish(_TrainJob([jobs[k]], jobs[k].get('hparams'),

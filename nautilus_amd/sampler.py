@@ -936,7 +936,8 @@ class Sampler:
                         pass
                     elif self.comm is None:
                         try:
-                            bound.sample(1000, return_points=False)
+                            bound.sample(1000, return_points=False,
+                                         guard=True)
                         except BarrenBound:
                             # measured: the pre-fill accepted next to nothing
                             barren = True
@@ -947,7 +948,7 @@ class Sampler:
                         before = self._counters(self._rank_keyed(bound))
                         try:
                             bound.sample(-(-1000 // self.comm.world),
-                                         return_points=False)
+                                         return_points=False, guard=True)
                         except BarrenBound:
                             barren = True
                         self._sum_counters(bound, before)
