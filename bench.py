@@ -518,9 +518,15 @@ def main():
     # (separate FETCH_SIZE / WRITE_SIZE passes, only the timed region is
     # profiled) and reports the measured value; otherwise null, with the
     # latest committed measurement under profiles/ named for reference.
-    traffic, traffic_src = None, ('not measured in this run (use '
-                                  '--pmc-traffic); committed measurements: '
-                                  'profiles/r03/bench_pmc_traffic.json')
+    import glob
+    committed = sorted(glob.glob(os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*',
+        'bench_pmc_traffic.json')))
+    traffic, traffic_src = None, (
+        'not measured in this run (use --pmc-traffic); newest committed '
+        'measurement: %s' % (os.path.relpath(
+            committed[-1], os.path.dirname(os.path.abspath(__file__)))
+            if committed else 'none'))
     if args.pmc_traffic and rank == 0 and world == 1:
         got = pmc_traffic(sys.argv[1:])
         if got is not None:

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <csignal>
 #include <cstring>
+#include <ctime>
 #include <execinfo.h>
 #include <limits>
 #include <unistd.h>
@@ -779,16 +780,67 @@ int nb_accept_staged(const nb_bound* b, uint64_t seed, uint64_t offset,
   }
   int *dense = nullptr, *totals = nullptr;
   long long n_pad = 0;
+  // NB_STAGE_TIMING=1 (debugging aid): HIP events around the two stages; the
+  // times of a call are printed by the NEXT call, so that nothing waits for
+  // the device inside the measured sequence
+  static const bool timing = getenv("NB_STAGE_TIMING") != nullptr;
+  static hipEvent_t ev[3][3];
+  static double host_us[3][4];
+  static int ev_calls = 0;
+  hipEvent_t* e = nullptr;
+  double* hu = nullptr;
+  auto now_us = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  };
+  if (timing) {
+    if (ev_calls == 0)
+      for (int i = 0; i < 9; ++i) (void)hipEventCreate(&ev[i / 3][i % 3]);
+    if (ev_calls > 1) {
+      // call k - 2 and the gap to call k - 1 (both finished or in flight
+      // behind nothing this call waits for but their own events)
+      hipEvent_t* p = ev[(ev_calls - 2) % 3];
+      hipEvent_t* q = ev[(ev_calls - 1) % 3];
+      const double* h = host_us[(ev_calls - 2) % 3];
+      const double* hq = host_us[(ev_calls - 1) % 3];
+      float t_geo = 0.f, t_emu = 0.f, t_gap = 0.f;
+      (void)hipEventSynchronize(q[0]);
+      (void)hipEventElapsedTime(&t_geo, p[0], p[1]);
+      (void)hipEventElapsedTime(&t_emu, p[1], p[2]);
+      (void)hipEventElapsedTime(&t_gap, p[2], q[0]);
+      fprintf(stderr, "[stage] call %d: device: candidates + compaction %.3f "
+              "ms, batched scores %.3f ms, then idle until the next call's "
+              "first event %.3f ms; host: stage-one launches %.0f us, "
+              "stage-two launch %.0f us, until the next call %.0f us\n",
+              ev_calls - 2, t_geo, t_emu, t_gap, h[1] - h[0], h[2] - h[1],
+              hq[0] - h[2]);
+    }
+    e = ev[ev_calls % 3];
+    hu = host_us[ev_calls % 3];
+    ++ev_calls;
+    hu[0] = now_us();
+    (void)hipEventRecord(e[0], as_stream(stream));
+  }
   int rc = nb_launch_cand(b->dt, b->self_list_dev, b->group_base_dev, 1,
                           b->n_groups, 0, 0, 0, 2, x, n, flags, nullptr,
                           (int*)work, seed, offset, &dense, &totals, &n_pad,
                           as_stream(stream));
   if (rc != NB_OK) return rc;
+  if (e != nullptr) {
+    (void)hipEventRecord(e[1], as_stream(stream));
+    hu[1] = now_us();
+  }
   if (totals_offset != nullptr)
     *totals_offset = (int64_t)((char*)totals - (char*)work);
-  return nb_stage_two(b->blob_dev, b->n_dim, 0, x, b->groups_dev, b->n_groups,
-                      totals, dense, n_pad, n, 2, flags, nullptr,
-                      as_stream(stream));
+  rc = nb_stage_two(b->blob_dev, b->n_dim, 0, x, b->groups_dev, b->n_groups,
+                    totals, dense, n_pad, n, 2, flags, nullptr,
+                    as_stream(stream));
+  if (e != nullptr) {
+    (void)hipEventRecord(e[2], as_stream(stream));
+    hu[2] = now_us();
+  }
+  return rc;
 }
 
 int nb_neural_score_rows(const nb_bound* b, int32_t m, int32_t recentre,

@@ -24,7 +24,9 @@ namespace {
 constexpr int GM_THREADS = 512;
 constexpr int GM_WAVES = GM_THREADS / 64;
 constexpr unsigned GM_TAG = 3u;           // Philox tag of the seeding draws
-constexpr int GM_SWEEP_EPT = 17;          // ceil(128 * 129 / 2 / 512)
+// both components' operand tiles side by side in LDS (2 x DT (DT + 1) / 2
+// tiles of 2 KB): up to DT = 7 (112 KB)
+__host__ __device__ constexpr bool gm_both(int dt) { return dt <= 7; }
 
 struct GmmArgs {
   const double* x;
@@ -60,6 +62,8 @@ nb_gmm_kernel(GmmArgs a) {
   constexpr int NT = DT * (DT + 1) / 2;
   constexpr int GW = (DT + 1) / 2;          // waves per moment sub-group
   constexpr int SG = GM_WAVES / GW;
+  constexpr bool BOTH = gm_both(DT);        // two sets of operand tiles in LDS
+  constexpr int NKT = BOTH ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double red[GM_WAVES], sh_val[4];
   __shared__ int sh_idx[2], sh_bad;
@@ -71,10 +75,11 @@ nb_gmm_kernel(GmmArgs a) {
   const double* __restrict__ x = a.x;
   const int n = a.n, d = a.d, m = d + 1;
   const int mm = (m * m + 1) & ~1;
-  double* T = lds;                         // NT tiles: Sigma_k -> -Sigma_k^-1 -> T
-  double* colk = T + NT * NB_TILE;         // [DP] pivot column of the sweep
-  double* mus = colk + DP;                 // [DP] mu_k in slot order
-  double* cen = mus + DP;                  // [2][DP] k-means centres
+  double* T = lds;                         // NKT x NT tiles: Sigma_k -> -Sigma_k^-1 -> T
+  double* colk = T + NKT * NT * NB_TILE;   // [NKT][DP] pivot columns of the sweeps
+  double* mus = colk + NKT * DP;           // [NKT][DP] mu_k in slot order
+  double* cen = mus + NKT * DP;            // [2][DP] k-means centres
+  unsigned short* swt = (unsigned short*)(cen + 2 * DP);   // [d (d + 1) / 2]
   double* cpart = T;                       // [GM_WAVES][2][DP] (seeding only)
   const double inf = __builtin_huge_val();
 
@@ -108,7 +113,9 @@ nb_gmm_kernel(GmmArgs a) {
   auto moments = [&](const volatile double* w) {
     const int sg = wave / GW, wv = wave - sg * GW;
     if (sg < SG)
-      sy_moments<DT>(x, w, d, 0, n, sg, SG, wv, lane,
+      // (a shorter ring than the stand-alone moment kernel's: this kernel
+      // keeps more alive around it)
+      sy_moments<DT, (DT <= 2 ? 8 : (DT <= 4 ? 4 : 2))>(x, w, d, 0, n, sg, SG, wv, lane,
                      part + (size_t)sg * NT * NB_TILE);
     __threadfence_block();
     __syncthreads();
@@ -287,25 +294,18 @@ nb_gmm_kernel(GmmArgs a) {
   __syncthreads();
   GM_STAMP(1);
 
-  // the entries (r >= c) of the lower triangle this thread owns in the sweeps
-  int sw_r[GM_SWEEP_EPT], sw_c[GM_SWEEP_EPT], sw_p[GM_SWEEP_EPT];
-  {
-    const int n_low = d * (d + 1) / 2;
-#pragma unroll
-    for (int q = 0; q < GM_SWEEP_EPT; ++q) {
-      const int e = tid + q * GM_THREADS;
-      int r = -1, c = 0;
-      if (e < n_low) {
-        r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-        while (r * (r + 1) / 2 > e) --r;
-        while ((r + 1) * (r + 2) / 2 <= e) ++r;
-        c = e - r * (r + 1) / 2;
-      }
-      sw_r[q] = r;
-      sw_c[q] = c;
-      sw_p[q] = r >= 0 ? sy_pos(r, c) : 0;
-    }
+  // the entries (r >= c) of the lower triangle, packed (r << 8 | c), in LDS:
+  // thread t owns the entries t, t + 512, ... of every sweep (a table in
+  // registers -- 17 slots of three ints for n_dim 128 -- was live across the
+  // whole EM loop and evaluated in full at every pivot whatever n_dim)
+  const int n_low = d * (d + 1) / 2;
+  for (int e = tid; e < n_low; e += GM_THREADS) {
+    int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > e) --r;
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    swt[e] = (unsigned short)((r << 8) | (e - r * (r + 1) / 2));
   }
+  __syncthreads();
 
   // ---- EM ------------------------------------------------------------------
   const double eps10 = 10.0 * 2.220446049250313e-16;
@@ -315,66 +315,94 @@ nb_gmm_kernel(GmmArgs a) {
   bool failed = sh_bad != 0;
   const int ks_max = 4 * DT;
   // weighted log probabilities of both components for all points with the
-  // current parameters (mixture/_base.py:_estimate_weighted_log_prob)
+  // current parameters (mixture/_base.py:_estimate_weighted_log_prob).  Both
+  // components go through the pivots TOGETHER where two sets of operand
+  // tiles fit the LDS (BOTH: n_dim <= 111): one pair of barriers per pivot
+  // for both sweeps, and the quadratic forms of both read every point once.
+  constexpr int NK = BOTH ? 2 : 1;
   auto log_prob = [&]() {
-    for (int k = 0; k < 2; ++k) {
-      const volatile double* cov = (volatile double*)o_cov + k * d * d;
-      const volatile double* mean = (volatile double*)o_mean + k * d;
-      for (int e = tid; e < NT * NB_TILE; e += GM_THREADS) T[e] = 0.0;
+    for (int k0 = 0; k0 < 2; k0 += NK) {
+      for (int e = tid; e < NK * NT * NB_TILE; e += GM_THREADS) T[e] = 0.0;
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < GM_SWEEP_EPT; ++q)
-        if (sw_r[q] >= 0) T[sw_p[q]] = cov[sw_r[q] * d + sw_c[q]];
-      for (int f = tid; f < DP; f += GM_THREADS)
-        mus[mv_slot(f)] = (f < d) ? mean[f] : 0.0;
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = k0 + kk;
+        const volatile double* cov = (volatile double*)o_cov + k * d * d;
+        const volatile double* mean = (volatile double*)o_mean + k * d;
+        double* Tk = T + kk * NT * NB_TILE;
+        for (int e = tid; e < n_low; e += GM_THREADS) {
+          const int r = swt[e] >> 8, c = swt[e] & 255;
+          Tk[sy_pos(r, c)] = cov[r * d + c];
+        }
+        for (int f = tid; f < DP; f += GM_THREADS)
+          mus[kk * DP + mv_slot(f)] = (f < d) ? mean[f] : 0.0;
+      }
       __syncthreads();
       GM_STAMP(3);
       // symmetric sweep operator over all pivots: T <- -Sigma^-1, the pivots
       // are those of the L D L^T factorisation (log det = sum log d_p)
-      double logdet = 0.0;
-      for (int p = 0; p < d; ++p) {
-        for (int i = tid; i < d; i += GM_THREADS)
-          colk[i] = T[i >= p ? sy_pos(i, p) : sy_pos(p, i)];
-        __syncthreads();
-        const double dp = colk[p];
-        if (!(dp > 0.0)) {                   // not positive definite
-          if (tid == 0) sh_bad = 1;
-        }
-        const double inv_d = 1.0 / dp;
-        logdet += log(dp);
+      double logdet[NK];
 #pragma unroll
-        for (int q = 0; q < GM_SWEEP_EPT; ++q) {
-          const int r = sw_r[q], c = sw_c[q];
-          if (r < 0) continue;
-          double v;
-          if (r == p && c == p) v = -inv_d;
-          else if (r == p) v = colk[c] * inv_d;
-          else if (c == p) v = colk[r] * inv_d;
-          else v = T[sw_p[q]] - colk[r] * colk[c] * inv_d;
-          T[sw_p[q]] = v;
+      for (int kk = 0; kk < NK; ++kk) logdet[kk] = 0.0;
+      for (int p = 0; p < d; ++p) {
+        for (int i = tid; i < NK * d; i += GM_THREADS) {
+          const int kk = i >= d ? 1 : 0, ii = i - kk * d;
+          colk[kk * DP + ii] = T[kk * NT * NB_TILE +
+                                 (ii >= p ? sy_pos(ii, p) : sy_pos(p, ii))];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          double* Tk = T + kk * NT * NB_TILE;
+          const double* ck = colk + kk * DP;
+          const double dp = ck[p];
+          if (!(dp > 0.0)) {                   // not positive definite
+            if (tid == 0) sh_bad = 1;
+          }
+          const double inv_d = 1.0 / dp;
+          logdet[kk] += log(dp);
+          for (int e = tid; e < n_low; e += GM_THREADS) {
+            const int r = swt[e] >> 8, c = swt[e] & 255;
+            const int at = sy_pos(r, c);
+            double v;
+            if (r == p && c == p) v = -inv_d;
+            else if (r == p) v = ck[c] * inv_d;
+            else if (c == p) v = ck[r] * inv_d;
+            else v = Tk[at] - ck[r] * ck[c] * inv_d;
+            Tk[at] = v;
+          }
         }
         __syncthreads();
       }
       GM_STAMP(4);
       // -> T form: -(...) and doubled off-diagonal entries
 #pragma unroll
-      for (int q = 0; q < GM_SWEEP_EPT; ++q)
-        if (sw_r[q] >= 0)
-          T[sw_p[q]] *= (sw_r[q] == sw_c[q]) ? -1.0 : -2.0;
+      for (int kk = 0; kk < NK; ++kk)
+        for (int e = tid; e < n_low; e += GM_THREADS) {
+          const int r = swt[e] >> 8, c = swt[e] & 255;
+          T[kk * NT * NB_TILE + sy_pos(r, c)] *= (r == c) ? -1.0 : -2.0;
+        }
       __syncthreads();
-      const double konst = log(k == 0 ? pi0 : pi1) -
-                           0.5 * (d * 1.8378770664093453 + logdet);
-      volatile double* lp = k == 0 ? lp0 : lp1;
+      double konst[NK];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk)
+        konst[kk] = log(k0 + kk == 0 ? pi0 : pi1) -
+                    0.5 * (d * 1.8378770664093453 + logdet[kk]);
       for (int tile = wave; tile * 16 < n; tile += GM_WAVES) {
         long long pt[1] = {(long long)tile * 16 + lj};
         bool valid[1] = {pt[0] < n};
         double xin[1][4 * DT];
         load_points<DT, 1>((const nb_gd*)x, pt, valid, d, (long long)n, lane, xin);
 #pragma unroll
-        for (int ks = 0; ks < ks_max; ++ks)
-          xin[0][ks] = valid[0] ? xin[0][ks] - mus[4 * ks + lg] : 0.0;
-        const double g = sy_quadform<DT>(T, xin[0], d, lane);
-        if (valid[0] && lg == 0) lp[pt[0]] = konst - 0.5 * g;
+        for (int kk = 0; kk < NK; ++kk) {
+          double dx[4 * DT];
+#pragma unroll
+          for (int ks = 0; ks < ks_max; ++ks)
+            dx[ks] = valid[0] ? xin[0][ks] - mus[kk * DP + 4 * ks + lg] : 0.0;
+          const double g = sy_quadform<DT>(T + kk * NT * NB_TILE, dx, d, lane);
+          volatile double* lp = (k0 + kk) == 0 ? lp0 : lp1;
+          if (valid[0] && lg == 0) lp[pt[0]] = konst[kk] - 0.5 * g;
+        }
       }
       __threadfence_block();
       __syncthreads();
@@ -461,9 +489,12 @@ nb_gmm_kernel(GmmArgs a) {
 
 inline int gm_dt(int d) { return (d + 1 + 15) / 16; }
 inline size_t gm_lds_doubles(int dt) {
-  const size_t tiles = (size_t)dt * (dt + 1) / 2 * NB_TILE;
+  const size_t nk = gm_both(dt) ? 2 : 1;
+  const size_t tiles = nk * dt * (dt + 1) / 2 * NB_TILE;
   const size_t seed = (size_t)GM_WAVES * 2 * 16 * dt;      // cpart aliases T
-  return (tiles > seed ? tiles : seed) + 4 * 16 * dt;
+  // ... pivot columns, means, k-means centres, table of the triangle's entries
+  return (tiles > seed ? tiles : seed) + (2 * nk + 2) * 16 * dt +
+         ((size_t)16 * dt * (16 * dt + 1) / 2 + 3) / 4;
 }
 
 template <int DT>

@@ -62,7 +62,7 @@ __device__ __forceinline__ double sy_quadform(const double* T,
 // the accumulator layout, written to out[NT][256].  Wave `w` of a sub-group
 // of (DT + 1) / 2 wavefronts owns the tile rows w and DT-1-w (balanced
 // triangle).
-template <int DT, typename WPtr>
+template <int DT, int PF_ = 0, typename WPtr>
 __device__ __forceinline__ void sy_moments(const double* __restrict__ x,
                                            WPtr wgt, int d, int p0, int p1,
                                            int sg, int nsg, int w, int lane,
@@ -76,36 +76,65 @@ __device__ __forceinline__ void sy_moments(const double* __restrict__ x,
     acc_lo[j] = nb_d4{0.0, 0.0, 0.0, 0.0};
     acc_hi[j] = nb_d4{0.0, 0.0, 0.0, 0.0};
   }
-  for (int s = p0 + 4 * sg; s < p1; s += 4 * nsg) {
+  // The rows of PF steps are in flight ahead of the MFMAs of a step (one
+  // step = 4 points = DT + 1 MFMAs per wavefront, ~0.15 us; a load from L2 /
+  // HBM takes 1-2 us: without the ring every step paid that latency -- 160 us
+  // per call for 2000 points at n_dim 50, against ~20 us of matrix-core
+  // work).  Loads are unconditional (clamped addresses) and masked by
+  // multiplication, so that nothing branches around them; steps past the end
+  // contribute exact zeros, the order of the sums is that of the plain loop.
+  constexpr int PF =
+      PF_ > 0 ? PF_ : (DT <= 4 ? 8 : (DT <= 6 ? 5 : (DT <= 7 ? 3 : 2)));
+  const int step = 4 * nsg;
+  // per-lane masks of the feature columns (1 for a feature, the constant 1 in
+  // column d)
+  double m_feat[DT], m_one[DT];
+  int f_at[DT];
+#pragma unroll
+  for (int ft = 0; ft < DT; ++ft) {
+    const int f = 16 * ft + fi;
+    m_feat[ft] = f < d ? 1.0 : 0.0;
+    m_one[ft] = f == d ? 1.0 : 0.0;
+    f_at[ft] = f < d ? f : d - 1;
+  }
+  double rb[PF][DT], rw[PF];
+  auto fetch = [&](int s, double (&b)[DT], double& wp)
+      __attribute__((always_inline)) {
     const int p = s + kp;
-    const bool on = p < p1;
-    const double wp = on ? (wgt != nullptr ? wgt[p] : 1.0) : 0.0;
-    double b[DT];
+    const int pc = p < p1 ? p : (p1 > 0 ? p1 - 1 : 0);
+    const double on = p < p1 ? 1.0 : 0.0;
+    const double* row = x + (size_t)pc * d;
 #pragma unroll
-    for (int ft = 0; ft < DT; ++ft) {
-      const int f = 16 * ft + fi;
-      double v = 0.0;
-      if (on && f < d) v = x[(size_t)p * d + f];
-      else if (on && f == d) v = 1.0;
-      b[ft] = v;
-    }
-    double a_lo, a_hi;
-    {
-      const int f = 16 * row_lo + fi;
-      double v = 0.0;
-      if (on && f < d) v = x[(size_t)p * d + f];
-      else if (on && f == d) v = 1.0;
-      a_lo = v * wp;
-      const int f2 = 16 * row_hi + fi;
-      v = 0.0;
-      if (on && f2 < d) v = x[(size_t)p * d + f2];
-      else if (on && f2 == d) v = 1.0;
-      a_hi = v * wp;
-    }
+    for (int ft = 0; ft < DT; ++ft) b[ft] = row[f_at[ft]];
+    wp = wgt != nullptr ? wgt[pc] : 1.0;
+    // (masks applied where the values are used)
+    wp *= on;
+  };
+  const int s0 = p0 + 4 * sg;
 #pragma unroll
-    for (int jt = 0; jt < DT; ++jt) {
-      if (jt <= row_lo) acc_lo[jt] = MFMA(a_lo, b[jt], acc_lo[jt]);
-      if (two && jt <= row_hi) acc_hi[jt] = MFMA(a_hi, b[jt], acc_hi[jt]);
+  for (int j = 0; j < PF; ++j) fetch(s0 + j * step, rb[j], rw[j]);
+  for (int s = s0; s < p1; s += PF * step) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      double b[DT];
+      const double on = (s + j * step + kp) < p1 ? 1.0 : 0.0;
+#pragma unroll
+      for (int ft = 0; ft < DT; ++ft)
+        b[ft] = (rb[j][ft] * m_feat[ft] + m_one[ft]) * on;
+      const double wp = rw[j];
+      // rows of the A operand: the same columns, weighted
+      double a_lo = 0.0, a_hi = 0.0;
+#pragma unroll
+      for (int ft = 0; ft < DT; ++ft) {
+        if (ft == row_lo) a_lo = b[ft] * wp;
+        if (ft == row_hi) a_hi = b[ft] * wp;
+      }
+      fetch(s + (j + PF) * step, rb[j], rw[j]);
+#pragma unroll
+      for (int jt = 0; jt < DT; ++jt) {
+        if (jt <= row_lo) acc_lo[jt] = MFMA(a_lo, b[jt], acc_lo[jt]);
+        if (two && jt <= row_hi) acc_hi[jt] = MFMA(a_hi, b[jt], acc_hi[jt]);
+      }
     }
   }
 #pragma unroll

@@ -189,7 +189,7 @@ def test_C5_funnel_real_size():
     """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
     the device MVEE / mixture fit at 100 dimensions -- 60 s of the run and
     the invariants of a run in progress.  The run itself does not end inside
-    any budget this project has (DESIGN.md section 8: the exploration front
+    any budget this project has (DESIGN.md appendix A: the exploration front
     has to walk down the funnel to x_0 ~ 0.27, ~830 bounds at the measured
     8.3 bounds per dimension, with training sets beyond 10^6 rows from bound
     50 on; a GPU lease lasts one hour and a checkpoint of ~10 GB cannot

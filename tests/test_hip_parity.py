@@ -456,7 +456,8 @@ def test_list_eval_against_the_oracle(dev):
         for pos in range(len(order) - 1, -1, -1):
             want_first[inside[order[pos]]] = pos
         assert 0.01 < want_any.mean() < 0.99
-        assert len(np.unique(want_first)) >= min(4, len(order))
+        if order[0] != 0:      # (behind the outermost bound every row is 0)
+            assert len(np.unique(want_first)) >= 3
 
         def check():
             got_any = lst.contains_any(x).cpu().numpy()
