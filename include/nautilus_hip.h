@@ -436,13 +436,16 @@ int nb_neural_score_rows(const nb_bound* bound, int32_t m, int32_t recentre,
  * GaussianMixture(n_components=2, n_init=n_init, covariance_type='full')
  * restated on the device -- k-means++ / Lloyd initialisation, EM until the
  * mean log-likelihood changes by less than tol (scikit-learn defaults: tol
- * 1e-3, reg_covar 1e-6, max_iter 100).  One workgroup per restart.
+ * 1e-3, reg_covar 1e-6, max_iter 100).  All restarts run concurrently, each
+ * on up to eight workgroups that share its rows.
  * out_dev: n_init records of nb_gmm_out_doubles(n_dim) doubles
  *   [lower_bound, n_iter, converged, failed, weight0, weight1,
  *    mean0[D], mean1[D], cov0[D*D], cov1[D*D]]
  * (the caller keeps the record with the largest lower bound, as
- * mixture/_base.py:fit_predict does).  scratch_dev: n_init *
- * nb_gmm_scratch_doubles(n, n_dim) doubles.  init_labels_dev (optional,
+ * mixture/_base.py:fit_predict does).  scratch_dev:
+ * nb_gmm_work_doubles(n, n_dim, n_init) doubles; restart r works in the
+ * nb_gmm_scratch_doubles(n, n_dim) doubles from r * that many on (the rest
+ * holds the restarts' barrier counters).  init_labels_dev (optional,
  * [n_init][n] int32 in {0,1}) replaces the k-means initialisation.
  * n_dim <= 128.  After the call the scratch of restart r holds, from double
  * nb_gmm_logp_offset(n_dim) on, log(w_k N(x_i; mu_k, Sigma_k)) of all points
@@ -451,6 +454,7 @@ int nb_neural_score_rows(const nb_bound* bound, int32_t m, int32_t recentre,
  * points on the host.                                                         */
 int64_t nb_gmm_out_doubles(int32_t n_dim);
 int64_t nb_gmm_scratch_doubles(int64_t n, int32_t n_dim);
+int64_t nb_gmm_work_doubles(int64_t n, int32_t n_dim, int32_t n_init);
 int64_t nb_gmm_logp_offset(int32_t n_dim);
 int nb_gmm_fit(const double* x_dev, int64_t n, int32_t n_dim, int32_t n_init,
                uint64_t seed, double tol, double reg_covar, int32_t max_iter,

@@ -177,6 +177,7 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     'nb_gmm_out_doubles': (C.c_int64, [C.c_int32]),
     'nb_gmm_scratch_doubles': (C.c_int64, [C.c_int64, C.c_int32]),
+    'nb_gmm_work_doubles': (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     'nb_gmm_logp_offset': (C.c_int64, [C.c_int32]),
     'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                              C.c_uint64, C.c_double, C.c_double, C.c_int32,

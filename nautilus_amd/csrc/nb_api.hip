@@ -99,6 +99,8 @@ int nb_launch_prior(const double* u, long long n, int d,
                     const double* scale, double* out, hipStream_t stream);
 long long nb_gmm_out_stride_impl(int d);
 long long nb_gmm_scratch_stride_impl(long long n, int d);
+long long nb_gmm_work_doubles_impl(long long n, int d, int n_init);
+long long nb_gmm_logp_offset_impl(long long n, int d);
 int nb_launch_gmm(const double* x, long long n, int d, int n_init,
                   unsigned long long seed, double tol, double reg, int max_iter,
                   const int* init_labels, double* out, double* scratch,
@@ -1117,9 +1119,12 @@ int64_t nb_gmm_scratch_doubles(int64_t n, int32_t n_dim) {
   return nb_gmm_scratch_stride_impl(n, n_dim);
 }
 
+int64_t nb_gmm_work_doubles(int64_t n, int32_t n_dim, int32_t n_init) {
+  return nb_gmm_work_doubles_impl(n, n_dim, n_init);
+}
+
 int64_t nb_gmm_logp_offset(int32_t n_dim) {
-  const int64_t m = (int64_t)n_dim + 1;
-  return (m * m + 1) & ~(int64_t)1;
+  return nb_gmm_logp_offset_impl(2, n_dim);     // (does not depend on n)
 }
 
 int nb_gmm_fit(const double* x, int64_t n, int32_t n_dim, int32_t n_init,

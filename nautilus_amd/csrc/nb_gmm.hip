@@ -6,17 +6,32 @@
 // then EM with tol = 1e-3 on the mean log-likelihood, reg_covar = 1e-6,
 // max_iter = 100 (mixture/_base.py:fit_predict, _gaussian_mixture.py).
 //
-// One workgroup per restart, all restarts of a fit run concurrently;
-// n_dim <= 128.
-//   M-step: ONE weighted second-moment product on the matrix cores over the
-//           augmented rows q = (x, 1):  S0 = sum_i r_i0 q_i q_i^T  holds
-//           sum r x x^T, sum r x and sum r at once (nb_sym.h, sy_moments);
-//           component 1 follows from S_all - S0 (S_all computed once)
-//   E-step: Sigma_k is built in LDS as lower-triangular operand tiles and
-//           inverted in place with the symmetric sweep operator (the pivots
-//           give log det Sigma_k); (x - mu_k)^T Sigma_k^-1 (x - mu_k) for all
-//           points on the matrix cores (sy_quadform)
-// Everything is deterministic (fixed reduction orders, Philox for the seeding).
+// All restarts of a fit run concurrently, and every restart on W WORKGROUPS
+// (grid = (W, n_init), W <= 8; n_dim <= 128): an fp64 MFMA takes 64 cycles on
+// this part, so ONE compute unit needs ~40 us for the moment product and
+// ~75 us for the two quadratic forms of 2000 points at n_dim 50 -- per EM
+// iteration, of which a unimodal cloud takes up to 100.  The rows are dealt
+// out over the workgroups of a restart; what depends on all rows crosses
+// them once per iteration:
+//   M-step: every workgroup forms the weighted second moments of ITS rows on
+//           the matrix cores over the augmented rows q = (x, 1):
+//           S0 = sum_i r_i0 q_i q_i^T holds sum r x x^T, sum r x and sum r at
+//           once (nb_sym.h, sy_moments); the per-workgroup sums and the sum
+//           of log-likelihoods of the E-step before go to global memory, ONE
+//           barrier over the restart's workgroups (a counter in the L2),
+//           then every workgroup adds the W partial sums in the same order
+//           and derives the same parameters (component 1 from S_all - S0,
+//           S_all computed once the same way) -- redundantly, bit-identical
+//   E-step: every workgroup builds Sigma_k in its LDS as lower-triangular
+//           operand tiles and inverts it in place with the symmetric sweep
+//           operator (the pivots give log det Sigma_k; both components go
+//           through the pivots together where two tile sets fit the LDS);
+//           (x - mu_k)^T Sigma_k^-1 (x - mu_k) for ITS rows on the matrix
+//           cores (sy_quadform), responsibilities and its share of the
+//           log-likelihood sum
+// The seeding (k-means++ and Lloyd, 0.3 ms of a fit) runs on workgroup 0 of
+// the restart.  Everything is deterministic (fixed reduction orders, Philox
+// for the seeding).
 #include "nb_sym.h"
 
 namespace {
@@ -24,6 +39,8 @@ namespace {
 constexpr int GM_THREADS = 512;
 constexpr int GM_WAVES = GM_THREADS / 64;
 constexpr unsigned GM_TAG = 3u;           // Philox tag of the seeding draws
+constexpr int GM_MAXW = 8;                // workgroups per restart
+constexpr int GM_SYNC_INTS = 32;          // counter block of a restart (128 B)
 // both components' operand tiles side by side in LDS (2 x DT (DT + 1) / 2
 // tiles of 2 KB): up to DT = 7 (112 KB)
 __host__ __device__ constexpr bool gm_both(int dt) { return dt <= 7; }
@@ -37,6 +54,7 @@ struct GmmArgs {
   const int* init_labels;     // optional [n_init][n]: skip k-means (tests)
   double* out;                // [n_init][out_stride]
   double* scratch;            // [n_init][scratch_stride]
+  int* sync;                  // [n_init][GM_SYNC_INTS], zero at launch
   long long out_stride, scratch_stride;
 };
 
@@ -52,6 +70,31 @@ __device__ __forceinline__ double block_sum(double v, double* red, int wave,
 #pragma unroll
   for (int w = 1; w < GM_WAVES; ++w) s += red[w];
   return s;
+}
+
+// scratch of one restart (doubles), sized for GM_MAXW workgroups
+struct GmLayout {
+  long long sall, lp0, lp1, r0, d2, lab, part_sg, part_wg, aux, flag, total;
+};
+__host__ __device__ inline GmLayout gm_layout(long long n, int d) {
+  const int m = d + 1, dt = (m + 15) / 16;
+  const long long mm = (m * m + 1) & ~1;
+  const long long nt = (long long)dt * (dt + 1) / 2 * NB_TILE;
+  const long long sgs = GM_WAVES / ((dt + 1) / 2);
+  const long long n2 = (n + 1) & ~1LL;
+  GmLayout L;
+  L.sall = 0;                                  // [GM_MAXW][mm] private copies
+  L.lp0 = L.sall + GM_MAXW * mm;               // [n]
+  L.lp1 = L.lp0 + n;                           // (contiguous: [2][n])
+  L.r0 = (L.lp1 + n + 1) & ~1LL;
+  L.d2 = L.r0 + n2;
+  L.lab = L.d2 + n2;                           // [n] ints
+  L.part_sg = L.lab + n2 / 2 + 2;              // [GM_MAXW][SG][NT][256]
+  L.part_wg = L.part_sg + GM_MAXW * sgs * nt;  // [2][GM_MAXW][NT][256]
+  L.aux = L.part_wg + 2 * GM_MAXW * nt;        // [2][GM_MAXW][8]
+  L.flag = L.aux + 2 * GM_MAXW * 8;            // [8]
+  L.total = L.flag + 8;
+  return L;
 }
 
 // DT = ceil((d + 1) / 16): tiles of the augmented rows
@@ -71,7 +114,8 @@ nb_gmm_kernel(GmmArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lg = lane >> 4, lj = lane & 15;
-  const int init = blockIdx.x;
+  const int wg = blockIdx.x, W = gridDim.x;
+  const int init = blockIdx.y;
   const double* __restrict__ x = a.x;
   const int n = a.n, d = a.d, m = d + 1;
   const int mm = (m * m + 1) & ~1;
@@ -79,27 +123,39 @@ nb_gmm_kernel(GmmArgs a) {
   double* colk = T + NKT * NT * NB_TILE;   // [NKT][DP] pivot columns of the sweeps
   double* mus = colk + NKT * DP;           // [NKT][DP] mu_k in slot order
   double* cen = mus + NKT * DP;            // [2][DP] k-means centres
-  unsigned short* swt = (unsigned short*)(cen + 2 * DP);   // [d (d + 1) / 2]
+  double* mean_l = cen + 2 * DP;           // [2][DP] mu_k in feature order
+  unsigned int* swt = (unsigned int*)(mean_l + 2 * DP);   // [d (d + 1) / 2]
+  double* piv = (double*)(swt + ((DP * (DP + 1) / 2 + 1) & ~1));   // [NKT][DP] pivots
   double* cpart = T;                       // [GM_WAVES][2][DP] (seeding only)
   const double inf = __builtin_huge_val();
 
+  // the rows of this workgroup (whole 16-point tiles)
+  const int rows_per = (((n + W - 1) / W) + 15) / 16 * 16;
+  const int row0 = wg * rows_per < n ? wg * rows_per : n;
+  const int row1 = row0 + rows_per < n ? row0 + rows_per : n;
+
   double* out = a.out + (long long)init * a.out_stride;
   double* scr = a.scratch + (long long)init * a.scratch_stride;
-  volatile double* sall = scr;                       // [m*m]
-  volatile double* lp0 = scr + mm;                   // [n]
-  volatile double* lp1 = lp0 + n;
-  volatile double* r0 = lp1 + n;
-  volatile double* d2 = r0 + n;
-  volatile int* lab = (volatile int*)(d2 + n);       // [n] ints
-  double* part = scr + mm + 5LL * n + 2;             // [SG][NT][256]
+  const GmLayout L = gm_layout(n, d);
+  volatile double* sall = scr + L.sall + (long long)wg * mm;   // [m*m], private
+  volatile double* lp0 = scr + L.lp0;                // [n]
+  volatile double* lp1 = scr + L.lp1;
+  volatile double* r0 = scr + L.r0;
+  volatile double* d2 = scr + L.d2;
+  volatile int* lab = (volatile int*)(scr + L.lab);  // [n] ints
+  double* part_sg = scr + L.part_sg + (long long)wg * SG * NT * NB_TILE;
+  volatile double* part_wg = scr + L.part_wg;        // [2][GM_MAXW][NT][256]
+  volatile double* aux = scr + L.aux;                // [2][GM_MAXW][8]
+  volatile double* flag = scr + L.flag;
   double* o_mean = out + 6;                          // [2][d]
   double* o_cov = o_mean + 2 * d;                    // [2][d*d]
+  int* cnt = a.sync + init * GM_SYNC_INTS;
 
   if (tid == 0) sh_bad = 0;
   __syncthreads();
 #ifdef NB_GMM_TIMING
-  // cycle counts per phase of restart 0 (debug build, make debug
-  // DEFS=-DNB_GMM_TIMING): S_all, seeding + Lloyd, then per EM phase
+  // cycle counts per phase of restart 0, workgroup 0 (debug build, make debug
+  // DEFS=-DNB_GMM_TIMING)
   long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_last = wall_clock64();
 #define GM_STAMP(i) do { const long long t_now = wall_clock64(); \
@@ -108,30 +164,83 @@ nb_gmm_kernel(GmmArgs a) {
 #define GM_STAMP(i) do {} while (0)
 #endif
 
-  // weighted second moments of all points into `part` (every wave of a
-  // sub-group owns two tile rows)
-  auto moments = [&](const volatile double* w) {
+  // barrier over the workgroups of this restart: the b-th one is open once
+  // the counter has reached (b + 1) W.  What a workgroup wrote before it is
+  // visible to the others' volatile (device-coherent) loads behind it.
+  int n_bar = 0;
+  auto restart_barrier = [&]() {
+    __syncthreads();
+    if (W > 1) {
+      if (tid == 0) {
+        __threadfence();
+        atomicAdd(cnt, 1);
+        const int want = (n_bar + 1) * W;
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE,
+                                 __HIP_MEMORY_SCOPE_AGENT) < want)
+          __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+      }
+      __syncthreads();
+    }
+    ++n_bar;
+  };
+
+  // weighted second moments of this workgroup's rows: the sub-groups' partial
+  // tiles (every wave of a sub-group owns two tile rows), summed over the
+  // sub-groups into ONE partial set per workgroup, part_wg[buf][wg]
+  auto moments_wg = [&](const volatile double* w, int buf) {
     const int sg = wave / GW, wv = wave - sg * GW;
     if (sg < SG)
       // (a shorter ring than the stand-alone moment kernel's: this kernel
       // keeps more alive around it)
-      sy_moments<DT, (DT <= 2 ? 8 : (DT <= 4 ? 4 : 2))>(x, w, d, 0, n, sg, SG, wv, lane,
-                     part + (size_t)sg * NT * NB_TILE);
+      sy_moments<DT, (DT <= 2 ? 8 : (DT <= 4 ? 4 : 2))>(
+          x, w, d, row0, row1, sg, SG, wv, lane,
+          part_sg + (size_t)sg * NT * NB_TILE);
     __threadfence_block();
     __syncthreads();
+    volatile double* dst = part_wg + ((size_t)buf * GM_MAXW + wg) * NT * NB_TILE;
+    const volatile double* src = part_sg;
+    for (int e = tid; e < NT * NB_TILE; e += GM_THREADS) {
+      double v[SG];
+#pragma unroll
+      for (int s = 0; s < SG; ++s) v[s] = src[(size_t)s * NT * NB_TILE + e];
+      double acc = v[0];
+#pragma unroll
+      for (int s = 1; s < SG; ++s) acc += v[s];
+      dst[e] = acc;
+    }
   };
-  auto moment = [&](int r, int c) {        // entry (r, c), r >= c
-    return mom_element((const volatile double*)part, SG, NT, r, c);
+  // entry (r, c), r >= c, of the moment matrix of ALL rows: the workgroups'
+  // partial sums in workgroup order (loads first, then the sum)
+  auto moment_all = [&](int buf, int r, int c) {
+    const int it = r >> 4, jt = c >> 4, i = r & 15, j = c & 15;
+    const int off = mv_tri(it, jt) * NB_TILE + (i >> 2) * 64 + (i & 3) * 16 + j;
+    const volatile double* src =
+        part_wg + (size_t)buf * GM_MAXW * NT * NB_TILE + off;
+    double v[GM_MAXW];
+#pragma unroll
+    for (int u = 0; u < GM_MAXW; ++u)
+      v[u] = src[(size_t)(u < W ? u : 0) * NT * NB_TILE];
+    double s = v[0];
+#pragma unroll
+    for (int u = 1; u < GM_MAXW; ++u) s += (u < W) ? v[u] : 0.0;
+    return s;
   };
 
-  // S_all = sum q q^T, kept in global scratch (lower triangle + mirror)
-  moments(nullptr);
+  // S_all = sum q q^T over all rows: a private copy per workgroup (lower
+  // triangle + mirror)
+  moments_wg(nullptr, 0);
+  restart_barrier();
   for (int e = tid; e < m * m; e += GM_THREADS) {
     const int r = e / m, c = e - r * m;
-    sall[e] = moment(r > c ? r : c, r > c ? c : r);
+    sall[e] = moment_all(0, r > c ? r : c, r > c ? c : r);
   }
   __threadfence_block();
   __syncthreads();
+  GM_STAMP(0);
+
+  // ---- seeding: workgroup 0 of the restart, all rows ----------------------
+  if (wg == 0) {
   // mean feature variance (tolerance scale of k-means, cluster/_kmeans.py:_tolerance)
   double mean_var = 0.0;
   for (int f = 0; f < d; ++f) {
@@ -139,7 +248,6 @@ nb_gmm_kernel(GmmArgs a) {
     mean_var += sall[f * m + f] / n - mu * mu;
   }
   mean_var /= d;
-  GM_STAMP(0);
 
   // ---- initial hard assignment ---------------------------------------------
   if (a.init_labels != nullptr) {
@@ -292,9 +400,15 @@ nb_gmm_kernel(GmmArgs a) {
   }
   __threadfence_block();
   __syncthreads();
+  if (tid == 0) flag[0] = sh_bad != 0 ? 1.0 : 0.0;
+  }
+  restart_barrier();
+  if (tid == 0 && flag[0] != 0.0) sh_bad = 1;
+  __syncthreads();
   GM_STAMP(1);
 
-  // the entries (r >= c) of the lower triangle, packed (r << 8 | c), in LDS:
+  // the entries (r >= c) of the lower triangle, packed (position in the
+  // operand tiles << 14 | r << 7 | c), in LDS:
   // thread t owns the entries t, t + 512, ... of every sweep (a table in
   // registers -- 17 slots of three ints for n_dim 128 -- was live across the
   // whole EM loop and evaluated in full at every pivot whatever n_dim)
@@ -303,7 +417,8 @@ nb_gmm_kernel(GmmArgs a) {
     int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
     while (r * (r + 1) / 2 > e) --r;
     while ((r + 1) * (r + 2) / 2 <= e) ++r;
-    swt[e] = (unsigned short)((r << 8) | (e - r * (r + 1) / 2));
+    const int c = e - r * (r + 1) / 2;
+    swt[e] = ((unsigned)sy_pos(r, c) << 14) | (unsigned)(r << 7) | (unsigned)c;
   }
   __syncthreads();
 
@@ -311,39 +426,70 @@ nb_gmm_kernel(GmmArgs a) {
   const double eps10 = 10.0 * 2.220446049250313e-16;
   double lower = -inf;
   int n_iter = 0, converged = 0;
-  double pi0 = 0.5, pi1 = 0.5;
+  double pi0 = 0.5, pi1 = 0.5, nk0 = 1.0, nk1 = 1.0;
   bool failed = sh_bad != 0;
   const int ks_max = 4 * DT;
-  // weighted log probabilities of both components for all points with the
-  // current parameters (mixture/_base.py:_estimate_weighted_log_prob).  Both
-  // components go through the pivots TOGETHER where two sets of operand
-  // tiles fit the LDS (BOTH: n_dim <= 111): one pair of barriers per pivot
-  // for both sweeps, and the quadratic forms of both read every point once.
+  int pb = 1;                 // partial-sum buffer of the current M-step
+  // Parameters of the M-step behind the partial sums in buffer pb
+  // (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters): weights and
+  // means here, the covariances where they are needed -- as operand tiles in
+  // LDS (log_prob) and, at the end, in the output record
+  auto m_step = [&]() {
+    const double s00 = moment_all(pb, d, d);
+    nk0 = s00 + eps10;
+    nk1 = ((double)n - s00) + eps10;
+    pi0 = nk0 / (nk0 + nk1);      // _m_step: weights_ /= weights_.sum()
+    pi1 = nk1 / (nk0 + nk1);
+    __syncthreads();              // mean_l free
+    for (int f = tid; f < DP; f += GM_THREADS) {
+      double m0 = 0.0, m1 = 0.0;
+      if (f < d) {
+        const double s0 = moment_all(pb, d, f);
+        m0 = s0 / nk0;
+        m1 = (sall[d * m + f] - s0) / nk1;
+      }
+      mean_l[f] = m0;
+      mean_l[DP + f] = m1;
+    }
+    __syncthreads();
+  };
+  auto cov_entry = [&](int r, int c, double& c0, double& c1) {
+    const double s0 = moment_all(pb, r, c);
+    const double s1 = sall[r * m + c] - s0;
+    const double reg = (r == c) ? a.reg : 0.0;
+    c0 = s0 / nk0 - mean_l[r] * mean_l[c] + reg;
+    c1 = s1 / nk1 - mean_l[DP + r] * mean_l[DP + c] + reg;
+  };
+  // weighted log probabilities of both components for this workgroup's rows
+  // with the current parameters (mixture/_base.py:
+  // _estimate_weighted_log_prob).  Both components go through the pivots
+  // TOGETHER where two sets of operand tiles fit the LDS (BOTH: n_dim <=
+  // 111): one pair of barriers per pivot for both sweeps, and the quadratic
+  // forms of both read every point once.
   constexpr int NK = BOTH ? 2 : 1;
   auto log_prob = [&]() {
     for (int k0 = 0; k0 < 2; k0 += NK) {
       for (int e = tid; e < NK * NT * NB_TILE; e += GM_THREADS) T[e] = 0.0;
       __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) {
-        const int k = k0 + kk;
-        const volatile double* cov = (volatile double*)o_cov + k * d * d;
-        const volatile double* mean = (volatile double*)o_mean + k * d;
-        double* Tk = T + kk * NT * NB_TILE;
-        for (int e = tid; e < n_low; e += GM_THREADS) {
-          const int r = swt[e] >> 8, c = swt[e] & 255;
-          Tk[sy_pos(r, c)] = cov[r * d + c];
+      for (int e = tid; e < n_low; e += GM_THREADS) {
+        const unsigned w = swt[e];
+        double c0, c1;
+        cov_entry((w >> 7) & 127, w & 127, c0, c1);
+        if constexpr (BOTH) {
+          T[w >> 14] = c0;
+          T[NT * NB_TILE + (w >> 14)] = c1;
+        } else {
+          T[w >> 14] = k0 == 0 ? c0 : c1;
         }
-        for (int f = tid; f < DP; f += GM_THREADS)
-          mus[kk * DP + mv_slot(f)] = (f < d) ? mean[f] : 0.0;
+      }
+      for (int f = tid; f < NK * DP; f += GM_THREADS) {
+        const int kk = f >= DP ? 1 : 0, ff = f - kk * DP;
+        mus[kk * DP + mv_slot(ff)] = mean_l[(k0 + kk) * DP + ff];
       }
       __syncthreads();
       GM_STAMP(3);
       // symmetric sweep operator over all pivots: T <- -Sigma^-1, the pivots
       // are those of the L D L^T factorisation (log det = sum log d_p)
-      double logdet[NK];
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) logdet[kk] = 0.0;
       for (int p = 0; p < d; ++p) {
         for (int i = tid; i < NK * d; i += GM_THREADS) {
           const int kk = i >= d ? 1 : 0, ii = i - kk * d;
@@ -351,36 +497,71 @@ nb_gmm_kernel(GmmArgs a) {
                                  (ii >= p ? sy_pos(ii, p) : sy_pos(p, ii))];
         }
         __syncthreads();
+        // entries in groups of four: the table words, then every operand,
+        // are read before the first is used (left as a plain loop the three
+        // dependent LDS round trips of an entry ran one after the other)
+        double inv_d[NK];
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
-          double* Tk = T + kk * NT * NB_TILE;
-          const double* ck = colk + kk * DP;
-          const double dp = ck[p];
+          const double dp = colk[kk * DP + p];
           if (!(dp > 0.0)) {                   // not positive definite
             if (tid == 0) sh_bad = 1;
           }
-          const double inv_d = 1.0 / dp;
-          logdet[kk] += log(dp);
-          for (int e = tid; e < n_low; e += GM_THREADS) {
-            const int r = swt[e] >> 8, c = swt[e] & 255;
-            const int at = sy_pos(r, c);
-            double v;
-            if (r == p && c == p) v = -inv_d;
-            else if (r == p) v = ck[c] * inv_d;
-            else if (c == p) v = ck[r] * inv_d;
-            else v = Tk[at] - ck[r] * ck[c] * inv_d;
-            Tk[at] = v;
+          if (tid == 0) piv[kk * DP + p] = dp;
+          inv_d[kk] = 1.0 / dp;
+        }
+        for (int e0 = tid; e0 < n_low; e0 += 4 * GM_THREADS) {
+          unsigned w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * GM_THREADS;
+            w[u] = swt[e < n_low ? e : 0];
+          }
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            double* Tk = T + kk * NT * NB_TILE;
+            const double* ck = colk + kk * DP;
+            double cr[4], cc[4], tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              cr[u] = ck[(w[u] >> 7) & 127];
+              cc[u] = ck[w[u] & 127];
+              tv[u] = Tk[w[u] >> 14];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = (w[u] >> 7) & 127, c = w[u] & 127;
+              double v;
+              if (r == p && c == p) v = -inv_d[kk];
+              else if (r == p) v = cc[u] * inv_d[kk];
+              else if (c == p) v = cr[u] * inv_d[kk];
+              else v = tv[u] - cr[u] * cc[u] * inv_d[kk];
+              if (e0 + u * GM_THREADS < n_low) Tk[w[u] >> 14] = v;
+            }
           }
         }
         __syncthreads();
+      }
+      // log det = sum of the logs of the pivots, in pivot order (every
+      // thread the same sum: the logs in parallel, then added in order)
+      for (int i = tid; i < NK * DP; i += GM_THREADS)
+        if (i % DP < d) piv[i] = log(piv[i]);
+      __syncthreads();
+      double logdet[NK];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        double acc = 0.0;
+        for (int pp = 0; pp < d; ++pp) acc += piv[kk * DP + pp];
+        logdet[kk] = acc;
       }
       GM_STAMP(4);
       // -> T form: -(...) and doubled off-diagonal entries
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk)
         for (int e = tid; e < n_low; e += GM_THREADS) {
-          const int r = swt[e] >> 8, c = swt[e] & 255;
-          T[kk * NT * NB_TILE + sy_pos(r, c)] *= (r == c) ? -1.0 : -2.0;
+          const unsigned w = swt[e];
+          T[kk * NT * NB_TILE + (w >> 14)] *=
+              (((w >> 7) & 127) == (w & 127)) ? -1.0 : -2.0;
         }
       __syncthreads();
       double konst[NK];
@@ -388,11 +569,32 @@ nb_gmm_kernel(GmmArgs a) {
       for (int kk = 0; kk < NK; ++kk)
         konst[kk] = log(k0 + kk == 0 ? pi0 : pi1) -
                     0.5 * (d * 1.8378770664093453 + logdet[kk]);
-      for (int tile = wave; tile * 16 < n; tile += GM_WAVES) {
+      // (the points of a wavefront's next tile are loaded in front of the
+      // products of the current one where the registers allow it)
+      constexpr bool PRE = DT <= 5;
+      const int tile0 = row0 / 16;
+      double xnext[1][4 * DT];
+      if constexpr (PRE) {
+        long long pn[1] = {(long long)(tile0 + wave) * 16 + lj};
+        bool vn[1] = {pn[0] < row1};
+        load_points<DT, 1>((const nb_gd*)x, pn, vn, d, (long long)n, lane,
+                           xnext);
+      }
+      for (int tile = tile0 + wave; tile * 16 < row1; tile += GM_WAVES) {
         long long pt[1] = {(long long)tile * 16 + lj};
-        bool valid[1] = {pt[0] < n};
+        bool valid[1] = {pt[0] < row1};
         double xin[1][4 * DT];
-        load_points<DT, 1>((const nb_gd*)x, pt, valid, d, (long long)n, lane, xin);
+        if constexpr (PRE) {
+#pragma unroll
+          for (int ks = 0; ks < 4 * DT; ++ks) xin[0][ks] = xnext[0][ks];
+          long long pn[1] = {(long long)(tile + GM_WAVES) * 16 + lj};
+          bool vn[1] = {pn[0] < row1};
+          load_points<DT, 1>((const nb_gd*)x, pn, vn, d, (long long)n, lane,
+                             xnext);
+        } else {
+          load_points<DT, 1>((const nb_gd*)x, pt, valid, d, (long long)n, lane,
+                             xin);
+        }
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
           double dx[4 * DT];
@@ -409,47 +611,32 @@ nb_gmm_kernel(GmmArgs a) {
       GM_STAMP(5);
     }
   };
+  double lse_wg = 0.0;        // this workgroup's share of the last E-step's sum
+  bool have_params = false;
   for (int it = 0; it <= a.max_iter && !failed; ++it) {
-    // M-step (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters)
-    moments(r0);
+    // this workgroup's moments under the current responsibilities and its
+    // share of the log-likelihood sum of the E-step before, then the barrier
+    moments_wg(r0, pb);
+    if (tid == 0) aux[((size_t)pb * GM_MAXW + wg) * 8] = lse_wg;
+    restart_barrier();
     GM_STAMP(2);
-    const double s00 = moment(d, d);
-    const double nk0 = s00 + eps10;
-    const double nk1 = ((double)n - s00) + eps10;
-    pi0 = nk0 / (nk0 + nk1);      // _m_step: weights_ /= weights_.sum()
-    pi1 = nk1 / (nk0 + nk1);
-    for (int f = tid; f < d; f += GM_THREADS) {
-      const double s0 = moment(d, f);
-      o_mean[f] = s0 / nk0;
-      o_mean[d + f] = (sall[d * m + f] - s0) / nk1;
+    if (it > 0) {
+      double lsum = 0.0;
+      for (int u = 0; u < W; ++u) lsum += aux[((size_t)pb * GM_MAXW + u) * 8];
+      const double lb = lsum / n;
+      n_iter = it;
+      if (fabs(lb - lower) < a.tol) converged = 1;
+      lower = lb;
     }
-    __threadfence_block();
-    __syncthreads();
-    for (int e = tid; e < d * d; e += GM_THREADS) {
-      const int r = e / d, c = e - r * d;
-      if (c > r) continue;
-      const double s0 = moment(r, c);
-      const double s1 = sall[r * m + c] - s0;
-      const double reg = (r == c) ? a.reg : 0.0;
-      const double m0r = ((volatile double*)o_mean)[r], m0c = ((volatile double*)o_mean)[c];
-      const double m1r = ((volatile double*)o_mean)[d + r], m1c = ((volatile double*)o_mean)[d + c];
-      const double c0 = s0 / nk0 - m0r * m0c + reg;
-      const double c1 = s1 / nk1 - m1r * m1c + reg;
-      o_cov[r * d + c] = c0;
-      o_cov[c * d + r] = c0;
-      o_cov[d * d + r * d + c] = c1;
-      o_cov[d * d + c * d + r] = c1;
-    }
-    __threadfence_block();
-    __syncthreads();
-    GM_STAMP(3);
+    m_step();
+    have_params = true;
     if (it == a.max_iter || converged) break;
 
     // E-step (mixture/_base.py:_estimate_log_prob_resp)
     log_prob();
     failed = sh_bad != 0;
     double lse_part = 0.0;
-    for (int i = tid; i < n; i += GM_THREADS) {
+    for (int i = row0 + tid; i < row1; i += GM_THREADS) {
       const double l0 = lp0[i], l1 = lp1[i];
       const double mx = l0 > l1 ? l0 : l1;
       const double lse = mx + log(exp(l0 - mx) + exp(l1 - mx));
@@ -457,12 +644,10 @@ nb_gmm_kernel(GmmArgs a) {
       lse_part += lse;
     }
     __threadfence_block();
-    const double lb = block_sum(lse_part, red, wave, lane) / n;
+    lse_wg = block_sum(lse_part, red, wave, lane);
     __syncthreads();
     GM_STAMP(6);
-    n_iter = it + 1;
-    if (fabs(lb - lower) < a.tol) converged = 1;
-    lower = lb;
+    pb ^= 1;
   }
   // the log probabilities under the FINAL parameters (those of the last
   // M-step) stay in the scratch of this restart: Union.split assigns every
@@ -472,18 +657,38 @@ nb_gmm_kernel(GmmArgs a) {
     failed = sh_bad != 0;
   }
 #ifdef NB_GMM_TIMING
-  if (tid == 0 && init == 0)
-    printf("[gmm] n=%d d=%d iters=%d  ticks(100MHz): s_all %lld seed+lloyd %lld "
-           "moments %lld mstep/build %lld sweeps %lld quadform %lld estep %lld\n",
-           n, d, n_iter, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
+  if (tid == 0 && init == 0 && wg == 0)
+    printf("[gmm] n=%d d=%d W=%d iters=%d  ticks(100MHz): s_all %lld "
+           "seed+lloyd %lld moments+barrier %lld build %lld sweeps %lld "
+           "quadform %lld estep %lld\n",
+           n, d, W, n_iter, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
 #endif
-  if (tid == 0) {
-    out[0] = failed ? -inf : lower;
-    out[1] = n_iter;
-    out[2] = converged;
-    out[3] = failed ? 1.0 : 0.0;
-    out[4] = pi0;
-    out[5] = pi1;
+  if (wg == 0) {
+    // the record of the restart: final parameters of the last M-step
+    if (have_params) {
+      for (int f = tid; f < d; f += GM_THREADS) {
+        o_mean[f] = mean_l[f];
+        o_mean[d + f] = mean_l[DP + f];
+      }
+      for (int e = tid; e < n_low; e += GM_THREADS) {
+        const unsigned w = swt[e];
+        const int r = (w >> 7) & 127, c = w & 127;
+        double c0, c1;
+        cov_entry(r, c, c0, c1);
+        o_cov[r * d + c] = c0;
+        o_cov[c * d + r] = c0;
+        o_cov[d * d + r * d + c] = c1;
+        o_cov[d * d + c * d + r] = c1;
+      }
+    }
+    if (tid == 0) {
+      out[0] = failed ? -inf : lower;
+      out[1] = n_iter;
+      out[2] = converged;
+      out[3] = failed ? 1.0 : 0.0;
+      out[4] = pi0;
+      out[5] = pi1;
+    }
   }
 }
 
@@ -492,13 +697,22 @@ inline size_t gm_lds_doubles(int dt) {
   const size_t nk = gm_both(dt) ? 2 : 1;
   const size_t tiles = nk * dt * (dt + 1) / 2 * NB_TILE;
   const size_t seed = (size_t)GM_WAVES * 2 * 16 * dt;      // cpart aliases T
-  // ... pivot columns, means, k-means centres, table of the triangle's entries
-  return (tiles > seed ? tiles : seed) + (2 * nk + 2) * 16 * dt +
-         ((size_t)16 * dt * (16 * dt + 1) / 2 + 3) / 4;
+  // ... pivot columns, means (slot and feature order), pivots, k-means
+  // centres, table of the triangle's entries
+  return (tiles > seed ? tiles : seed) + (3 * nk + 4) * 16 * dt +
+         ((size_t)16 * dt * (16 * dt + 1) / 2 + 1) / 2 + 2;
+}
+// workgroups per restart: a tile row of 256 points or more each, all
+// workgroups of the launch resident at once (they wait for each other)
+inline int gm_wgs(long long n, int n_init) {
+  long long w = n / 256;
+  if (w > GM_MAXW) w = GM_MAXW;
+  if (w * n_init > 128) w = 128 / n_init;
+  return (int)(w < 1 ? 1 : w);
 }
 
 template <int DT>
-int launch_gmm(const GmmArgs& a, hipStream_t stream) {
+int launch_gmm(const GmmArgs& a, int wgs, hipStream_t stream) {
   const size_t lds = gm_lds_doubles(DT) * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
@@ -513,8 +727,8 @@ int launch_gmm(const GmmArgs& a, hipStream_t stream) {
     allowed = lds;
   }
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nb_gmm_kernel<DT>, dim3(a.n_init), dim3(GM_THREADS), lds,
-                     stream, a);
+  hipLaunchKernelGGL(nb_gmm_kernel<DT>, dim3(wgs, a.n_init), dim3(GM_THREADS),
+                     lds, stream, a);
   return NB_OK;
 }
 
@@ -522,11 +736,15 @@ int launch_gmm(const GmmArgs& a, hipStream_t stream) {
 
 long long nb_gmm_out_stride_impl(int d) { return 6 + 2LL * d + 2LL * d * d; }
 long long nb_gmm_scratch_stride_impl(long long n, int d) {
-  const int m = d + 1, dt = gm_dt(d);
-  const long long mm = (m * m + 1) & ~1;
-  const long long part = (long long)(GM_WAVES / ((dt + 1) / 2)) *
-                         (dt * (dt + 1) / 2) * NB_TILE;
-  return mm + 5 * n + 2 + part;
+  return gm_layout(n, d).total;
+}
+// [n_init restarts][counter blocks of the restarts]
+long long nb_gmm_work_doubles_impl(long long n, int d, int n_init) {
+  return (long long)n_init * (nb_gmm_scratch_stride_impl(n, d) +
+                              GM_SYNC_INTS / 2) + 16;
+}
+long long nb_gmm_logp_offset_impl(long long n, int d) {
+  return gm_layout(n, d).lp0;
 }
 
 int nb_launch_gmm(const double* x, long long n, int d, int n_init,
@@ -547,17 +765,22 @@ int nb_launch_gmm(const double* x, long long n, int d, int n_init,
   a.out = out; a.scratch = scratch;
   a.out_stride = nb_gmm_out_stride_impl(d);
   a.scratch_stride = nb_gmm_scratch_stride_impl(n, d);
+  a.sync = (int*)(scratch + (long long)n_init * a.scratch_stride);
+  NB_HIP_CHECK(hipMemsetAsync(a.sync, 0,
+                              (size_t)n_init * GM_SYNC_INTS * sizeof(int),
+                              stream));
+  const int wgs = gm_wgs(n, n_init);
   int rc = NB_OK;
   switch (gm_dt(d)) {
-    case 1: rc = launch_gmm<1>(a, stream); break;
-    case 2: rc = launch_gmm<2>(a, stream); break;
-    case 3: rc = launch_gmm<3>(a, stream); break;
-    case 4: rc = launch_gmm<4>(a, stream); break;
-    case 5: rc = launch_gmm<5>(a, stream); break;
-    case 6: rc = launch_gmm<6>(a, stream); break;
-    case 7: rc = launch_gmm<7>(a, stream); break;
-    case 8: rc = launch_gmm<8>(a, stream); break;
-    default: rc = launch_gmm<9>(a, stream); break;
+    case 1: rc = launch_gmm<1>(a, wgs, stream); break;
+    case 2: rc = launch_gmm<2>(a, wgs, stream); break;
+    case 3: rc = launch_gmm<3>(a, wgs, stream); break;
+    case 4: rc = launch_gmm<4>(a, wgs, stream); break;
+    case 5: rc = launch_gmm<5>(a, wgs, stream); break;
+    case 6: rc = launch_gmm<6>(a, wgs, stream); break;
+    case 7: rc = launch_gmm<7>(a, wgs, stream); break;
+    case 8: rc = launch_gmm<8>(a, wgs, stream); break;
+    default: rc = launch_gmm<9>(a, wgs, stream); break;
   }
   if (rc != NB_OK) return rc;
   NB_HIP_CHECK(hipGetLastError());

@@ -520,7 +520,7 @@ def gmm_fit(x, n_init=10, seed=0, tol=1e-3, reg_covar=1e-6, max_iter=100,
     n, d = x.shape
     stride = lib.nb_gmm_out_doubles(d)
     out = torch.zeros(n_init * stride, dtype=torch.float64, device='cuda')
-    scratch = torch.empty(n_init * lib.nb_gmm_scratch_doubles(n, d),
+    scratch = torch.empty(lib.nb_gmm_work_doubles(n, d, n_init),
                           dtype=torch.float64, device='cuda')
     lab = None
     if init_labels is not None:
@@ -531,7 +531,7 @@ def gmm_fit(x, n_init=10, seed=0, tol=1e-3, reg_covar=1e-6, max_iter=100,
         float(reg_covar), int(max_iter), _ptr(lab) if lab is not None else None,
         _ptr(out), _ptr(scratch), _stream()))
     rec = out.cpu().numpy().reshape(n_init, stride)
-    per = scratch.numel() // n_init
+    per = lib.nb_gmm_scratch_doubles(n, d)
     off = lib.nb_gmm_logp_offset(d)
     fits = []
     for i, r in enumerate(rec):

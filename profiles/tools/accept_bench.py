@@ -65,33 +65,50 @@ for case in CASES:
     n = 1 << 20
     x = dev.propose(7, 0, n)
     dev.accept(7, 0, x)                      # warm-up
-    reps = 5
+    reps = int(os.environ.get('NB_ACCEPT_REPS', 20))
     with device.EvalCounters() as counters:
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
         prof = None
         if os.environ.get('NB_ACCEPT_CPROFILE'):
             import cProfile
             prof = cProfile.Profile()
             prof.enable()
+        # every call timed on its own (synchronised): the median is the
+        # kernels' time; a process that ran kernels of another n_dim before
+        # sees single calls stall for 20-80 ms (the device drops its clocks
+        # and ramps back over the next calls, profiles/r05/
+        # slow_mode_probe.txt) -- averaged over five queued calls that was
+        # the "slow mode" of rounds 3-4
+        each = []
+        for r in range(reps):
+            t0 = time.perf_counter()
+            flags = dev.accept(7, 0, x)
+            torch.cuda.synchronize()
+            each.append(time.perf_counter() - t0)
+        dt = float(np.median(each))
+        # ... and queued back to back behind one synchronisation
+        t0 = time.perf_counter()
         for r in range(reps):
             flags = dev.accept(7, 0, x)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt_queued = (time.perf_counter() - t0) / reps
         if prof is not None:
             import pstats
             prof.disable()
             pstats.Stats(prof).sort_stats('tottime').print_stats(12)
         work = counters.read()
+    reps_counted = 2 * reps
     flops = ((work['outer_point_evals'] + work['ellipsoid_point_evals']) *
              d * (d + 1) + work['emulator_point_evals'] * 2.0 *
-             (100 * d + 6020)) / reps
+             (100 * d + 6020)) / reps_counted
     kept = float((flags & 2).bool().double().mean())
-    print('D=%d K=%d M=%d E=%d, %d proposals: %.2f ms per call, %.1f TFLOP/s '
+    print('D=%d K=%d M=%d E=%d, %d proposals: %.2f ms per call (median of %d '
+          'synchronised calls; slowest %.2f, queued mean %.2f), %.1f TFLOP/s '
           '= %.3f of the fp64 MFMA peak (accepted %.3f, emulator evaluations '
           'per proposal %.2f)' % (
-              d, k, m, e, n, dt * 1e3, flops / dt / 1e12, flops / dt / 1e12 /
-              PEAK, kept, work['emulator_point_evals'] / reps / n / e),
+              d, k, m, e, n, dt * 1e3, reps, max(each) * 1e3, dt_queued * 1e3,
+              flops / dt / 1e12, flops / dt / 1e12 / PEAK, kept,
+              work['emulator_point_evals'] / reps_counted / n / e),
           flush=True)
     # the emulator stage alone: all proposals of one mode, gathered
     idx = torch.arange(n, device='cuda')

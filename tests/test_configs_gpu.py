@@ -8,9 +8,13 @@ runs its whole exploration and a sampling phase to a reduced N_eff against the
 analytic evidence.  C5 needs ~20 minutes even here, so by default it runs for
 a bounded wall time and the test asserts what must hold at any point of a run
 -- every bound built on the device, volumes shrinking, evidence finite and
-consistent with its shells; with ``NB_FULL_CONFIGS=1`` C4 and C5 run to the
-reference's default N_eff = 10 000 (committed full runs:
-profiles/r03/configs.json)."""
+consistent with its shells; with ``NB_FULL_CONFIGS=1`` C4 runs to the
+reference's default N_eff = 10 000 (committed full runs: the newest
+profiles/r*/configs.json).  Configuration 5's problem family (the funnel) is
+held against the REFERENCE'S OWN RUNS of the same problem at the settings the
+reference finishes on CPUs (tests/golden/e2e_funnel.json, written by
+make_golden_funnel.py) and against quadrature values at config 5's own
+settings at 10 and 30 dimensions."""
 
 import json
 import os
@@ -33,7 +37,7 @@ def gpu_only():
 
 
 def _run(name, seed=0, timeout=np.inf, n_batch=None, n_eff=10000,
-         discard_exploration=True):
+         discard_exploration=True, n_live=None, n_networks=None):
     import torch
     from nautilus_amd import Sampler, geometry, unit_prior
     from nautilus_amd.configs import baseline_config
@@ -48,7 +52,8 @@ def _run(name, seed=0, timeout=np.inf, n_batch=None, n_eff=10000,
     geometry._best_of_inits_host = spy
     try:
         s = Sampler(unit_prior, c['likelihood'], n_dim=c['n_dim'],
-                    n_live=c['n_live'], n_networks=c['n_networks'],
+                    n_live=n_live or c['n_live'],
+                    n_networks=n_networks or c['n_networks'],
                     n_batch=n_batch or c['n_batch'], vectorized=True,
                     seed=seed)
         done = s.run(n_eff=n_eff, discard_exploration=discard_exploration,
@@ -72,7 +77,7 @@ def _invariants(c, s):
     for b in s.bounds[1:]:
         assert b.n_dim == c['n_dim']
         for nb in b.neural_bounds:
-            assert len(nb.emulator.neural_networks) == c['n_networks']
+            assert len(nb.emulator.neural_networks) == s.n_networks
     # the newest bound encloses most of the current live points (not all: the
     # emulator's threshold sits at the predicted score of the lowest live
     # point, neural.py:97, so points near the likelihood threshold may fall
@@ -126,8 +131,9 @@ def test_gaussian_configs_against_reference_runs(name, seeds):
 
 
 def _committed(name):
-    for rnd in ('r03', 'r02'):
-        path = os.path.join(ROOT, 'profiles', rnd, 'configs.json')
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*',
+                                              'configs.json')))[::-1]:
         if os.path.exists(path):
             with open(path) as f:
                 row = json.load(f).get(name)
@@ -205,24 +211,115 @@ def test_C5_funnel_real_size():
         assert abs(s.log_z - c['analytic_log_z']) < 0.1
 
 
-@pytest.mark.parametrize('name', ['C5-D10'] + (['C5-D20'] if FULL else []))
-def test_C5_family_finishes(name):
-    """Configuration 5's problem -- the D-dimensional form of the reference's
-    funnel test (tests/test_sampler.py:311-326), n_live 10000, 8 networks, the
-    reference's defaults otherwise (discard_exploration=False, n_eff 10000)
-    -- at the dimensions where a run ends: complete runs with the REFERENCE'S
-    OWN ASSERTION, |log Z - log Z_true| < 0.1 (measured: -0.0540 against
-    -0.0501 at D = 10 in 35 s and 80 bounds, -0.0619 against -0.0591 at D = 20
-    in 175 s and 166 bounds; profiles/r04/C5-D*.json), and the funnel's
-    posterior mean."""
-    c, s, done, host_calls = _run(name, discard_exploration=False)
+def _x0_moments(s):
+    pts, log_w, _ = s.posterior()
+    w = np.exp(log_w - log_w.max())
+    w /= w.sum()
+    mean = pts.T @ w
+    return mean, float(((pts[:, 0] - mean[0])**2) @ w)
+
+
+def _funnel_reference(n_dim, discard):
+    with open(os.path.join(GOLDEN, 'e2e_funnel.json')) as f:
+        runs = json.load(f)['runs']
+    return [r for r in runs if r['setting'] == 'reduced' and
+            r['n_dim'] == n_dim and r['discard_exploration'] == discard]
+
+
+@pytest.mark.parametrize('n_dim,seeds', [(10, (0, 1, 2)), (20, (0, 1))])
+def test_funnel_against_reference_runs(n_dim, seeds):
+    """Configuration 5's problem at 10 / 20 dimensions with the settings of
+    the reference runs in tests/golden/e2e_funnel.json (n_live 2000, 4
+    networks, n_batch 100, n_eff 10000, exploration discarded; the reference
+    needs 12 / 42 minutes per run on a CPU core): the evidence in the
+    reference's band -- sigma(log Z) of ONE run of either sampler is ~0.01 at
+    this N_eff --, likelihood calls, number of bounds and the posterior of
+    x_0 as the reference has them.  Both samplers put E[x_0] ABOVE the
+    quadrature value (0.4895 / 0.4879) by 0.002-0.004 and Var[x_0] below it:
+    the bounds lose mass at the narrow end of the funnel, in the reference
+    exactly as here (profiles/r05/funnel_bias.json)."""
+    from nautilus_amd.configs import funnel_log_z, funnel_moments
+    ref = _funnel_reference(n_dim, True)
+    assert len(ref) >= 3
+    ref_z = np.array([r['log_z'] for r in ref])
+    ref_like = np.mean([r['n_like'] for r in ref])
+    ref_bounds = np.mean([r['n_bounds'] for r in ref])
+    ref_mean = np.mean([r['mean_x0'] for r in ref])
+    ref_var = np.mean([r['var_x0'] for r in ref])
+    sigma = 0.01
+    zs = []
+    for seed in seeds:
+        c, s, done, host_calls = _run('C5-D%d' % n_dim, seed=seed, n_batch=100,
+                                      n_live=2000, n_networks=4)
+        assert done and not host_calls and s.n_eff >= 10000
+        _invariants(c, s)
+        assert abs(s.log_z - ref_z.mean()) < 4 * sigma * \
+            np.sqrt(1 + 1 / len(ref))
+        # the reference's own assertion (tests/test_sampler.py:326)
+        assert abs(s.log_z - funnel_log_z(n_dim)) < 0.1
+        assert abs(s.n_like / ref_like - 1) < 0.06
+        assert abs(len(s.bounds) - ref_bounds) <= 8
+        mean, var = _x0_moments(s)
+        se = np.sqrt(ref_var / 10000)
+        assert abs(mean[0] - ref_mean) < 4.5 * se * np.sqrt(1 + 1 / len(ref))
+        assert abs(var / ref_var - 1) < 0.12
+        assert np.all(np.abs(mean[1:] - 0.5) < 0.01)
+        # ... and neither sits on the quadrature value
+        assert abs(mean[0] - funnel_moments(n_dim)[0]) < 0.012
+        zs.append(s.log_z)
+    assert abs(np.mean(zs) - ref_z.mean()) < 3.5 * sigma * \
+        np.sqrt(1 / len(zs) + 1 / len(ref))
+
+
+def test_funnel_exploration_kept_shares_the_reference_bias():
+    """``discard_exploration=False`` (the reference's default, and what its
+    funnel test runs with): the estimate that keeps the exploration points
+    is biased LOW on the funnel, in the reference as here -- 10 dimensions,
+    n_live 2000: log Z - analytic = -0.044 in the reference's run
+    (e2e_funnel.json), -0.043 / -0.046 / -0.047 here (profiles/r05/
+    funnel_b.jsonl); at 20 dimensions -0.118 against -0.114, beyond the
+    reference's own tolerance of 0.1.  The bias of configuration 5's runs
+    in round 4 (-0.054 at 30, -0.179 at 50 dimensions with n_live 10000) is
+    this."""
+    from nautilus_amd.configs import funnel_log_z
+    ref = _funnel_reference(10, False)
+    assert len(ref) >= 1
+    c, s, done, host_calls = _run('C5-D10', seed=3, n_batch=100, n_live=2000,
+                                  n_networks=4, discard_exploration=False)
+    assert done and not host_calls
+    ref_z = np.mean([r['log_z'] for r in ref])
+    assert abs(s.log_z - ref_z) < 0.02
+    assert s.log_z - funnel_log_z(10) < -0.02          # the shared bias
+    assert abs(s.n_like / np.mean([r['n_like'] for r in ref]) - 1) < 0.06
+
+
+@pytest.mark.parametrize('name,discard', [('C5-D10', False), ('C5-D30', True)]
+                         + ([('C5-D20', False)] if FULL else []))
+def test_C5_family_finishes(name, discard):
+    """Configuration 5's own settings (n_live 10000, 8 networks) at the
+    dimensions where a run ends.  10 (and 20) dimensions with the
+    reference's defaults (discard_exploration=False), the REFERENCE'S OWN
+    ASSERTION |log Z - log Z_true| < 0.1 (tests/test_sampler.py:326;
+    measured -0.004 / -0.003) and E[x_0] within 0.002 of the quadrature value
+    0.4895 (measured +0.0004; five standard errors of this run are 0.0006,
+    the exploration bias of test_funnel_exploration_kept_... adds to them).
+    30 dimensions with the exploration discarded (260 bounds, ~200 s):
+    log Z - analytic = -0.014 and E[x_0] 0.0037 above the quadrature value --
+    the loss of mass at the narrow end that the reference shows at its own
+    sizes (test_funnel_against_reference_runs); with the exploration kept
+    the same run gives -0.048 (round 4: -0.054)."""
+    from nautilus_amd.configs import funnel_moments
+    c, s, done, host_calls = _run(name, discard_exploration=discard)
     assert not host_calls
     assert done and s.explored and s.n_eff >= 10000
     assert s.n_dead_bounds <= 2
-    assert abs(s.log_z - c['analytic_log_z']) < 0.1
-    pts, log_w, _ = s.posterior()
-    mean = np.average(pts, weights=np.exp(log_w), axis=0)
-    # x_0 ~ N(0.5, 0.1) truncated by the cube of the OTHER coordinates (wide
-    # slices lose mass): slightly below 0.5; all others symmetric about 0.5
-    assert 0.46 < mean[0] < 0.5
+    mean, var = _x0_moments(s)
+    want_mean, want_var = funnel_moments(c['n_dim'])
+    if name == 'C5-D30':
+        assert abs(s.log_z - c['analytic_log_z']) < 0.05
+        assert 0.0 < mean[0] - want_mean < 0.008
+    else:
+        assert abs(s.log_z - c['analytic_log_z']) < 0.1
+        assert abs(mean[0] - want_mean) < 0.002
+    assert abs(var / want_var - 1) < 0.2
     assert np.all(np.abs(mean[1:] - 0.5) < 0.01)
