@@ -357,6 +357,61 @@ def roctx_region(resume):
         return
 
 
+def two_stage_roofline(d, k=4, e=4, n=1 << 20, reps=10):
+    """``DeviceBound.accept`` of a K = M = 4, E = 4 bound through the staged
+    route: flops from the evaluation counters over the median call."""
+    import torch
+    from nautilus_amd import bounds as nbd, device
+    from nautilus_amd.emulator import NeuralNetworkEmulator, Network
+    rs = np.random.RandomState(0)
+    units = [d, 100, 50, 20, 1]
+
+    def net():
+        coefs, icpts = [], []
+        for a, b in zip(units[:-1], units[1:]):
+            lim = np.sqrt(6.0 / (a + b))
+            coefs.append(rs.uniform(-lim, lim, (a, b)))
+            icpts.append(rs.uniform(-lim, lim, b))
+        return Network(coefs, icpts)
+    members, neural = [], []
+    for c in 0.25 + 0.5 * rs.rand(k, d):
+        a = rs.normal(size=(d, d)) * 0.02 / np.sqrt(d) + 0.04 * np.eye(d)
+        cov = a @ a.T
+        b_mat = np.linalg.cholesky(cov)
+        args = (c, b_mat, np.linalg.inv(b_mat), np.linalg.inv(cov))
+        members.append(nbd.Ellipsoid.from_params(*args))
+        emu = NeuralNetworkEmulator.from_weights(
+            np.zeros(d), np.ones(d), [net() for _ in range(e)])
+        neural.append(nbd.NeuralBound.from_parts(
+            nbd.Ellipsoid.from_params(*args), emu, 0.0))
+    outer = nbd.Union.from_members(members, unit=True)
+    outer.log_v_all = np.array([m.log_v for m in members])
+    dev = nbd.NautilusBound.from_parts(
+        outer, neural, rng=np.random.default_rng(1)).device_bound()
+    x = dev.propose(7, 0, n)
+    dev.accept(7, 0, x)
+    each = []
+    with device.EvalCounters() as counters:
+        torch.cuda.synchronize()
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            dev.accept(7, 0, x)
+            torch.cuda.synchronize()
+            each.append(time.perf_counter() - t0)
+        work = counters.read()
+    flops = ((work['outer_point_evals'] + work['ellipsoid_point_evals']) *
+             d * (d + 1) + work['emulator_point_evals'] * 2.0 *
+             (100 * d + 6020)) / reps
+    ms = float(np.median(each)) * 1e3
+    tf = flops / (ms * 1e-3) / 1e12
+    return dict(kernel='nb_cand_kernel + nb_eval_fast_kernel<batch>',
+                bound='mfma', achieved=tf, peak=FP64_MFMA_PEAK_TF,
+                unit='TFLOP/s', frac=tf / FP64_MFMA_PEAK_TF, traffic=None,
+                points=n, members=k, neural_bounds=k, networks=e, n_dim=d,
+                avg_call_ms=ms, slowest_call_ms=float(max(each)) * 1e3,
+                flop_per_call=flops)
+
+
 def main():
     args = parse()
     import torch
@@ -668,6 +723,13 @@ def main():
             flop_per_point=d2 * (d2 + 1), bytes_per_point=8 * d2 + 1,
             avg_launch_ms=ms, inside_fraction=float(mask.double().mean()))
         del x, mask
+        # ... and the two-stage bound evaluation (geometric stage + candidate
+        # lists + one batched emulator launch) of a bound with four outer
+        # members and four neural bounds at the same dimension: median of
+        # synchronised calls (single calls of a process that ran kernels of
+        # another n_dim before stall for tens of milliseconds while the device
+        # re-ramps its clocks, profiles/r05/slow_mode_probe.txt)
+        out['roofline_two_stage_d100'] = two_stage_roofline(100)
         out['mfma_f64_probe_tflops'] = device.mfma_f64_peak(20000)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(

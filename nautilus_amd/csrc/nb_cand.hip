@@ -506,12 +506,10 @@ unsigned long long* nb_eval_counters();
 // n_dim; lists (first-hit bookkeeping, sphere pre-test, periodic shift next to
 // the points): two up to n_dim 80, one beyond -- the shapes that need no
 // scratch (profiles/tools/kernel_resources.sh: 0 bytes for every shipped
-// instantiation; a kernel WITH scratch at n_dim ~ 100 ran three times slower
-// for the rest of a process's life in 2 of 5 processes, profiles/r04/
-// second_session/scratch_experiment_2.txt).  Until round 5 the kernels held
-// ~6 DT registers of loop-invariant slot offsets and padding predicates across
-// the bound loop; with the lane group opaque per bound they are recomputed
-// where they are used.
+// instantiation).  Until round 5 the kernels held ~6 DT registers of
+// loop-invariant slot offsets and padding predicates across the bound loop
+// and spilled with two tiles beyond n_dim 64; with the lane group opaque per
+// bound they are recomputed where they are used.
 static int cand_tiles(int dt, int mode) {
   if (mode == CM_SAMPLE) return 2;
   return dt <= 5 ? 2 : 1;

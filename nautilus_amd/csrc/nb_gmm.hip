@@ -74,7 +74,7 @@ __device__ __forceinline__ double block_sum(double v, double* red, int wave,
 
 // scratch of one restart (doubles), sized for GM_MAXW workgroups
 struct GmLayout {
-  long long sall, lp0, lp1, r0, d2, lab, part_sg, part_wg, aux, flag, total;
+  long long sall, lp0, lp1, r0, d2, lab, part_sg, part_wg, aux, kaux, total;
 };
 __host__ __device__ inline GmLayout gm_layout(long long n, int d) {
   const int m = d + 1, dt = (m + 15) / 16;
@@ -92,8 +92,8 @@ __host__ __device__ inline GmLayout gm_layout(long long n, int d) {
   L.part_sg = L.lab + n2 / 2 + 2;              // [GM_MAXW][SG][NT][256]
   L.part_wg = L.part_sg + GM_MAXW * sgs * nt;  // [2][GM_MAXW][NT][256]
   L.aux = L.part_wg + 2 * GM_MAXW * nt;        // [2][GM_MAXW][8]
-  L.flag = L.aux + 2 * GM_MAXW * 8;            // [8]
-  L.total = L.flag + 8;
+  L.kaux = L.aux + 2 * GM_MAXW * 8;            // [2][GM_MAXW][2 DP + 8]
+  L.total = L.kaux + 2 * GM_MAXW * (2LL * 16 * dt + 8);
   return L;
 }
 
@@ -107,6 +107,9 @@ nb_gmm_kernel(GmmArgs a) {
   constexpr int SG = GM_WAVES / GW;
   constexpr bool BOTH = gm_both(DT);        // two sets of operand tiles in LDS
   constexpr int NKT = BOTH ? 2 : 1;
+  // entries of the lower triangle per thread (n_dim <= 16 DT - 1)
+  constexpr int EPT_N = (DP - 1) * DP / 2 < 8256 ? (DP - 1) * DP / 2 : 8256;
+  constexpr int EPT = (EPT_N + GM_THREADS - 1) / GM_THREADS;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double red[GM_WAVES], sh_val[4];
   __shared__ int sh_idx[2], sh_bad;
@@ -120,8 +123,8 @@ nb_gmm_kernel(GmmArgs a) {
   const int n = a.n, d = a.d, m = d + 1;
   const int mm = (m * m + 1) & ~1;
   double* T = lds;                         // NKT x NT tiles: Sigma_k -> -Sigma_k^-1 -> T
-  double* colk = T + NKT * NT * NB_TILE;   // [NKT][DP] pivot columns of the sweeps
-  double* mus = colk + NKT * DP;           // [NKT][DP] mu_k in slot order
+  double* colk = T + NKT * NT * NB_TILE;   // [2][NKT][DP] pivot columns of the sweeps
+  double* mus = colk + 2 * NKT * DP;       // [NKT][DP] mu_k in slot order
   double* cen = mus + NKT * DP;            // [2][DP] k-means centres
   double* mean_l = cen + 2 * DP;           // [2][DP] mu_k in feature order
   unsigned int* swt = (unsigned int*)(mean_l + 2 * DP);   // [d (d + 1) / 2]
@@ -146,7 +149,6 @@ nb_gmm_kernel(GmmArgs a) {
   double* part_sg = scr + L.part_sg + (long long)wg * SG * NT * NB_TILE;
   volatile double* part_wg = scr + L.part_wg;        // [2][GM_MAXW][NT][256]
   volatile double* aux = scr + L.aux;                // [2][GM_MAXW][8]
-  volatile double* flag = scr + L.flag;
   double* o_mean = out + 6;                          // [2][d]
   double* o_cov = o_mean + 2 * d;                    // [2][d*d]
   int* cnt = a.sync + init * GM_SYNC_INTS;
@@ -239,21 +241,33 @@ nb_gmm_kernel(GmmArgs a) {
   __syncthreads();
   GM_STAMP(0);
 
-  // ---- seeding: workgroup 0 of the restart, all rows ----------------------
-  if (wg == 0) {
-  // mean feature variance (tolerance scale of k-means, cluster/_kmeans.py:_tolerance)
-  double mean_var = 0.0;
-  for (int f = 0; f < d; ++f) {
-    const double mu = sall[d * m + f] / n;
-    mean_var += sall[f * m + f] / n - mu * mu;
+  // ---- seeding ---------------------------------------------------------
+  // mean feature variance (tolerance scale of k-means, cluster/_kmeans.py:
+  // _tolerance)
+  double mean_var;
+  {
+    double term = 0.0;
+    if (tid < d) {
+      const double mu = sall[d * m + tid] / n;
+      term = sall[tid * m + tid] / n - mu * mu;
+    }
+    mean_var = block_sum(term, red, wave, lane) / d;
+    __syncthreads();
   }
-  mean_var /= d;
+  // partial results of a Lloyd iteration per workgroup, two buffers in turn:
+  // [2][DP] centre sums, points of cluster 1, changed labels; slot 2 of the
+  // first buffer's tail: the seeding's verdict
+  const long long kst = 2 * DP + 8;
+  volatile double* kaux = scr + L.kaux;              // [2][GM_MAXW][kst]
 
   // ---- initial hard assignment ---------------------------------------------
   if (a.init_labels != nullptr) {
-    for (int i = tid; i < n; i += GM_THREADS)
+    for (int i = row0 + tid; i < row1; i += GM_THREADS)
       r0[i] = a.init_labels[(long long)init * n + i] == 0 ? 1.0 : 0.0;
   } else {
+    // k-means++ (two centres) on workgroup 0, all rows; the centres go to
+    // the others through global memory
+    if (wg == 0) {
     double u0, u1, u2, u3;
     nb_uniform_pair(a.seed, (unsigned long long)init, 0u, GM_TAG, u0, u1);
     nb_uniform_pair(a.seed, (unsigned long long)init, 1u, GM_TAG, u2, u3);
@@ -327,14 +341,25 @@ nb_gmm_kernel(GmmArgs a) {
     __syncthreads();
     for (int f = tid; f < d; f += GM_THREADS)
       cen[DP + f] = x[(long long)second * d + f];
-    for (int i = tid; i < n; i += GM_THREADS) lab[i] = -1;
+    for (int f = tid; f < DP; f += GM_THREADS) {
+      kaux[f] = f < d ? cen[f] : 0.0;
+      kaux[DP + f] = f < d ? cen[DP + f] : 0.0;
+    }
+    }
+    restart_barrier();
+    for (int f = tid; f < 2 * DP; f += GM_THREADS) cen[f] = kaux[f];
+    for (int i = row0 + tid; i < row1; i += GM_THREADS) lab[i] = -1;
     __threadfence_block();
-    __syncthreads();
+    restart_barrier();      // (kaux buffer 0 is reused by the first iteration)
 
-    // Lloyd iterations (cluster/_kmeans.py:_kmeans_single_lloyd)
+    // Lloyd iterations (cluster/_kmeans.py:_kmeans_single_lloyd), the rows
+    // dealt out over the workgroups: labels and partial centre sums of the
+    // own rows, one barrier, then every workgroup adds the partial sums in
+    // the same order and takes the same decisions
     for (int it = 0; it < 300; ++it) {
+      volatile double* mine = kaux + ((size_t)(it & 1) * GM_MAXW + wg) * kst;
       double changed = 0.0;
-      for (int i = tid; i < n; i += GM_THREADS) {
+      for (int i = row0 + tid; i < row1; i += GM_THREADS) {
         double s0 = 0.0, s1 = 0.0;
         for (int f = 0; f < d; ++f) {
           const double xv = x[(long long)i * d + f];
@@ -349,12 +374,13 @@ nb_gmm_kernel(GmmArgs a) {
       __threadfence_block();
       changed = block_sum(changed, red, wave, lane);
       __syncthreads();
-      // new centres: (feature, chunk of points) decomposition, the features
-      // in passes of 64
+      // centre sums of the own rows: (feature, chunk of points)
+      // decomposition, the features in passes of 64
       {
         const int ch = wave;
-        const int per = (n + GM_WAVES - 1) / GM_WAVES;
-        const int i0 = ch * per, i1 = (i0 + per < n) ? i0 + per : n;
+        const int per = (row1 - row0 + GM_WAVES - 1) / GM_WAVES;
+        const int i0 = row0 + ch * per;
+        const int i1 = (i0 + per < row1) ? i0 + per : row1;
         double c1 = 0.0;
         for (int fb = 0; fb < DP; fb += 64) {
           const int f = fb + lane;
@@ -373,8 +399,24 @@ nb_gmm_kernel(GmmArgs a) {
         if (lane == 0) red[ch] = c1;
       }
       __syncthreads();
-      double n1 = 0.0;
-      for (int w = 0; w < GM_WAVES; ++w) n1 += red[w];
+      if (tid < 2 * DP) {
+        double sum = 0.0;
+        for (int w = 0; w < GM_WAVES; ++w) sum += cpart[w * 2 * DP + tid];
+        mine[tid] = sum;
+      }
+      if (tid == 0) {
+        double n1w = 0.0;
+        for (int w = 0; w < GM_WAVES; ++w) n1w += red[w];
+        mine[2 * DP] = n1w;
+        mine[2 * DP + 1] = changed;
+      }
+      restart_barrier();
+      const volatile double* all = kaux + (size_t)(it & 1) * GM_MAXW * kst;
+      double n1 = 0.0, changed_all = 0.0;
+      for (int u = 0; u < W; ++u) {
+        n1 += all[u * kst + 2 * DP];
+        changed_all += all[u * kst + 2 * DP + 1];
+      }
       const double n0 = n - n1;
       if (n0 < 1.0 || n1 < 1.0) {            // an empty cluster: give up
         if (tid == 0) sh_bad = 1;
@@ -384,26 +426,27 @@ nb_gmm_kernel(GmmArgs a) {
       double shift = 0.0;
       if (tid < 2 * DP) {
         const int k = tid / DP, f = tid - k * DP;
-        double s = 0.0;
-        for (int w = 0; w < GM_WAVES; ++w) s += cpart[(w * 2 + k) * DP + f];
-        const double c_new = (f < d) ? s / (k ? n1 : n0) : 0.0;
+        double v[GM_MAXW];
+#pragma unroll
+        for (int u = 0; u < GM_MAXW; ++u)
+          v[u] = all[(u < W ? u : 0) * kst + tid];
+        double sum = v[0];
+#pragma unroll
+        for (int u = 1; u < GM_MAXW; ++u) sum += (u < W) ? v[u] : 0.0;
+        const double c_new = (f < d) ? sum / (k ? n1 : n0) : 0.0;
         const double dlt = c_new - ((f < d) ? cen[k * DP + f] : 0.0);
         shift = dlt * dlt;
         cen[k * DP + f] = c_new;   // only this thread touches cen[k][f] here
       }
       shift = block_sum(shift, red, wave, lane);
       __syncthreads();
-      if (changed == 0.0 || shift <= 1e-4 * mean_var) break;
+      if (changed_all == 0.0 || shift <= 1e-4 * mean_var) break;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += GM_THREADS) r0[i] = lab[i] == 0 ? 1.0 : 0.0;
+    for (int i = row0 + tid; i < row1; i += GM_THREADS)
+      r0[i] = lab[i] == 0 ? 1.0 : 0.0;
   }
   __threadfence_block();
-  __syncthreads();
-  if (tid == 0) flag[0] = sh_bad != 0 ? 1.0 : 0.0;
-  }
-  restart_barrier();
-  if (tid == 0 && flag[0] != 0.0) sh_bad = 1;
   __syncthreads();
   GM_STAMP(1);
 
@@ -489,59 +532,76 @@ nb_gmm_kernel(GmmArgs a) {
       __syncthreads();
       GM_STAMP(3);
       // symmetric sweep operator over all pivots: T <- -Sigma^-1, the pivots
-      // are those of the L D L^T factorisation (log det = sum log d_p)
+      // are those of the L D L^T factorisation (log det = sum log d_p).
+      // Every thread keeps ITS entries of the triangle (e = tid, tid + 512,
+      // ...) in registers through all pivots; per pivot the owners of column
+      // p publish it (LDS, two buffers in turn), ONE barrier, and every entry
+      // is updated from two LDS reads -- the matrices themselves are read
+      // and written once per sweep.  (With the matrices in LDS every pivot
+      // cost 2.2 us: ~34 dependent LDS operations per thread and two
+      // barriers; 62 % of an EM iteration.)
+      int er[EPT], ec[EPT], epos[EPT];
+      double tv[NK][EPT];
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) {
+        const int e = tid + u * GM_THREADS;
+        const unsigned w = swt[e < n_low ? e : 0];
+        er[u] = e < n_low ? (int)((w >> 7) & 127) : 255;
+        ec[u] = (int)(w & 127);
+        epos[u] = (int)(w >> 14);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+          tv[kk][u] = T[kk * NT * NB_TILE + epos[u]];
+      }
       for (int p = 0; p < d; ++p) {
-        for (int i = tid; i < NK * d; i += GM_THREADS) {
-          const int kk = i >= d ? 1 : 0, ii = i - kk * d;
-          colk[kk * DP + ii] = T[kk * NT * NB_TILE +
-                                 (ii >= p ? sy_pos(ii, p) : sy_pos(p, ii))];
+        double* ck = colk + (p & 1) * NK * DP;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+          if (er[u] == 255) continue;
+          const int at = ec[u] == p ? er[u] : (er[u] == p ? ec[u] : -1);
+          if (at >= 0) {
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) ck[kk * DP + at] = tv[kk][u];
+          }
         }
         __syncthreads();
-        // entries in groups of four: the table words, then every operand,
-        // are read before the first is used (left as a plain loop the three
-        // dependent LDS round trips of an entry ran one after the other)
-        double inv_d[NK];
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
-          const double dp = colk[kk * DP + p];
+          const double* c = ck + kk * DP;
+          const double dp = c[p];
           if (!(dp > 0.0)) {                   // not positive definite
             if (tid == 0) sh_bad = 1;
           }
           if (tid == 0) piv[kk * DP + p] = dp;
-          inv_d[kk] = 1.0 / dp;
-        }
-        for (int e0 = tid; e0 < n_low; e0 += 4 * GM_THREADS) {
-          unsigned w[4];
+          const double inv_d = 1.0 / dp;
+          double cr[EPT], cc[EPT];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * GM_THREADS;
-            w[u] = swt[e < n_low ? e : 0];
+          for (int u = 0; u < EPT; ++u) {
+            cr[u] = c[er[u] & 127];
+            cc[u] = c[ec[u]];
           }
 #pragma unroll
-          for (int kk = 0; kk < NK; ++kk) {
-            double* Tk = T + kk * NT * NB_TILE;
-            const double* ck = colk + kk * DP;
-            double cr[4], cc[4], tv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              cr[u] = ck[(w[u] >> 7) & 127];
-              cc[u] = ck[w[u] & 127];
-              tv[u] = Tk[w[u] >> 14];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int r = (w[u] >> 7) & 127, c = w[u] & 127;
-              double v;
-              if (r == p && c == p) v = -inv_d[kk];
-              else if (r == p) v = cc[u] * inv_d[kk];
-              else if (c == p) v = cr[u] * inv_d[kk];
-              else v = tv[u] - cr[u] * cc[u] * inv_d[kk];
-              if (e0 + u * GM_THREADS < n_low) Tk[w[u] >> 14] = v;
-            }
+          for (int u = 0; u < EPT; ++u) {
+            const int r = er[u], cidx = ec[u];
+            double v;
+            if (r == p && cidx == p) v = -inv_d;
+            else if (r == p) v = cc[u] * inv_d;
+            else if (cidx == p) v = cr[u] * inv_d;
+            else v = tv[kk][u] - cr[u] * cc[u] * inv_d;
+            tv[kk][u] = v;
           }
         }
-        __syncthreads();
       }
+      // -> T form: -(...) and doubled off-diagonal entries, back to LDS
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) {
+        if (er[u] == 255) continue;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk)
+          T[kk * NT * NB_TILE + epos[u]] =
+              tv[kk][u] * (er[u] == ec[u] ? -1.0 : -2.0);
+      }
+      __syncthreads();
       // log det = sum of the logs of the pivots, in pivot order (every
       // thread the same sum: the logs in parallel, then added in order)
       for (int i = tid; i < NK * DP; i += GM_THREADS)
@@ -555,15 +615,6 @@ nb_gmm_kernel(GmmArgs a) {
         logdet[kk] = acc;
       }
       GM_STAMP(4);
-      // -> T form: -(...) and doubled off-diagonal entries
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk)
-        for (int e = tid; e < n_low; e += GM_THREADS) {
-          const unsigned w = swt[e];
-          T[kk * NT * NB_TILE + (w >> 14)] *=
-              (((w >> 7) & 127) == (w & 127)) ? -1.0 : -2.0;
-        }
-      __syncthreads();
       double konst[NK];
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk)
@@ -699,7 +750,7 @@ inline size_t gm_lds_doubles(int dt) {
   const size_t seed = (size_t)GM_WAVES * 2 * 16 * dt;      // cpart aliases T
   // ... pivot columns, means (slot and feature order), pivots, k-means
   // centres, table of the triangle's entries
-  return (tiles > seed ? tiles : seed) + (3 * nk + 4) * 16 * dt +
+  return (tiles > seed ? tiles : seed) + (4 * nk + 4) * 16 * dt +
          ((size_t)16 * dt * (16 * dt + 1) / 2 + 1) / 2 + 2;
 }
 // workgroups per restart: a tile row of 256 points or more each, all

@@ -8,9 +8,9 @@ like = GaussianLikelihood(np.full(d, 0.5), np.eye(d) * 0.05**2)
 s = Sampler(unit_prior, like, n_dim=d, n_live=2000, n_networks=4, n_batch=16384, vectorized=True, seed=0)
 stats = []
 orig = emulator.train_ensembles
-def wrapped(jobs):
+def wrapped(jobs, **kw):
     torch.cuda.synchronize(); t0 = time.time()
-    out = orig(jobs)
+    out = orig(jobs, **kw)
     torch.cuda.synchronize(); dt = time.time() - t0
     for j, (nets, st) in zip(jobs, out):
         stats.append((st['n_rows'], st['n_iter'], dt))

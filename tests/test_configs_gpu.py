@@ -226,7 +226,7 @@ def _funnel_reference(n_dim, discard):
             r['n_dim'] == n_dim and r['discard_exploration'] == discard]
 
 
-@pytest.mark.parametrize('n_dim,seeds', [(10, (0, 1, 2)), (20, (0, 1))])
+@pytest.mark.parametrize('n_dim,seeds', [(10, (0, 1)), (20, (0,))])
 def test_funnel_against_reference_runs(n_dim, seeds):
     """Configuration 5's problem at 10 / 20 dimensions with the settings of
     the reference runs in tests/golden/e2e_funnel.json (n_live 2000, 4
