@@ -46,18 +46,6 @@ GUARD_LAUNCHES = 64
 GUARD_ACCEPTANCE = 1e-7
 
 
-_ENVELOPE_STREAM = None
-
-
-def _envelope_stream():
-    """The stream the sampling envelope of a NautilusBound is built on (next
-    to the training kernels on the caller's stream)."""
-    global _ENVELOPE_STREAM
-    if _ENVELOPE_STREAM is None:
-        _ENVELOPE_STREAM = torch.cuda.Stream()
-    return _ENVELOPE_STREAM
-
-
 class BarrenBound(RuntimeError):
     """A bound whose rejection sampler accepts (next to) nothing."""
 
@@ -691,15 +679,13 @@ class NeuralBound(_DeviceBoundBase):
 
     @classmethod
     def compute_many(cls, data, log_l_min, enlarge_per_dim=1.1, n_networks=4,
-                     neural_network_kwargs={}, rng=None, comm=None,
-                     overlap=None):
+                     neural_network_kwargs={}, rng=None, comm=None):
         """bounds/neural.py:58-97 for several (points, log_l) sets -- the
         neural bounds of one NautilusBound (nautilus.py:107-114).  The
         reference trains their emulators one after the other; here all
         ensembles train side by side on the GPU.  No random numbers are
         consumed (the networks are seeded 0..n_networks-1, neural.py:88), so
-        the order of the work does not matter.  ``overlap``: host work to run
-        once while the emulators train (``emulator.train_ensembles``)."""
+        the order of the work does not matter."""
         rng = _default_rng(rng)
         bounds, train = [], []
         xs, lives = [], []
@@ -734,8 +720,7 @@ class NeuralBound(_DeviceBoundBase):
             emus = NeuralNetworkEmulator.train_many(
                 [(x_t, score) for _, x_t, score, _ in train],
                 n_networks=n_networks,
-                neural_network_kwargs=neural_network_kwargs, comm=comm,
-                overlap=overlap)
+                neural_network_kwargs=neural_network_kwargs, comm=comm)
             for (self, x_t, score, hi), emu in zip(train, emus):
                 self.emulator = emu
                 # A network whose last epoch is no better than the constant
@@ -770,8 +755,6 @@ class NeuralBound(_DeviceBoundBase):
                             not _os.path.exists(dump):
                         np.savez(dump, x_t=x_t.cpu().numpy(), score=score,
                                  hi=hi, mean=emu.mean, scale=emu.scale)
-        elif overlap is not None:
-            overlap()
         return bounds
 
     @classmethod
@@ -889,54 +872,30 @@ class NautilusBound(_RejectionSampler):
         for ell in multi.bounds:
             sel = ell.contains_device(x)
             data.append((x[sel], log_l[sel.cpu().numpy()]))
-        env = {}
-
-        def envelope():
-            """Sampling envelope (:116-133).  It depends on the live points
-            only, not on the emulators: built while they train (the resident
-            training kernels hold half of the GPU's compute units or fewer
-            and need the host once per chunk of epochs), on a stream of its
-            own; with several GPUs the ranks that train nothing build it
-            while the others train."""
-            te = time()
-            main = torch.cuda.current_stream()
-            side = _envelope_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                outer = Union.compute(
-                    live, enlarge_per_dim=enlarge_per_dim,
-                    n_points_min=n_points_min,
-                    bound_class=UnitCubeEllipsoidMixture, rng=self.rng)
-                limit = np.log(split_threshold * enlarge_per_dim**self.n_dim)
-                while outer.log_v - log_v_target > limit:
-                    if not outer.split():
-                        break
-                while outer.log_v - log_v_target > limit:
-                    if not outer.trim():
-                        break
-                # the composite draws through its own fused pipeline; the
-                # envelope's counters keep accumulating (they are valid MC
-                # samples of the same volume), only its private FIFO is
-                # dropped
-                outer._queue().clear()
-            main.wait_stream(side)
-            env['outer'] = outer
-            env['s'] = time() - te
-
         self.neural_bounds = NeuralBound.compute_many(
             data, log_l_min, enlarge_per_dim=enlarge_per_dim,
             n_networks=n_networks,
             neural_network_kwargs=neural_network_kwargs, rng=self.rng,
-            comm=comm, overlap=envelope)
-        if 'outer' not in env:
-            envelope()
-        self.outer_bound = env['outer']
+            comm=comm)
+
         t2 = time()
-        # (bound_envelope: host seconds inside the envelope, which now lie
-        # inside the training's wall time)
-        self.timing = dict(bound_decompose=t1 - t0,
-                           bound_neural=t2 - t1 - env['s'],
-                           bound_envelope=env['s'])
+        # sampling envelope (:116-133)
+        self.outer_bound = Union.compute(
+            live, enlarge_per_dim=enlarge_per_dim, n_points_min=n_points_min,
+            bound_class=UnitCubeEllipsoidMixture, rng=self.rng)
+        limit = np.log(split_threshold * enlarge_per_dim**self.n_dim)
+        while self.outer_bound.log_v - log_v_target > limit:
+            if not self.outer_bound.split():
+                break
+        while self.outer_bound.log_v - log_v_target > limit:
+            if not self.outer_bound.trim():
+                break
+        # the composite draws through its own fused pipeline; the envelope's
+        # counters keep accumulating (they are valid MC samples of the same
+        # volume), only its private FIFO is dropped
+        self.outer_bound._queue().clear()
+        self.timing = dict(bound_decompose=t1 - t0, bound_neural=t2 - t1,
+                           bound_envelope=time() - t2)
         return self
 
     @classmethod

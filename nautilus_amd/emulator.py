@@ -288,7 +288,7 @@ class NeuralNetworkEmulator:
 
     @classmethod
     def train_many(cls, data, n_networks=4, neural_network_kwargs={},
-                   comm=None, overlap=None):
+                   comm=None):
         """``train`` for several (x, y) sets at once; the ensembles train
         concurrently on separate streams.  With ``comm`` (a
         ``parallel.ShardedComm``) network g of the flattened (ensemble,
@@ -310,9 +310,8 @@ class NeuralNetworkEmulator:
             emus.append(emu)
             jobs.append(dict(xs=xs, y=yt, seeds=list(range(n_networks)),
                              hparams=hp))
-        results = (train_ensembles(jobs, overlap=overlap)
-                   if comm is None or comm.world == 1
-                   else train_ensembles_sharded(jobs, comm, overlap=overlap))
+        results = (train_ensembles(jobs) if comm is None or comm.world == 1
+                   else train_ensembles_sharded(jobs, comm))
         user = {k: v for k, v in dict(neural_network_kwargs).items()
                 if k != 'random_state'}
         for emu, (nets, stats) in zip(emus, results):
@@ -453,9 +452,8 @@ class _TrainJob:
 
     def _buffers(self, n_items):
         """Pinned host / device buffers of a chunk; a slot is reused once its
-        chunk has been waited for (at most RING_SLOTS - 1 chunks are in
-        flight, ``enqueue_ahead``)."""
-        if len(self._ring) < RING_SLOTS:
+        chunk has been waited for (at most three are alive)."""
+        if len(self._ring) < 3:
             pin = torch.empty(n_items, dtype=torch.int32,
                               pin_memory=torch.cuda.is_available())
             dev = torch.empty(n_items, dtype=torch.int32, device='cuda')
@@ -517,27 +515,6 @@ class _TrainJob:
             return False
         return True
 
-    def enqueue_ahead(self, n_chunks):
-        """Queue up to ``n_chunks`` more chunks of epochs without waiting for
-        any (the caller is about to spend host time elsewhere,
-        ``train_ensembles(overlap=...)``); a network that stops skips the
-        chunks queued behind on the device."""
-        if self.finished:
-            return
-        with torch.cuda.stream(self.stream):
-            while n_chunks > 0 and len(self.tickets) < 3 and \
-                    np.any(self.status >= 0):
-                nxt = self.next_chunk()
-                if nxt is None:
-                    break
-                pin, dev, chunk = nxt
-                n_items = chunk * sum(self.ns)
-                dev[:n_items].copy_(pin[:n_items], non_blocking=True)
-                self.tickets.append(self.trainer.run_async(
-                    dev, self.shuffles.offsets * chunk, chunk))
-                self.done_epochs += chunk
-                n_chunks -= 1
-
     def release(self):
         """Destroy the trainer (frees its XCDs and device buffers)."""
         self.trainer.close()
@@ -568,21 +545,9 @@ class _TrainJob:
 
 
 MAX_RESIDENT = 16    # networks of one resident launch (two per XCD)
-RING_SLOTS = 6       # order buffers of a training job (chunks in flight + 1)
-AHEAD_CHUNKS = 2     # chunks queued before host work is overlapped (the
-                     # native trainer keeps four tickets: three in flight
-                     # here + the one the next step adds)
-# Host work is overlapped with the training of at most this many networks:
-# they hold four of the eight XCDs, and the kernels of the overlapped work
-# (the mixture fit keeps up to 80 workgroups resident that wait for each
-# other) find compute units of their own.  With more networks every XCD runs
-# resident training workgroups, and two kernels whose workgroups wait for
-# their own kind can starve each other of compute units for good; there the
-# work runs behind the training.
-OVERLAP_MAX_NETWORKS = 4
 
 
-def train_ensembles(jobs, overlap=None):
+def train_ensembles(jobs):
     """Train several ensembles (the neural bounds of a multi-modal
     NautilusBound).  The resident training kernel takes up to 16 networks per
     launch -- every network on the 32 CUs of an XCD, two networks per XCD
@@ -594,30 +559,16 @@ def train_ensembles(jobs, overlap=None):
     NB_TRAIN_TWO_LAUNCH set (several processes on one GPU) every ensemble
     gets a trainer and a stream of its own.  ``jobs``: list of dicts with
     keys xs, y, seeds and optionally hparams, permutations, init,
-    max_epochs.  ``overlap``: a callable that is run ONCE while the first
-    chunks of epochs train (host work and kernels on another stream: the
-    sampling envelope of a NautilusBound does not depend on its emulators,
-    nautilus.py:116-133); without networks to train it is run at once."""
+    max_epochs."""
     import os
     main = torch.cuda.current_stream()
     out = [None] * len(jobs)
-    pending = [overlap] if overlap is not None else []
-    concurrent = sum(len(j['seeds']) for j in jobs) <= OVERLAP_MAX_NETWORKS
-
-    def run_overlap(force=False):
-        if pending and (concurrent or force):
-            pending.pop()()
     if len(jobs) == 0:
-        run_overlap(True)
         return out
 
     def finish(job, keys):
-        more = job.step()
-        if pending and more and concurrent:
-            job.enqueue_ahead(AHEAD_CHUNKS)
-        run_overlap()
-        while more:
-            more = job.step()
+        while job.step():
+            pass
         for k, res in zip(keys, job.results()):
             out[k] = res
         main.wait_stream(job.stream)
@@ -633,15 +584,10 @@ def train_ensembles(jobs, overlap=None):
             running.append((k, _TrainJob([job], job.get('hparams'),
                                          job.get('max_epochs'), stream)))
         active = list(running)
-        first = True
         while active:
             active = [(k, j) for k, j in active if j.step()]
-            if first:
-                run_overlap()
-                first = False
         for k, j in running:
             finish(j, [k])
-        run_overlap(True)
         return out
     # fleets of at most MAX_RESIDENT networks, ensembles in order
     fleets, cur, size = [], [], 0
@@ -671,7 +617,6 @@ def train_ensembles(jobs, overlap=None):
                                  jobs[k].get('max_epochs'), main), [k])
             continue
         finish(job, keys)
-    run_overlap(True)
     return out
 
 
@@ -709,7 +654,7 @@ def _unpack_network(row, n_dim, hidden=HIDDEN):
     return Network(coefs, intercepts, int(row[0]), [float(row[1])])
 
 
-def train_ensembles_sharded(jobs, comm, overlap=None):
+def train_ensembles_sharded(jobs, comm):
     """``train_ensembles`` with the networks dealt out over the ranks of
     ``comm``: network g (ensembles in order, seeds in order) belongs to rank
     g mod world.  Every rank trains its share as smaller ensembles, then one
@@ -737,9 +682,7 @@ def train_ensembles_sharded(jobs, comm, overlap=None):
         for opt in ('permutations', 'init'):
             if jobs[j].get(opt) is not None:
                 lj[opt].append(jobs[j][opt][pos])
-    # (a rank without networks of its own does the overlapped host work while
-    # the others train)
-    trained = train_ensembles(local_jobs, overlap=overlap)
+    trained = train_ensembles(local_jobs) if local_jobs else []
     n_dim = jobs[0]['xs'].shape[1]
     units = [n_dim, *HIDDEN, 1]
     width = 2 + sum(a * b + b for a, b in zip(units[:-1], units[1:]))

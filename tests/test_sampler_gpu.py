@@ -782,57 +782,3 @@ def test_measured_barren_bound_is_dropped(monkeypatch):
     assert s.run(n_eff=2000, discard_exploration=True) is True
     assert s.n_dead_bounds == 1
     assert abs(s.log_z - analytic) < max(0.03, 4 * np.std(ref_lz))
-
-
-def test_envelope_built_while_the_emulators_train_is_the_same_bound(monkeypatch):
-    """``NautilusBound.compute`` builds the sampling envelope
-    (nautilus.py:116-133) on a stream of its own while the first chunks of
-    epochs train (``emulator.train_ensembles(overlap=...)``).  It depends on
-    the live points only: the bound is bit for bit the one the sequential
-    order gives -- envelope members, counters of its volume estimate, the
-    emulators' weights."""
-    import torch
-    from nautilus_amd import bounds, emulator
-    rng = np.random.default_rng(3)
-    d = 6
-    pts = 0.5 + 0.06 * rng.normal(size=(6000, d))
-    log_l = -np.sum((pts - 0.5)**2, axis=1) / 0.02
-    thr = np.sort(log_l)[-1500]
-
-    def build():
-        return bounds.NautilusBound.compute(
-            pts, log_l, thr, np.log(1e-3), n_networks=2,
-            rng=np.random.default_rng(5))
-    calls = []
-    real = emulator._TrainJob.enqueue_ahead
-
-    def spy(self, n):
-        calls.append(n)
-        return real(self, n)
-    monkeypatch.setattr(emulator._TrainJob, 'enqueue_ahead', spy)
-    a = build()
-    assert calls                       # the overlapped route was taken
-    monkeypatch.setattr(emulator, 'OVERLAP_MAX_NETWORKS', 0)
-    calls.clear()
-    b = build()
-    assert not calls                   # ... and here the sequential one
-    torch.cuda.synchronize()
-    assert len(a.outer_bound.bounds) == len(b.outer_bound.bounds)
-    for ma, mb in zip(a.outer_bound.bounds, b.outer_bound.bounds):
-        assert np.array_equal(ma.dim_cube, mb.dim_cube)
-        if ma.ellipsoid is not None:
-            assert np.array_equal(ma.ellipsoid.c, mb.ellipsoid.c)
-            assert np.array_equal(ma.ellipsoid.B, mb.ellipsoid.B)
-    assert np.array_equal(a.outer_bound.log_v_all, b.outer_bound.log_v_all)
-    assert (a.outer_bound.n_sample, a.outer_bound.n_reject) == \
-        (b.outer_bound.n_sample, b.outer_bound.n_reject)
-    for na, nb_ in zip(a.neural_bounds, b.neural_bounds):
-        assert na.score_predict_min == nb_.score_predict_min
-        for ea, eb in zip(na.emulator.neural_networks,
-                          nb_.emulator.neural_networks):
-            assert ea.n_iter_ == eb.n_iter_
-            for wa, wb in zip(ea.coefs_, eb.coefs_):
-                assert np.array_equal(wa, wb)
-    xa = a.sample(500)
-    xb = b.sample(500)
-    assert np.array_equal(xa, xb)
