@@ -78,6 +78,11 @@ def parse():
                         'separate child passes; adds two full runs)')
     p.add_argument('--explore-timeout', type=float, default=1500.0)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--timed-region-only', action='store_true',
+                   help='skip the kernel micro-benchmarks behind the timed '
+                        'steps (the --pmc-traffic child passes: their '
+                        'dispatches would be taken for the last ones of the '
+                        'timed region)')
     p.add_argument('--host-likelihood', action='store_true',
                    help='evaluate the likelihood with numpy on the host '
                         '(points cross PCIe both ways every step): the '
@@ -303,7 +308,7 @@ def pmc_traffic(argv):
                '--output-format', 'csv', '-d', tmp, '-o', 'pmc', '--',
                sys.executable, os.path.abspath(__file__)] + [
                    a for a in argv if a != '--pmc-traffic'] + [
-                   '--no-cpu-baseline']
+                   '--no-cpu-baseline', '--timed-region-only']
         env = dict(os.environ, TMPDIR='/tmp')
         try:
             child = subprocess.run(cmd, cwd='/tmp', env=env, check=True,
@@ -729,7 +734,8 @@ def main():
         # synchronised calls (single calls of a process that ran kernels of
         # another n_dim before stall for tens of milliseconds while the device
         # re-ramps its clocks, profiles/r05/slow_mode_probe.txt)
-        out['roofline_two_stage_d100'] = two_stage_roofline(100)
+        if not args.timed_region_only:
+            out['roofline_two_stage_d100'] = two_stage_roofline(100)
         out['mfma_f64_probe_tflops'] = device.mfma_f64_peak(20000)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(
