@@ -430,6 +430,9 @@ def main():
         # several processes on one GPU: the resident training kernel owns
         # whole XCDs per process and must not be shared between processes
         os.environ['NB_TRAIN_TWO_LAUNCH'] = '1'
+        # ... and the mixture fit's workgroups wait for each other: one per
+        # restart where several processes fit at the same time on one GPU
+        os.environ['NB_GMM_MAX_WGS'] = '1'
         local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None

@@ -34,6 +34,8 @@
 // for the seeding).
 #include "nb_sym.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int GM_THREADS = 512;
@@ -756,8 +758,17 @@ inline size_t gm_lds_doubles(int dt) {
 // workgroups per restart: a tile row of 256 points or more each, all
 // workgroups of the launch resident at once (they wait for each other)
 inline int gm_wgs(long long n, int n_init) {
+  // NB_GMM_MAX_WGS: cap (1 = one workgroup per restart).  The workgroups of
+  // a restart wait for each other, so all of a launch must be resident at
+  // once; processes that SHARE a GPU (several ranks on one device) and fit
+  // at the same time should not count on that -- they set the cap to 1.
+  static const int cap = []() {
+    const char* e = getenv("NB_GMM_MAX_WGS");
+    const int v = e != nullptr ? atoi(e) : GM_MAXW;
+    return v < 1 ? 1 : (v > GM_MAXW ? GM_MAXW : v);
+  }();
   long long w = n / 256;
-  if (w > GM_MAXW) w = GM_MAXW;
+  if (w > cap) w = cap;
   if (w * n_init > 128) w = 128 / n_init;
   return (int)(w < 1 ? 1 : w);
 }

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
     os.environ.setdefault('NB_TRAIN_TWO_LAUNCH', '1')   # ranks share one GPU
+    os.environ.setdefault('NB_GMM_MAX_WGS', '1')
     dist.init_process_group('gloo')
     from nautilus_amd import GaussianLikelihood, Sampler, unit_prior
     from nautilus_amd.parallel import ShardedComm
