@@ -200,6 +200,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: the library resolves libamdhip64 to whatever the process
+    # has loaded, and the HIP runtime torch ships has to be that one (loaded
+    # the other way round -- build() and smoke() in one process -- the two
+    # runtimes each see their own device state: "no ROCm-capable device")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             'nautilus_amd: HIP library %s not found; run `make` (hipcc, '

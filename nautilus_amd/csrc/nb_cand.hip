@@ -175,6 +175,10 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   constexpr int DP = 16 * DT;
   // k-steps the operands run ahead (two tiles at n_dim > 112 have the
   // registers for six)
+  // (measured at n_dim 50 / 100, K = M = 4: 7 k-steps 0.858 / 2.23 ms, 10:
+  // 0.875 / 2.19, 14: 0.900 / 2.25, 20: 0.93 / 2.85; three tiles per
+  // wavefront at n_dim 50: 0.927 -- the stage is not waiting for its
+  // operands; profiles/r05/cand_prefetch_depth_and_three_tiles.txt)
   constexpr int PD = OCC >= 4 ? 6 : ((DT == 8 && T == 2) ? 6 : 10);
   extern __shared__ int cur[];           // [n_groups][CD_WPB] fill counts
   const int lane = threadIdx.x & 63;
