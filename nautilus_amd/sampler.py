@@ -739,7 +739,7 @@ class Sampler:
             self._live = None      # log_v_live rebuilds it from the shells
         elif self.__dict__.get('_live') is not None:
             self._live.add(log_l_dev)
-        self.log_l[shell] = np.append(self.log_l[shell], log_l)
+        self.log_l[shell] = _grow(self.log_l[shell], log_l)
         if blobs is not None:                      # sampler.py:1137-1141
             if self.blobs is None:
                 self.blobs = [blobs]
@@ -1133,6 +1133,29 @@ class Sampler:
         widths = [9, 6, 8, 8, 8, 6, 5, 7]
         print(' | '.join('{:<{}}'.format(c, w)
                          for c, w in zip(cells, widths)), end=end, flush=True)
+
+
+def _grow(cur, new):
+    """``np.append(cur, new)`` for a 1-D float array that is appended to
+    batch after batch (sampler.py:1135-1136 re-allocates and copies the
+    whole shell every time: 10 MB per 65 536-point batch once a shell holds
+    10^6 values, 0.3 ms of the bench's step).  The result is a view of a
+    buffer with spare room; the next call writes behind it in place where
+    ``cur`` still is the leading view of such a buffer, and copies once into
+    a buffer of twice the size where it is not."""
+    new = np.asarray(new, dtype=float)
+    n, k = len(cur), len(new)
+    base = cur.base
+    if (isinstance(base, np.ndarray) and base.ndim == 1 and
+            base.dtype == cur.dtype == np.float64 and base.flags.owndata and
+            base.flags.writeable and base.size >= n + k and
+            cur.ctypes.data == base.ctypes.data and cur.strides == (8,)):
+        base[n:n + k] = new
+        return base[:n + k]
+    buf = np.empty(max(2 * (n + k), 1024), dtype=np.float64)
+    buf[:n] = cur
+    buf[n:n + k] = new
+    return buf[:n + k]
 
 
 def device_block():

@@ -307,3 +307,33 @@ def test_native_shuffle_streams_equal_numpy():
                     ref[i].shuffle(idx)
                     orders[i] = orders[i][idx]
                 assert np.array_equal(rows[ep], orders[i]), (rnd, i, ep)
+
+
+def test_amortised_host_append_equals_np_append():
+    """``sampler._grow`` (the shells' log L on the host grow batch by batch,
+    sampler.py:1135-1136): the same values as ``np.append`` whatever happens
+    to the array in between (boolean masks as in add_bound, other views), and
+    views handed out earlier keep their values."""
+    from nautilus_amd.sampler import _grow
+    rng = np.random.default_rng(0)
+    a = np.zeros(0)
+    ref = np.zeros(0)
+    held = []
+    for i in range(300):
+        new = rng.random(int(rng.integers(0, 40)))
+        a = _grow(a, new)
+        ref = np.append(ref, new)
+        assert np.array_equal(a, ref)
+        if i % 37 == 0:
+            held.append((a, a.copy()))
+        if i % 53 == 0:
+            keep = rng.random(len(a)) < 0.5
+            a, ref = a[keep], ref[keep]
+    for view, copy in held:
+        assert np.array_equal(view, copy)
+    # not the leading view of a buffer: copied, never written behind
+    base = np.arange(10.0)
+    tail = base[2:6]
+    out = _grow(tail, [7.0])
+    assert np.array_equal(out, [2, 3, 4, 5, 7]) and base[6] == 6.0
+    assert np.array_equal(_grow(np.arange(5.0)[::2], [1.0]), [0, 2, 4, 1])
