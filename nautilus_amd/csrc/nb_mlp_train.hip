@@ -33,6 +33,7 @@
 #include <vector>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 namespace {
 
@@ -163,6 +164,17 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// v of the lane n places further on in its row of 16 lanes (row_ror: a DPP
+// operand modifier, no LDS traffic -- __shfl_xor is ds_bpermute and sits in
+// front of the next workgroup barrier's counter wait)
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <int NREG>
 __device__ __forceinline__ void lds_operand(const double* act, int lane,
                                             double* in) {
@@ -173,6 +185,11 @@ __device__ __forceinline__ void lds_operand(const double* act, int lane,
   for (int ks = 0; ks < NREG; ++ks)
     in[ks] = act[(16 * (ks >> 2) + 8 * ((ks >> 1) & 1) + 2 * lg + (ks & 1)) *
                      LS + li];
+  // ALL reads leave before the stage's first MFMA.  (Left alone the scheduler
+  // sinks every read to one MFMA ahead of its use to shorten live ranges: 64
+  // cycles of cover for an LDS latency of 100-130, and the chains of the
+  // layers 1, 2 and delta 1 -- 26-28 MFMAs -- ran at ~115 cycles per MFMA.)
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // The stash of one matrix (activations or deltas of a layer, `ld` units padded
@@ -218,11 +235,26 @@ __device__ __forceinline__ void flush_wave(const double* act, nb_gd* dst,
   const unsigned li = lane & 15, lg = lane >> 4;
   nb_gd* row = dst + (tile * 16) * ld + lane * 2;    // stash_index
   const double* src = act + li * LS + 2 * lg;
+  // the LDS reads of up to eight stores leave together (left to the
+  // scheduler every store waited for its own read: one LDS latency per KB)
+  constexpr int NC = N_UNIT / 8, CH = 8;
 #pragma unroll
-  for (int c = 0; c < N_UNIT / 8; ++c) {             // c = 2 ut + h
-    const nb_d2 v = {src[(c >> 1) * 16 * LS + (c & 1) * 8],
+  for (int c0 = 0; c0 < NC; c0 += CH) {
+    nb_d2 v[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {                   // c = 2 ut + h
+      const int c = c0 + i;
+      if (c < NC)
+        v[i] = nb_d2{src[(c >> 1) * 16 * LS + (c & 1) * 8],
                      src[(c >> 1) * 16 * LS + (c & 1) * 8 + 1]};
-    *(NB_G nb_d2*)(row + c * 128) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = c0 + i;
+      if (c < NC) *(NB_G nb_d2*)(row + c * 128) = v[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -245,6 +277,29 @@ __device__ __forceinline__ void load_ops(__amdgpu_buffer_rsrc_t rsrc,
     wr[2 * p] = v.x;
     wr[2 * p + 1] = v.y;
   }
+}
+
+// Pair p of the operands above, of the full tile (sub < 0) or of ONE 4-unit
+// sub-tile of it (output rows 4 sub .. 4 sub + 3): the
+// operand of v_mfma_f64_4x4x4_4b, whose four blocks are the four groups of
+// four points of the 16-row tile and all take the same A -- replicated by the
+// load (lane = point group * 4 + row, k = lane / 16; the instruction has no
+// broadcast of its own for f64: profiles/tools/mfma_map.hip).  One such
+// instruction takes 16 cycles, a 16x16x4 one 64, and its result is register
+// `sub` of the tile's accumulator BIT FOR BIT (profiles/tools/
+// mfma_subtile.hip), so the small layers -- 20 + 1 units in layer 3, one
+// output -- run on the sub-tiles that exist instead of on padded tiles.
+template <int TSTRIDE>
+__device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t rsrc,
+                                          unsigned tile0, unsigned lane,
+                                          int sub, int p, double* wr) {
+  const unsigned voff =
+      sub < 0 ? lane * 16 : ((lane >> 4) * 16 + 4 * sub + (lane & 3)) * 16;
+  const nb_d2 v = ld_xcd2(
+      rsrc, voff,
+      (tile0 + (unsigned)((p >> 1) * TSTRIDE * NB_TILE + (p & 1) * 128)) * 8);
+  wr[2 * p] = v.x;
+  wr[2 * p + 1] = v.y;
 }
 
 // ... of layer 1: only the pairs of the last k-tile depend on n_dim
@@ -279,22 +334,72 @@ __device__ __forceinline__ nb_d4 mma(const double* wr, const double* in) {
   return acc0;
 }
 
-// ... with a runtime number of k-steps in the last k-tile (same order of
-// summation: even k-steps into one accumulator, odd ones into the other)
-template <int N>
-__device__ __forceinline__ nb_d4 mma_l1(const double* wr, const double* in,
-                                        int ks_n) {
+// ... with `hook(p)` behind the p-th pair of MFMAs, pinned there: the operand
+// loads of LATER stages are issued from inside the chain, one or two per 128
+// cycles of matrix work.  (In front of the chain their issue delays its
+// first MFMA; behind it, the arrival at the stage's barrier; and wherever the
+// source puts them the scheduler moves them to the end of the chain unless
+// told otherwise.)
+template <int N, class Hook>
+__device__ __forceinline__ nb_d4 mma_hook(const double* wr, const double* in,
+                                          Hook&& hook) {
+  static_assert(N % 2 == 0, "pairs");
   nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
-  for (int k = 0; k < N - 4; k += 2) {
+  for (int k = 0; k < N; k += 2) {
     acc0 = MFMA(wr[k], in[k], acc0);
     acc1 = MFMA(wr[k + 1], in[k + 1], acc1);
+    __builtin_amdgcn_sched_barrier(0);
+    hook(k >> 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+  return acc0;
+}
+
+// ... of a sub-tile (same order of summation)
+template <int N>
+__device__ __forceinline__ double mma4(const double* wr, const double* in) {
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+  for (int k = 0; k + 1 < N; k += 2) {
+    acc0 = MFMA4(wr[k], in[k], acc0);
+    acc1 = MFMA4(wr[k + 1], in[k + 1], acc1);
+  }
+  if (N & 1) acc0 = MFMA4(wr[N - 1], in[N - 1], acc0);
+  return acc0 + acc1;
+}
+
+// ... of layer 1: a runtime number of k-steps in the last k-tile (same order
+// of summation: even k-steps into one accumulator, odd ones into the other),
+// a hook behind every pair (mma_hook)
+template <int N, class Hook>
+__device__ __forceinline__ nb_d4 mma_l1_hook(const double* wr, const double* in,
+                                             int ks_n, bool run, Hook&& hook) {
+  nb_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  // (a wavefront without this tile only issues the loads: run == false)
+  if (!run) ks_n = 0;
+#pragma unroll
+  for (int k = 0; k < N - 4; k += 2) {
+    if (run) {
+      acc0 = MFMA(wr[k], in[k], acc0);
+      acc1 = MFMA(wr[k + 1], in[k + 1], acc1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    hook(k >> 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int k = N - 4; k < N; ++k) {
     if (k < ks_n) {
       if (k & 1) acc1 = MFMA(wr[k], in[k], acc1);
       else acc0 = MFMA(wr[k], in[k], acc0);
+    }
+    if (k & 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      hook(k >> 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -464,15 +569,28 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
 
   // ---- weight operands: every wavefront loads the A operands of ITS output
   // tiles straight into registers (wave-uniform tile address + lane offset,
-  // one contiguous 512-byte row block per operand), a layer or more ahead of
-  // their use; nothing else sits in the memory queue in front of them -- the
-  // stash stores of the step are issued at the very end. ---------------------
-  double w1r[2][KS1], w2r[26], w3r[14], w4r[6], b4r[2], b3r[6], b2r[2][14];
+  // one contiguous 512-byte row block per operand).  A CU takes one such 1 KB
+  // load per ~16-20 cycles and the first data is ~1.5 k cycles away, so WHERE
+  // the ~70 loads of a wavefront are issued is what the pass costs: up here
+  // only those of layer 1's first tile (all 29 of layer 1 and 2, as until
+  // round 5, took ~1.8 k cycles to issue with the input block waiting behind
+  // them); everything else leaves from inside the MFMA chains (mma_hook), a
+  // stage or more ahead of its use, and never behind a stage's products,
+  // where the issue time went straight into the arrival at the barrier.
+  // Unconditionally in every wavefront: behind a branch the compiler no
+  // longer knows how many loads are in flight and the next wait is for all of
+  // them.  The stash stores of the step go last. ------------------------------
+  double w1r[2][KS1], w2r[26], w3r[2][14], w4r[6], b4r[2][2], b3r[6], b2r[2][14];
+  // 4-unit sub-tiles of layer 3 (and of delta 3): NB_H3 units, the bias unit
+  // behind them is a constant; wavefront w takes the sub-tiles w, w + 4
+  constexpr int NSUB3 = (NB_H3 + 3) / 4;
+  // unit tiles of the layer-1 activations that leave during layer 3 (the
+  // others during the output layer)
+  constexpr int L1_SPLIT = 3;
+  static_assert(NSUB3 <= 8 && 4 * NSUB3 <= LD3, "two sub-tiles per wavefront");
   const int ht1b = (wave + 4 < NB_HT1) ? wave + 4 : wave;
   load_ops_l1<KT1>(rW, W1 + wave * NB_TILE, ks1, lane, w1r[0]);
-  load_ops_l1<KT1>(rW, W1 + ht1b * NB_TILE, ks1, lane, w1r[1]);
-  if constexpr (KT1 <= 4)
-    load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- input block: k-step ks is handled by wavefront ks % 4 -------------
 #pragma unroll
@@ -481,18 +599,35 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
         fb_input(rows.x[j], 4 * (4 * j + wave) + lg, a.n_dim, valid);
   lds_barrier();
   FB_STAMP(11);
-  if constexpr (KT1 == 5)
-    load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
 
-  // ---- layer 1: output tiles wave, wave + 4 ------------------------------
+  // ---- layer 1: output tiles wave, wave + 4.  The second tile's operands
+  // leave from the first half of the first chain, layer 2's from there on to
+  // the end of the second (a wavefront without a second tile only issues
+  // them) -- also the pairs past n_dim's last k-step, which no MFMA uses.
+  // (Measured alternatives, profiles/r05/train_fb_schedule.txt: the second
+  // tile's operands up front with the first's; layer 2's all in the first
+  // chain: 1-2 % slower.) ------------------------------------------------------
   {
     double in[KS1];
     lds_operand<KS1>(sA0, lane, in);
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int ht = wave + 4 * rep;
-      if (ht < NB_HT1) {
-        const nb_d4 acc = mma_l1<KS1>(w1r[rep], in, ks1);
+      const bool run = ht < NB_HT1;
+      constexpr int NS = KS1 / 2, H = (NS + 1) / 2, NW = 2 * NS - H;
+      const nb_d4 acc = mma_l1_hook<KS1>(w1r[rep], in, ks1, run, [&](int p) {
+        const int q = rep * NS + p;
+        if (q < H) {
+#pragma unroll
+          for (int i = NS * q / H; i < NS * (q + 1) / H; ++i)
+            load_pair<NB_HT1>(rW, W1 + ht1b * NB_TILE, lane, -1, i, w1r[1]);
+        } else {
+#pragma unroll
+          for (int i = 13 * (q - H) / NW; i < 13 * (q - H + 1) / NW; ++i)
+            load_pair<NB_HT2>(rW, W2 + wave * NB_TILE, lane, -1, i, w2r);
+        }
+      });
+      if (run) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double v = fmax(acc[r], 0.0);
@@ -501,32 +636,38 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
           sA1[unit * LS + li] = v;
         }
       }
-      // (beyond 80 dimensions the operands of layer 2 are loaded into the
-      // registers the first tile's have left, a tile's chain ahead of their
-      // use: all at once they did not fit and the spills' reloads waited for
-      // the whole memory queue)
-      if constexpr (KT1 > 5) {
-        if (rep == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          load_ops<26, NB_HT2>(rW, W2 + wave * NB_TILE, lane, w2r);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
     }
   }
   lds_barrier();
   FB_STAMP(12);
   // the remaining operands, in the order of use (in flight during layer 2)
-  load_ops<14, NB_HT3>(rW, W3 + (wave & 1) * NB_TILE, lane, w3r);
-  load_ops<6, 1>(rW, W4, lane, w4r);
-  load_ops<2, NB_HT3>(rT, T4 + (wave & 1) * NB_TILE, lane, b4r);
-  load_ops<6, NB_HT2>(rT, T3 + wave * NB_TILE, lane, b3r);
-
-  // ---- layer 2: output tile = wave ----------------------------------------
+  // ---- layer 2: output tile = wave.  The operands of the stages that
+  // follow are loaded from inside its chain: layer 3's sub-tiles in the first
+  // seven pairs, the output layer's and those of delta 3 / delta 2 behind
+  // them, into registers the chain has left.  (UNCONDITIONAL loads -- a
+  // wavefront without a second sub-tile loads the last one again: behind a
+  // branch the compiler no longer knows how many loads are in flight and
+  // makes the next MFMA wait for all of them.) ----------------------------------
   {
+    const int sb0 = wave, sb1 = (wave + 4 < NSUB3) ? wave + 4 : NSUB3 - 1;
     double in[26];
     lds_operand<26>(sA1, lane, in);
-    const nb_d4 acc = mma<26>(w2r, in);
+    const nb_d4 acc = mma_hook<26>(w2r, in, [&](int p) {
+      if (p < 7) {
+        load_pair<NB_HT3>(rW, W3 + (sb0 >> 2) * NB_TILE, lane, sb0 & 3, p,
+                          w3r[0]);
+        load_pair<NB_HT3>(rW, W3 + (sb1 >> 2) * NB_TILE, lane, sb1 & 3, p,
+                          w3r[1]);
+      } else if (p < 10) {
+        load_pair<1>(rW, W4, lane, 0, p - 7, w4r);
+        load_pair<NB_HT2>(rT, T3 + wave * NB_TILE, lane, -1, p - 7, b3r);
+      } else if (p == 10) {
+        load_pair<NB_HT3>(rT, T4 + (sb0 >> 2) * NB_TILE, lane, sb0 & 3, 0,
+                          b4r[0]);
+        load_pair<NB_HT3>(rT, T4 + (sb1 >> 2) * NB_TILE, lane, sb1 & 3, 0,
+                          b4r[1]);
+      }
+    });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double v = fmax(acc[r], 0.0);
@@ -537,43 +678,50 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   }
   lds_barrier();
   FB_STAMP(13);
-  // (the operands of the last backward product take the registers layer 2's
-  // have left; five stages until they are needed)
-  load_ops<14, NB_HT1>(rT, T2 + wave * NB_TILE, lane, b2r[0]);
-  load_ops<14, NB_HT1>(rT, T2 + ht1b * NB_TILE, lane, b2r[1]);
 
   // ---- layer 3: two output tiles; the other two wavefronts send the blocks
   // that are complete to the stash (their weight operands are all older than
   // these stores in the in-order memory queue: nothing ever waits for them) ---
-  if (wave == 2) flush_wave<LD1>(sA1, sp.A1, LD1, tile, lane);
-  if (wave == 3) {
-    flush_wave<LD2>(sA2, sp.A2, LD2, tile, lane);
-    flush_wave<LD0>(sA0, sp.A0, LD0, tile, lane);
-  }
-  if (wave < NB_HT3) {
+  {
     double in[14];
     lds_operand<14>(sA2, lane, in);
-    const nb_d4 acc = mma<14>(w3r, in);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double v = fmax(acc[r], 0.0);
-      const int unit = 16 * wave + 4 * r + lg;
-      if (unit == NB_H3) v = 1.0;
-      sA3[unit * LS + li] = v;
+    for (int rep = 0; rep < 2; ++rep) {
+      const int sb = wave + 4 * rep;
+      if (sb < NSUB3) {
+        double v = fmax(mma4<14>(w3r[rep], in), 0.0);
+        const int unit = 4 * sb + lg;
+        if (unit == NB_H3) v = 1.0;
+        sA3[unit * LS + li] = v;
+      }
+    }
+    // the units behind the sub-tiles: the bias unit and the padding
+    if (wave == 3) {
+#pragma unroll
+      for (int unit = 4 * NSUB3 + lg; unit < LD3; unit += 4)
+        sA3[unit * LS + li] = (unit == NB_H3) ? 1.0 : 0.0;
     }
   }
+  // (behind their sub-tile: the wavefronts with one sub-tile have the time
+  // of wavefront 0's second one)
+  if (wave == 1) flush_wave<LD0>(sA0, sp.A0, LD0, tile, lane);
+  if (wave == 2) flush_wave<LD2>(sA2, sp.A2, LD2, tile, lane);
+  if (wave == 3) flush_wave<L1_SPLIT * 16>(sA1, sp.A1, LD1, tile, lane);
   lds_barrier();
   FB_STAMP(14);
 
   // ---- output layer, delta 4, loss partial (wavefront 0) -------------------
   double lp = 0.0;
   if (wave == 1) flush_wave<LD3>(sA3, sp.A3, LD3, tile, lane);
+  if (wave == 2)
+    flush_wave<LD1 - L1_SPLIT * 16>(sA1 + L1_SPLIT * 16 * LS,
+                                    sp.A1 + L1_SPLIT * 256, LD1, tile, lane);
   if (wave == 0) {
     double in[6];
     lds_operand<6>(sA3, lane, in);
-    const nb_d4 acc = mma<6>(w4r, in);
+    const double acc = mma4<6>(w4r, in);
     double d40 = 0.0;
-    if (lg == 0 && valid) d40 = acc[0] - rows.yv;    // sklearn :365
+    if (lg == 0 && valid) d40 = acc - rows.yv;       // sklearn :365
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int unit = 4 * r + lg;
@@ -581,25 +729,45 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
       sD4[unit * LS + li] = v;
     }
     lp = 0.5 * d40 * d40;
-    for (int s = 8; s >= 1; s >>= 1) lp += __shfl_xor(lp, s);
+    // sum over the 16 rows of the tile in the order of the xor butterfly
+    // (8, 4, 2, 1): after the step of distance d the values have period d in
+    // the row, so the lane d places further on holds what lane ^ d holds
+    lp += row_ror<8>(lp);
+    lp += row_ror<4>(lp);
+    lp += row_ror<2>(lp);
+    lp += row_ror<1>(lp);
   }
+  // the operands of delta 1's first tile, three short stages ahead of their
+  // use and behind this stage's work of every wavefront.  (A CU takes one 1 KB
+  // load per ~20 cycles: the 14 loads of all four wavefronts behind layer 3,
+  // where they were, made that stage wait for their issue.)
+  __builtin_amdgcn_sched_barrier(0);
+  load_ops<14, NB_HT1>(rT, T2 + wave * NB_TILE, lane, b2r[0]);
+  __builtin_amdgcn_sched_barrier(0);
   lds_barrier();
   FB_STAMP(15);
 
   // ---- delta 3 (ReLU mask = activation == 0; bias unit carries none) ------
-  if (wave == 2) flush_wave<LD4>(sD4, sp.D4, LD4, tile, lane);
-  if (wave < NB_HT3) {
+  {
     double dout[2];
     lds_operand<2>(sD4, lane, dout);
-    const nb_d4 acc = mma<2>(b4r, dout);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int unit = 16 * wave + 4 * r + lg;
-      double v = acc[r];
-      if (sA3[unit * LS + li] == 0.0 || unit == NB_H3) v = 0.0;
-      sD3[unit * LS + li] = v;
+    for (int rep = 0; rep < 2; ++rep) {
+      const int sb = wave + 4 * rep;
+      if (sb < NSUB3) {
+        const int unit = 4 * sb + lg;
+        double v = mma4<2>(b4r[rep], dout);
+        if (sA3[unit * LS + li] == 0.0 || unit == NB_H3) v = 0.0;
+        sD3[unit * LS + li] = v;
+      }
+    }
+    if (wave == 3) {
+#pragma unroll
+      for (int unit = 4 * NSUB3 + lg; unit < LD3; unit += 4)
+        sD3[unit * LS + li] = 0.0;
     }
   }
+  if (wave == 2) flush_wave<LD4>(sD4, sp.D4, LD4, tile, lane);
   lds_barrier();
   FB_STAMP(16);
 
@@ -627,6 +795,11 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   // ticks per round trip) that fits into the time the others need for their
   // second tile, and the early jobs start ~1.2 k ticks sooner (with the
   // counters far away this order made wavefront 3 the last of the stage) ------
+  // (the second tile's operands: its chain starts a tile's chain from here.
+  // In front of the wait for the stores that wait would be for them; between
+  // that wait and the barrier: measured no better)
+  load_ops<14, NB_HT1>(rT, T2 + ht1b * NB_TILE, lane, b2r[1]);
+  __builtin_amdgcn_sched_barrier(0);
   if (wave == 3) {
     flush_wave<LD3>(sD3, sp.D3, LD3, tile, lane);
     flush_wave<LD2>(sD2, sp.D2, LD2, tile, lane);
