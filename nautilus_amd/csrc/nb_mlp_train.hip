@@ -11,9 +11,11 @@
 //      forward through the four layers (the output tiles of a layer are split
 //      over the wavefronts, activations / deltas are exchanged through LDS in
 //      [unit][row] layout), output delta, backward deltas through W^T read
-//      from the same 16x16 tile-major weights; every weight operand is
-//      loaded before the first barrier; activations and deltas go to a stash
-//      in global memory (L2 resident, ~0.8 MB per network; stash_index).
+//      from transposed copies of the tiles; weight operands go straight into
+//      registers, issued from inside the MFMA chains of the stages before
+//      their use (mma_hook); the small layers run on 4-unit sub-tiles
+//      (v_mfma_f64_4x4x4_4b); activations and deltas go to a stash in global
+//      memory (L2 resident, ~0.8 MB per network; stash_index).
 //  G   one workgroup of four wavefronts per 16x16 weight tile: dW = act^T delta
 //      over the rows of the minibatch, wavefront q contracting two k-steps of
 //      every other 16-row tile; the four partial tiles meet in LDS, are added in a
@@ -610,16 +612,27 @@ __device__ __forceinline__ void fb_body(const TrainArgs& a, const NetState& st,
   {
     double in[KS1];
     lds_operand<KS1>(sA0, lane, in);
+#ifdef NB_W1B_BEHIND_INPUT
+    // second tile's operands while the first chain waits for its own
+#pragma unroll
+    for (int i = 0; i < KS1 / 2; ++i)
+      load_pair<NB_HT1>(rW, W1 + ht1b * NB_TILE, lane, -1, i, w1r[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int ht = wave + 4 * rep;
       const bool run = ht < NB_HT1;
+#ifdef NB_W1B_BEHIND_INPUT
+      constexpr int NS = KS1 / 2, H = 0, NW = 2 * NS - H;
+#else
       constexpr int NS = KS1 / 2, H = (NS + 1) / 2, NW = 2 * NS - H;
+#endif
       const nb_d4 acc = mma_l1_hook<KS1>(w1r[rep], in, ks1, run, [&](int p) {
         const int q = rep * NS + p;
         if (q < H) {
 #pragma unroll
-          for (int i = NS * q / H; i < NS * (q + 1) / H; ++i)
+          for (int i = NS * q / (H ? H : 1); i < NS * (q + 1) / (H ? H : 1); ++i)
             load_pair<NB_HT1>(rW, W1 + ht1b * NB_TILE, lane, -1, i, w1r[1]);
         } else {
 #pragma unroll
