@@ -609,11 +609,17 @@ class Sampler:
             else:
                 args = self.prior.unit_to_physical(points)
             ll = self.likelihood(args)
+            blobs = None
             if isinstance(ll, tuple):
-                raise NotImplementedError(
-                    'blobs are supported for host likelihoods only')
+                # a device likelihood's blobs are cuda tensors (or arrays) of
+                # one row per point; they join the host bookkeeping like a
+                # vectorized host likelihood's (sampler.py:875-904)
+                blobs = self._pack_blobs([
+                    b.cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+                    for b in ll[1:]])
+                ll = ll[0]
             self.n_like += ll.shape[0]
-            return ll.cpu().numpy(), ll, None
+            return ll.cpu().numpy(), ll, blobs
 
         if callable(self.prior):
             transform = self.prior
@@ -647,16 +653,53 @@ class Sampler:
             else:
                 blobs = [np.array([row[col] for row in blobs])
                          for col in range(n_col)]
-            if self.blobs_dtype is None:
-                if n_col > 1:
-                    self.blobs_dtype = [('blob_{}'.format(i), b.dtype)
-                                        for i, b in enumerate(blobs)]
-                else:
-                    self.blobs_dtype = blobs[0].dtype
-            blobs = np.squeeze(np.array(list(zip(*blobs)),
-                                        dtype=self.blobs_dtype))
+            blobs = self._pack_blobs(blobs)
         self.n_like += len(log_l)
         return log_l, torch.from_numpy(log_l).cuda(), blobs
+
+    def _pack_blobs(self, cols):
+        """The blob columns of one batch (one array per returned value, one
+        row per point) as the reference stores them: a plain array for one
+        column, a structured one for several (sampler.py:892-904)."""
+        if self.blobs_dtype is None:
+            if len(cols) > 1:
+                self.blobs_dtype = [('blob_{}'.format(i), b.dtype)
+                                    for i, b in enumerate(cols)]
+            else:
+                self.blobs_dtype = cols[0].dtype
+        return np.squeeze(np.array(list(zip(*cols)), dtype=self.blobs_dtype))
+
+    def _gather_blobs(self, blobs, n_local, interleaved_to=None):
+        """The blobs of a sharded batch follow their points: ``n_local`` rows
+        per rank travel as bytes through the same all-gather (rank-major, the
+        order ``gather_rows`` gives the points).  ``interleaved_to = n``: the
+        ranks evaluated rows r, r + world, ... of one batch of n points
+        (``_sharded_likelihood``), padded to n_local rows each; the rows come
+        back in the order of the batch."""
+        comm = self.comm
+        flat = np.ascontiguousarray(blobs).reshape(-1)
+        have = n_local if interleaved_to is None else len(
+            range(comm.rank, interleaved_to, comm.world))
+        dtype = flat.dtype
+        # (an empty share knows its dtype but not its row width: the widths
+        # of all ranks are reduced along)
+        width = flat.view(np.uint8).size // have if have > 0 else 0
+        width = int(comm.max_float(float(width), 'cuda'))
+        raw = np.zeros((n_local, width), dtype=np.uint8)
+        if have > 0:
+            raw[:have] = flat.view(np.uint8).reshape(have, width)
+        table = comm.gather_rows(
+            torch.from_numpy(raw).to(comm._dev('cuda'))).cpu().numpy()
+        if interleaved_to is not None:
+            table = np.ascontiguousarray(
+                table.reshape(comm.world, n_local, width).transpose(1, 0, 2)
+            ).reshape(-1, width)[:interleaved_to]
+        n = table.shape[0]
+        out = np.ascontiguousarray(table).reshape(-1).view(dtype)
+        tail = np.shape(blobs)[1:] if np.ndim(blobs) > 1 and have > 1 else ()
+        if not tail and out.size != n:
+            tail = (out.size // n,)
+        return out.reshape((n,) + tuple(tail))
 
     def update_shell_info(self, index):
         """sampler.py:910-943 with the reductions on the device."""
@@ -715,14 +758,14 @@ class Sampler:
                     self.blobs[-1] = np.concatenate(
                         (self.blobs[-1], self.blobs_t[idx_t]))
         elif self.comm is not None:
-            pts, log_l, log_l_dev, n_bound = self._sharded_batch(shell)
+            pts, log_l, log_l_dev, n_bound, blobs = self._sharded_batch(shell)
         else:
             pts, n_bound = self.sample_shell(shell)
         t1 = time()
         self.shell_n_sample[shell] += n_bound
         if log_l is None:
             if self.comm is not None and not self._device_likelihood:
-                log_l, log_l_dev = self._sharded_likelihood(pts)
+                log_l, log_l_dev, blobs = self._sharded_likelihood(pts)
             else:
                 log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
         t2 = time()
@@ -822,8 +865,7 @@ class Sampler:
         n_like0 = self.n_like
         _, ll_dev, blobs = self.evaluate_likelihood(pts)
         if blobs is not None:
-            raise NotImplementedError(
-                'blobs are not exchanged between ranks of a sharded run')
+            blobs = self._gather_blobs(blobs, pts.shape[0])
         self.n_like = n_like0
         if self.explored and self.filepath is None:
             # (collectives of one communicator run in the order of issue: the
@@ -834,14 +876,14 @@ class Sampler:
             handle = comm.gather_rows_async(pts)
             self.n_like += ll_dev.shape[0]
             return (_RowsInFlight(handle, ll_dev.shape[0]),
-                    ll_dev.cpu().numpy(), ll_dev, n_bound)
+                    ll_dev.cpu().numpy(), ll_dev, n_bound, blobs)
         packed = torch.cat([pts, ll_dev[:, None]], dim=1)
         gathered = comm.gather_rows(packed)
         n_bound, = self._sum_counters(bound, before, [n_bound])
         pts = gathered[:, :-1].contiguous()
         ll_dev = gathered[:, -1].contiguous()
         self.n_like += pts.shape[0]
-        return pts, ll_dev.cpu().numpy(), ll_dev, n_bound
+        return pts, ll_dev.cpu().numpy(), ll_dev, n_bound, blobs
 
     def _sharded_transfer_batch(self):
         """A batch of the newest shell while transfer candidates are waiting
@@ -878,14 +920,13 @@ class Sampler:
         n_like0 = self.n_like
         ll, _, blobs = self.evaluate_likelihood(mine)
         if blobs is not None:
-            raise NotImplementedError(
-                'blobs are not exchanged between ranks of a sharded run')
+            blobs = self._gather_blobs(blobs, per, interleaved_to=n)
         self.n_like = n_like0 + n
         padded = torch.zeros(per, dtype=torch.float64, device='cuda')
         padded[:len(ll)] = torch.from_numpy(ll).cuda()
         table = comm.gather_rows(padded[:, None]).reshape(comm.world, per)
         ll_dev = table.t().reshape(-1)[:n].contiguous()
-        return ll_dev.cpu().numpy(), ll_dev
+        return ll_dev.cpu().numpy(), ll_dev, blobs
 
     # ------------------------------------------------------------------
     # bounds

@@ -24,6 +24,7 @@ def host_like(x):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--host-likelihood', action='store_true')
+    ap.add_argument('--blobs', action='store_true')
     ap.add_argument('--n-networks', type=int, default=2)
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
@@ -62,6 +63,18 @@ def main():
     else:
         prior, like = unit_prior, GaussianLikelihood(np.full(d, 0.5),
                                                      np.eye(d) * 0.01)
+    if args.blobs:
+        # two blobs per point that say which point they belong to
+        plain = like
+        if args.host_likelihood:
+            def like(x):
+                return (plain(x), x[:, 0].astype(np.float32),
+                        (1000 * x[:, 1]).astype(np.int16))
+        else:
+            def like(x):
+                return (plain(x), x[:, 0].to(torch.float32),
+                        (1000 * x[:, 1]).to(torch.int16))
+            like.device = True
     s = Sampler(prior, like, n_dim=d, n_live=400, n_networks=args.n_networks,
                 vectorized=True, seed=args.seed, n_batch=400,
                 comm=comm)
@@ -72,6 +85,18 @@ def main():
     digest = hashlib.sha1(np.ascontiguousarray(state).tobytes()).hexdigest()
     comm.assert_identical([float(int(digest[:12], 16)), s.log_z, s.n_eff],
                           'cuda', 'sampler state')
+    blobs_follow = None
+    if args.blobs:
+        pts, _, _, blobs = s.posterior(return_blobs=True)
+        blobs_follow = bool(
+            len(pts) == len(blobs) and
+            np.all(pts[:, 0].astype(np.float32) == blobs['blob_0']) and
+            np.all((1000 * pts[:, 1]).astype(np.int16) == blobs['blob_1']))
+        n_blob = sum(len(b) for b in s.blobs)
+        comm.assert_identical([float(n_blob), float(blobs_follow)], 'cuda',
+                              'blobs')
+        blobs_follow = blobs_follow and n_blob == sum(
+            len(v) for v in s.log_l)
     if comm.rank == 0:
         nets = [n for b in s.bounds[1:] for nbd in b.neural_bounds
                 if nbd.emulator is not None
@@ -83,7 +108,8 @@ def main():
             shell_n_sample=[int(v) for v in s.shell_n_sample],
             shell_n=[int(v) for v in s.shell_n],
             n_networks=len(nets),
-            construction_identical=construction_identical)), flush=True)
+            construction_identical=construction_identical,
+            blobs_follow=blobs_follow)), flush=True)
     comm.barrier()
     dist.destroy_process_group()
 

@@ -60,6 +60,34 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(h1.wait(), all_rows)
     assert torch.equal(h2.wait(), 2.0 * all_rows)
     assert torch.equal(h1.wait(), all_rows)          # idempotent
+    # blobs of a sharded batch follow their points (sampler.py:875-904 for
+    # the layouts): rank-major like gather_rows, or interleaved like the host
+    # likelihood of a batch every rank holds
+    from types import SimpleNamespace
+    from nautilus_amd.sampler import Sampler
+    me = SimpleNamespace(comm=comm)
+    for dtype in (np.float32, [('a', '|S10'), ('b', np.int16)], (np.int64, 3)):
+        dt = np.dtype(dtype)
+
+        def blob_of(i):
+            if dt.names:
+                return (str(i).encode(), i)
+            return np.full(dt.shape, i) if dt.shape else i
+        base = dt.base if dt.shape else dt
+        mine_rows = range(rank * n_local, (rank + 1) * n_local)
+        local = np.array([blob_of(i) for i in mine_rows], dtype=base)
+        got = Sampler._gather_blobs(me, np.squeeze(local), n_local)
+        want = np.array([blob_of(i) for i in range(world * n_local)],
+                        dtype=base)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+        n = 7                                        # not a multiple of world
+        per = -(-n // world)
+        local = np.array([blob_of(i) for i in range(rank, n, world)],
+                         dtype=base)
+        got = Sampler._gather_blobs(me, np.squeeze(local), per,
+                                    interleaved_to=n)
+        want = np.array([blob_of(i) for i in range(n)], dtype=base)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
     # collective stop decision: true everywhere if true anywhere
     assert comm.any_flag(rank == 1) is True
     assert comm.any_flag(False) is False

@@ -199,6 +199,37 @@ def test_blob_conventions(case, vectorized, discard):
         assert np.all(pts[:, 1].astype(f32) == blobs[:, 1])
 
 
+@pytest.mark.parametrize('case', ['one', 'two', 'named'])
+def test_blobs_of_a_device_likelihood(case):
+    """A likelihood that runs on the device may return blobs as well (cuda
+    tensors, one row per point): they are kept like a vectorized host
+    likelihood's (reference sampler.py:875-904, tests/test_blobs.py)."""
+    import torch
+    from nautilus_amd import Sampler, unit_prior
+
+    def like(x):
+        assert x.is_cuda
+        ll = -torch.linalg.norm(x - 0.5, dim=-1) * 0.001
+        if case == 'one':
+            return ll, (10 * x[:, 0]).to(torch.int64)
+        return ll, x[:, 0].to(torch.float32), (1000 * x[:, 1]).to(torch.int16)
+    like.device = True
+    dtype = [('a', np.float32), ('b', np.int16)] if case == 'named' else None
+    s = Sampler(unit_prior, like, n_dim=2, n_live=200, vectorized=True,
+                n_networks=1, blobs_dtype=dtype, seed=5)
+    s.run(f_live=0.2, n_like_max=3000, discard_exploration=True)
+    pts, log_w, log_l, blobs = s.posterior(return_blobs=True)
+    assert len(pts) == len(blobs) > 0
+    if case == 'one':
+        assert blobs.dtype == np.int64
+        assert np.all((10 * pts[:, 0]).astype(np.int64) == blobs)
+    else:
+        a, b = ('a', 'b') if case == 'named' else ('blob_0', 'blob_1')
+        assert blobs[a].dtype == np.float32 and blobs[b].dtype == np.int16
+        assert np.all(pts[:, 0].astype(np.float32) == blobs[a])
+        assert np.all((1000 * pts[:, 1]).astype(np.int16) == blobs[b])
+
+
 def test_run_with_a_narrower_emulator_architecture():
     """``neural_network_kwargs=dict(hidden_layer_sizes=(64, 32, 16))`` (the
     reference passes it to MLPRegressor, neural.py:79-83): the run's emulators

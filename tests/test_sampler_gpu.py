@@ -377,6 +377,21 @@ def test_whole_run_sharded_over_two_ranks(extra):
     assert np.all(np.abs(f1 - f2) < 0.15)
 
 
+@pytest.mark.parametrize('extra', [('--blobs',),
+                                   ('--blobs', '--host-likelihood')])
+def test_blobs_of_a_sharded_run(extra):
+    """Blobs travel with their points between the ranks (reference
+    sampler.py:875-904, 1137-1141; the pool of the reference returns them
+    through its map): a whole run on two ranks with a device likelihood (every
+    rank evaluates its own share) and with a host likelihood (rows r, r +
+    world, ... of a batch every rank holds) -- every blob of the posterior
+    names its point, and all ranks hold the same blobs."""
+    two = _run_sharded(2, *extra)
+    assert two['ok'] and two['world'] == 2
+    assert two['blobs_follow'] is True
+    assert abs(two['log_z']) < 0.05
+
+
 def test_multimodal_mixture_evidence_and_mode_weights():
     """BASELINE config 4 in small: equal-weight isotropic mixture.  Exercises
     the multi-ellipsoid Union (K > 1 members, overlap-corrected draw) and
