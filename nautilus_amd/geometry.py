@@ -283,16 +283,9 @@ class _Mixture:
         self.logp = logp          # (2, n) cuda tensor from the device fit
 
 
-def _best_of_inits_host(points_t, random_state):
-    """scikit-learn itself -- only reached when every device restart reports
-    a degenerate fit (an empty cluster or a covariance that is not positive
-    definite): scikit-learn relocates empty clusters and may still succeed,
-    and it is the reference's own estimator for this step (union.py:185-187),
-    so it decides."""
-    from sklearn.mixture import GaussianMixture
-    with single_threaded_blas():
-        return GaussianMixture(n_components=2, n_init=N_INIT,
-                               random_state=random_state).fit(points_t)
+class DegenerateMixture(ValueError):
+    """Every restart of the two-component mixture fit ended with an empty
+    cluster or a covariance that is not positive definite."""
 
 
 def _best_of_inits(points_t, random_state):
@@ -303,7 +296,16 @@ def _best_of_inits(points_t, random_state):
     fits = [f for f in device.gmm_fit(points_t, n_init=N_INIT,
                                       seed=random_state) if not f['failed']]
     if not fits:
-        return _best_of_inits_host(points_t, random_state)
+        # scikit-learn's fit raises here as well (mixture/
+        # _gaussian_mixture.py, _compute_precision_cholesky: "Fitting the
+        # mixture model failed because some components have ill-defined
+        # empirical covariance"); nothing on this path falls back to the host
+        raise DegenerateMixture(
+            'Fitting the mixture model failed because some components have '
+            'ill-defined empirical covariance (for instance caused by '
+            'singleton or collapsed samples) in every one of the %d device '
+            'restarts (%d points, %d dimensions).' %
+            (N_INIT, points_t.shape[0], points_t.shape[1]))
     best = max(fits, key=lambda f: f['lower_bound'])
     return _Mixture(best['weights'], best['means'], best['covariances'],
                     best['lower_bound'], best['logp'])
@@ -317,14 +319,7 @@ def two_component_labels(points_t, n_points_min, random_state):
     weighted log probabilities of its final parameters on the device; only
     2 n doubles come back."""
     gmm = _best_of_inits(points_t, random_state)
-    logp_dev = getattr(gmm, 'logp', None)
-    if logp_dev is not None:
-        logp = logp_dev.t().cpu().numpy()
-    else:                 # the scikit-learn fallback of _best_of_inits_host
-        from scipy.stats import multivariate_normal
-        logp = np.vstack([multivariate_normal.logpdf(
-            points_t, mean=gmm.means_[i], cov=gmm.covariances_[i]) +
-            np.log(gmm.weights_[i]) for i in range(2)]).T
+    logp = gmm.logp.t().cpu().numpy()
     labels = np.argmax(logp, axis=1)
     if not np.all(np.bincount(labels, minlength=2) >= n_points_min):
         small = np.argmin(np.bincount(labels, minlength=2))

@@ -596,9 +596,12 @@ class Sampler:
                 swap[self.rng.choice(fresh, size=m, replace=False)] = True
         return x[torch.from_numpy(~swap).cuda()], idx_t
 
-    def evaluate_likelihood(self, points):
+    def evaluate_likelihood(self, points, fetch=True):
         """sampler.py:832-908.  ``points`` is a cuda tensor (n, n_dim);
-        returns (log_l numpy, log_l cuda tensor, blobs or None)."""
+        returns (log_l numpy, log_l cuda tensor, blobs or None).  ``fetch =
+        False``: a device likelihood's values stay on the device (None in
+        place of the numpy array) -- ``add_samples`` brings them to the host
+        together with the shell statistics, one wait instead of two."""
         if self._device_likelihood:
             args = points
             if callable(self.prior):
@@ -619,7 +622,7 @@ class Sampler:
                     for b in ll[1:]])
                 ll = ll[0]
             self.n_like += ll.shape[0]
-            return ll.cpu().numpy(), ll, blobs
+            return (ll.cpu().numpy() if fetch else None), ll, blobs
 
         if callable(self.prior):
             transform = self.prior
@@ -701,21 +704,29 @@ class Sampler:
             tail = (out.size // n,)
         return out.reshape((n,) + tuple(tail))
 
-    def update_shell_info(self, index):
-        """sampler.py:910-943 with the reductions on the device."""
+    def _shell_slice(self, index):
+        """The log L of shell ``index`` that count (device view), the number
+        of draws they come from and the offset of the view in the shell."""
         n_sample = self.shell_n_sample[index]
         if self._discard_exploration and self.explored:
             start = self.shell_end_exp[index]
             n_sample = n_sample - self.shell_n_sample_exp[index]
         else:
             start = 0
-        ll = self._ll_dev[index].view()[start:]
+        return self._ll_dev[index].view()[start:], n_sample, start
+
+    def update_shell_info(self, index, stats=None):
+        """sampler.py:910-943 with the reductions on the device (``stats``:
+        the result of ``device.shell_stats`` for the shell's current slice,
+        already on the host)."""
+        ll, n_sample, start = self._shell_slice(index)
         n = ll.shape[0]
         if len(self._shell_max) != len(self._ll_dev):     # resumed / unpickled
             self._shell_max = np.full(len(self._ll_dev), np.inf)
         self.shell_n[index] = n
         if n > 0:
-            st = device.shell_stats(ll).cpu().numpy()
+            st = (device.shell_stats(ll).cpu().numpy() if stats is None
+                  else stats)
             if start == 0:
                 self._shell_max[index] = st[2]
             self.shell_log_v[index] = (self.bounds[index].log_v +
@@ -767,7 +778,10 @@ class Sampler:
             if self.comm is not None and not self._device_likelihood:
                 log_l, log_l_dev, blobs = self._sharded_likelihood(pts)
             else:
-                log_l, log_l_dev, blobs = self.evaluate_likelihood(pts)
+                # (a device likelihood's values come to the host further
+                # down, in one transfer with the shell statistics)
+                log_l, log_l_dev, blobs = self.evaluate_likelihood(
+                    pts, fetch=self.comm is not None or not DEFER_FETCH)
         t2 = time()
         if isinstance(pts, _RowsInFlight):
             # sharded sampling phase: the rows are on their way to this rank
@@ -782,6 +796,12 @@ class Sampler:
             self._live = None      # log_v_live rebuilds it from the shells
         elif self.__dict__.get('_live') is not None:
             self._live.add(log_l_dev)
+        stats = None
+        if log_l is None:
+            view = self._shell_slice(shell)[0]
+            both = torch.cat([device.shell_stats(view), log_l_dev])
+            both = both.cpu().numpy()
+            stats, log_l = both[:4], both[4:]
         self.log_l[shell] = _grow(self.log_l[shell], log_l)
         if blobs is not None:                      # sampler.py:1137-1141
             if self.blobs is None:
@@ -789,7 +809,7 @@ class Sampler:
             else:
                 self.blobs[shell] = np.append(self.blobs[shell], blobs,
                                               axis=0)
-        self.update_shell_info(shell)
+        self.update_shell_info(shell, stats)
         t3 = time()
         self.timing['sample_shell'] += t1 - t0
         self.timing['likelihood'] += t2 - t1
@@ -1174,6 +1194,12 @@ class Sampler:
         widths = [9, 6, 8, 8, 8, 6, 5, 7]
         print(' | '.join('{:<{}}'.format(c, w)
                          for c, w in zip(cells, widths)), end=end, flush=True)
+
+
+# add_samples fetches a device likelihood's values together with the shell
+# statistics (one wait per batch instead of two; profiles/tools/step_ab.py
+# measures both)
+DEFER_FETCH = True
 
 
 def _grow(cur, new):
