@@ -18,6 +18,9 @@
 #define NB_TILE 256          // doubles in one 16x16 tile
 
 typedef double nb_d4 __attribute__((ext_vector_type(4)));
+// a pair of doubles at an 8-byte-aligned address: one 16-byte load
+// (global_load_dwordx4 needs dword alignment only) -- the rows of an odd n_dim
+typedef double nb_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // Pointers to global memory, typed as such for device code.  A pointer the
 // compiler cannot trace back to a kernel argument -- loaded from a descriptor

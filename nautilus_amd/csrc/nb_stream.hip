@@ -23,6 +23,8 @@
 //  * r^2 is reduced over the 4 lanes of a point with two xor-shuffles.
 #include "nb_common.h"
 
+#include <cstdlib>
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 namespace {
@@ -144,7 +146,12 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
           d[t][2 * j + 1] = (in ? v.y : 0.0) - cper[2 * j + 1];
         }
       }
-    } else {
+    } else if (n_dim >= 3) {
+      // odd n_dim: the rows are 8-byte aligned only.  global_load_dwordx4
+      // needs dword alignment, not 16 bytes, so the same pair loads work from
+      // an 8-byte-aligned address (nb_d2u); the pair that holds the row's
+      // last feature is read one element earlier -- (x[D-2], x[D-1]) -- so
+      // that nothing behind the array is touched.
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         const long long pt = (grp * TPW + t) * 16 + li;
@@ -153,10 +160,26 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
 #pragma unroll
         for (int j = 0; j < 2 * DT; ++j) {
           const int f = 8 * j + 2 * lg;
-          const double v0 = row[f < n_dim ? f : n_dim - 1];
-          const double v1 = row[f + 1 < n_dim ? f + 1 : n_dim - 1];
-          d[t][2 * j] = ((ok && f < n_dim) ? v0 : 0.0) - cper[2 * j];
-          d[t][2 * j + 1] = ((ok && f + 1 < n_dim) ? v1 : 0.0) - cper[2 * j + 1];
+          const bool full = f + 1 < n_dim, half = f + 1 == n_dim;
+          const nb_d2u v =
+              *(const nb_d2u*)(row + (full ? f : (half ? f - 1 : 0)));
+          const double v0 = half ? v.y : v.x;
+          d[t][2 * j] = ((ok && (full || half)) ? v0 : 0.0) - cper[2 * j];
+          d[t][2 * j + 1] = ((ok && full) ? v.y : 0.0) - cper[2 * j + 1];
+        }
+      }
+    } else {
+      // n_dim = 1: one 8-byte load per point (a pair load would reach in
+      // front of or behind the array)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const long long pt = (grp * TPW + t) * 16 + li;
+        const bool ok = pt < n;
+        const double v0 = x[ok ? pt : n - 1];
+#pragma unroll
+        for (int j = 0; j < 2 * DT; ++j) {
+          d[t][2 * j] = ((ok && j == 0 && lg == 0) ? v0 : 0.0) - cper[2 * j];
+          d[t][2 * j + 1] = 0.0 - cper[2 * j + 1];
         }
       }
     }
@@ -301,7 +324,8 @@ int launch_variant(const double* cvec, const double* tiles, int n_dim,
                    const double* x, long long n, unsigned char* mask,
                    hipStream_t stream) {
   if constexpr (DT <= 4) {
-    if ((n_dim & 1) && n >= 64)
+    static const bool dma = getenv("NB_STREAM_ODD_DMA") != nullptr;
+    if (dma && (n_dim & 1) && n >= 64)
       return launch_odd<DT, KL, SMALL>(cvec, tiles, n_dim, x, n, mask, stream);
   }
   // 4 tiles per wavefront while the operands fit the register file, one

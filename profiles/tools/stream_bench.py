@@ -7,7 +7,7 @@ def timeit(fn, n=10, warm=2):
     torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter()-t)/n
-for d in (20, 49, 50, 64, 100):
+for d in ([int(v) for v in sys.argv[1:]] or (20, 49, 50, 64, 100)):
     rng = np.random.default_rng(d)
     A = rng.normal(size=(d,d)); cov = A@A.T/d + np.eye(d); B = np.linalg.cholesky(cov*0.02)
     ell = bo.OEllipsoid.from_params(0.5*np.ones(d), B)
