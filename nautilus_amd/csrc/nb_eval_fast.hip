@@ -147,28 +147,16 @@ __device__ __forceinline__ void load_points_raw(
         raw[t][j] = *(const NB_G double2*)(row + (f < n_dim ? f : n_dim - 2));
       }
     }
-  } else if (n_dim >= 3) {
-    // odd n_dim: 16-byte loads from 8-byte-aligned rows (nb_tile.h,
-    // load_points); the pair with the row's last feature is (x[D-2], x[D-1])
+  } else {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const nb_gd* row = x + row_of[t] * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
-        const bool full = f + 1 < n_dim, half = f + 1 == n_dim;
-        const nb_d2u v =
-            *(const NB_G nb_d2u*)(row + (full ? f : (half ? f - 1 : 0)));
-        raw[t][j].x = half ? v.y : v.x;
-        raw[t][j].y = v.y;
+        raw[t][j].x = row[f < n_dim ? f : n_dim - 1];
+        raw[t][j].y = row[f + 1 < n_dim ? f + 1 : n_dim - 1];
       }
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const double v0 = x[row_of[t]];
-#pragma unroll
-      for (int j = 0; j < 2 * DT; ++j) raw[t][j] = double2{v0, v0};
     }
   }
 }

@@ -19,11 +19,14 @@
 //    (8j + 2lg, 8j + 2lg + 1) of point li -- 64 contiguous bytes per point and
 //    instruction -- and the K index of the MFMA is permuted to match (the
 //    host packs the tiles with the same permutation), so no transpose is
-//    needed anywhere;
+//    needed anywhere.  Rows of an odd n_dim are 8-byte aligned only; the
+//    same pair loads work there (global_load_dwordx4 needs dword alignment):
+//    0.55 of the HBM peak at n_dim 49 against 0.62 at 50, where a kernel
+//    that staged 16-point blocks in LDS (global_load_lds) and gathered the
+//    operands with 8-byte LDS reads reached 0.47
+//    (profiles/r05/fifth_session/stream_odd_ab.txt);
 //  * r^2 is reduced over the 4 lanes of a point with two xor-shuffles.
 #include "nb_common.h"
-
-#include <cstdlib>
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
@@ -197,137 +200,10 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
   }
 }
 
-// Odd n_dim: rows are only 8-byte aligned, so the 16-byte row loads above are
-// not available.  A group of 16 points is still one contiguous, 16-byte
-// aligned block of 16 * D doubles: every wavefront DMAs its block into LDS
-// (global_load_lds, fully coalesced, double buffered -- the next block is in
-// flight while the current one is multiplied) and gathers the B operands
-// from there; an odd row stride spreads the points over the LDS banks.
-// EIGHT wavefronts x one tile per workgroup: a wavefront has one block in
-// flight and waits for it before it computes, so the memory latency is
-// covered by the other wavefront of its SIMD (four wavefronts x two tiles:
-// 0.40 of the HBM peak at n_dim = 49).
-typedef const void __attribute__((address_space(1))) * nbs_gptr;
-typedef void __attribute__((address_space(3))) * nbs_lptr;
-
-constexpr int ODD_TPW = 1;     // tiles per wavefront
-constexpr int ODD_NW = 8;      // wavefronts per workgroup
-
-template <int DT, int KL, bool SMALL>
-__global__ void __launch_bounds__(64 * ODD_NW)
-nb_ell_stream_odd_kernel(const double* __restrict__ cvec,
-                         const double* __restrict__ tiles, int n_dim,
-                         const double* __restrict__ x, long long n,
-                         unsigned char* __restrict__ mask, int bufsz) {
-  constexpr int TPW = ODD_TPW;
-  constexpr int NT = DT * (DT + 1) / 2;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* wl = lds;
-  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 2 * 64 * ODD_NW)
-    *(double2*)(wl + i) = *(const double2*)(tiles + i);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-  double* mybuf = lds + NT * NB_TILE + wave * 2 * bufsz;
-  const int blk = 16 * TPW * n_dim;          // doubles of one group of points
-  const long long total = n * n_dim;
-
-  double cper[4 * DT];
-#pragma unroll
-  for (int j = 0; j < 2 * DT; ++j) {
-    const int f = 8 * j + 2 * lg;
-    cper[2 * j] = cvec[f];
-    cper[2 * j + 1] = cvec[f + 1];
-  }
-
-  const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
-  const long long g0 = (long long)blockIdx.x * ODD_NW + wave;
-  const long long gstep = (long long)gridDim.x * ODD_NW;
-  auto issue = [&](long long grp, int b) {
-    const long long base = grp * blk;
-    for (int c = 0; c < blk; c += 128) {
-      const long long off = base + c + 2 * lane;
-      double* dst = mybuf + b * bufsz + c;
-      if (off + 1 < total) {
-        __builtin_amdgcn_global_load_lds((nbs_gptr)(x + off), (nbs_lptr)dst,
-                                         16, 0, 0);
-      } else if (off < total) {
-        dst[2 * lane] = x[off];          // last element of an odd-sized array
-      }
-    }
-  };
-  if (g0 < n_groups) issue(g0, 0);
-  int b = 0;
-  for (long long grp = g0; grp < n_groups; grp += gstep, b ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (grp + gstep < n_groups) issue(grp + gstep, b ^ 1);
-    const double* buf = mybuf + b * bufsz;
-    double d[TPW][4 * DT];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const double* row = buf + (t * 16 + li) * n_dim;
-#pragma unroll
-      for (int j = 0; j < 2 * DT; ++j) {
-        const int f = 8 * j + 2 * lg;
-        const double v0 = row[f < n_dim ? f : 0];
-        const double v1 = row[f + 1 < n_dim ? f + 1 : 0];
-        d[t][2 * j] = (f < n_dim ? v0 : 0.0) - cper[2 * j];
-        d[t][2 * j + 1] = (f + 1 < n_dim ? v1 : 0.0) - cper[2 * j + 1];
-      }
-    }
-    double part[TPW];
-    stream_quadform<DT, TPW, KL, SMALL>(wl, n_dim, lane, d, part);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      double r2 = part[t];
-      r2 += __shfl_xor(r2, 16);
-      r2 += __shfl_xor(r2, 32);
-      const long long pt = (grp * TPW + t) * 16 + li;
-      if (lg == 0 && pt < n) mask[pt] = (r2 < 1.0) ? 1 : 0;
-    }
-  }
-}
-
-template <int DT, int KL, bool SMALL>
-int launch_odd(const double* cvec, const double* tiles, int n_dim,
-               const double* x, long long n, unsigned char* mask,
-               hipStream_t stream) {
-  constexpr int NT = DT * (DT + 1) / 2;
-  const int bufsz = (16 * ODD_TPW * n_dim + 127) & ~127;
-  const size_t lds = ((size_t)NT * NB_TILE + 2 * ODD_NW * (size_t)bufsz) *
-                     sizeof(double);
-  static size_t allowed = 0;
-  if (lds > allowed) {
-    if (hipFuncSetAttribute((const void*)nb_ell_stream_odd_kernel<DT, KL, SMALL>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      nb_set_error("hipFuncSetAttribute(%zu bytes LDS) failed", lds);
-      return NB_ERR_HIP;
-    }
-    allowed = lds;
-  }
-  (void)hipGetLastError();
-  const long long n_groups = (n + 16 * ODD_TPW - 1) / (16 * ODD_TPW);
-  long long blocks = (n_groups + ODD_NW - 1) / ODD_NW;
-  if (blocks > 256) blocks = 256;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((nb_ell_stream_odd_kernel<DT, KL, SMALL>),
-                     dim3((unsigned)blocks), dim3(64 * ODD_NW), lds, stream, cvec,
-                     tiles, n_dim, x, n, mask, bufsz);
-  return NB_OK;
-}
-
 template <int DT, int KL, bool SMALL>
 int launch_variant(const double* cvec, const double* tiles, int n_dim,
                    const double* x, long long n, unsigned char* mask,
                    hipStream_t stream) {
-  if constexpr (DT <= 4) {
-    static const bool dma = getenv("NB_STREAM_ODD_DMA") != nullptr;
-    if (dma && (n_dim & 1) && n >= 64)
-      return launch_odd<DT, KL, SMALL>(cvec, tiles, n_dim, x, n, mask, stream);
-  }
   // 4 tiles per wavefront while the operands fit the register file, one
   // beyond 96 dimensions (two tiles of 28 slots spill 26-42 registers)
   constexpr int TPW = (DT <= 4) ? 4 : (DT <= 6 ? 2 : 1);

@@ -140,33 +140,17 @@ __device__ __forceinline__ void load_points(const nb_gd* __restrict__ x,
         xin[t][2 * j + 1] = in ? v.y : 0.0;
       }
     }
-  } else if (n_dim >= 3) {
-    // odd n_dim: rows are 8-byte aligned only, but a 16-byte global load
-    // needs dword alignment, not 16 bytes (nb_d2u); the pair that holds the
-    // row's last feature is read one element earlier, (x[D-2], x[D-1]), so
-    // that nothing behind the array is touched
+  } else {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const nb_gd* row = x + (valid[t] ? pt[t] : n - 1) * n_dim;
 #pragma unroll
       for (int j = 0; j < 2 * DT; ++j) {
         const int f = 8 * j + 2 * lg;
-        const bool full = f + 1 < n_dim, half = f + 1 == n_dim;
-        const nb_d2u v =
-            *(const NB_G nb_d2u*)(row + (full ? f : (half ? f - 1 : 0)));
-        xin[t][2 * j] = (valid[t] && (full || half)) ? (half ? v.y : v.x) : 0.0;
-        xin[t][2 * j + 1] = (valid[t] && full) ? v.y : 0.0;
-      }
-    }
-  } else {
-    // n_dim = 1
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const double v0 = x[valid[t] ? pt[t] : n - 1];
-#pragma unroll
-      for (int j = 0; j < 2 * DT; ++j) {
-        xin[t][2 * j] = (valid[t] && j == 0 && lg == 0) ? v0 : 0.0;
-        xin[t][2 * j + 1] = 0.0;
+        const double v0 = row[f < n_dim ? f : n_dim - 1];
+        const double v1 = row[f + 1 < n_dim ? f + 1 : n_dim - 1];
+        xin[t][2 * j] = (valid[t] && f < n_dim) ? v0 : 0.0;
+        xin[t][2 * j + 1] = (valid[t] && f + 1 < n_dim) ? v1 : 0.0;
       }
     }
   }

@@ -88,11 +88,13 @@ def test_ellipsoid_stream_large(dev):
         assert torch.equal(b.contains_stream(x[:k]), m1[:k])
 
 
-@pytest.mark.parametrize('d', [1, 7, 33, 49, 63, 65, 127])
+@pytest.mark.parametrize('d', [1, 3, 5, 7, 33, 49, 63, 65, 127])
 def test_ellipsoid_stream_odd_dims(dev, d):
-    """Odd n_dim (rows only 8-byte aligned): the DMA-staged streaming kernel
-    (n_dim <= 63) and the scalar-load path above it against the oracle, for
-    sizes around the 32-point groups and the end of the array."""
+    """Odd n_dim (rows only 8-byte aligned): 16-byte pair loads from
+    8-byte-aligned addresses (n_dim >= 3; the pair with a row's last feature
+    is read one element earlier) and the one-element path of n_dim = 1
+    against the oracle, for sizes around the point groups of a wavefront and
+    the end of the array."""
     import torch
     from oracle import bounds_oracle as bo
     rng = np.random.default_rng(d)
