@@ -200,6 +200,116 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
   }
 }
 
+// The same kernel software-pipelined for n_dim <= 64: a wavefront works on
+// UNITS of two tiles (32 points) and the loads of the unit after the current
+// one are in flight while the current one is multiplied (two register
+// buffers, the loop unrolled by two).  With four tiles loaded and then
+// multiplied the rate was 0.56 / 0.64 / 0.55 / 0.60 of the HBM peak at n_dim
+// 49 / 50 / 63 / 64; pipelined 0.63 / 0.64 / 0.61 / 0.62
+// (profiles/r05/fifth_session/stream_pipe_ab.txt).
+// All loads are unconditional -- a unit past the end is the last unit again,
+// recomputed and stored with the same values -- because the wait counts in
+// front of the MFMA chains must be exact (behind a conditional load the
+// compiler waits for the whole memory queue).
+template <int DT>
+struct StreamRaw { nb_d2u v[2][2 * DT]; };
+
+template <int DT>
+__device__ __forceinline__ void stream_issue(const double* __restrict__ x,
+                                             long long n, int n_dim,
+                                             long long unit, int li, int lg,
+                                             StreamRaw<DT>& raw) {
+  const bool even = (n_dim & 1) == 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long long pt = (unit * 2 + t) * 16 + li;
+    const double* row = x + (pt < n ? pt : n - 1) * n_dim;
+#pragma unroll
+    for (int j = 0; j < 2 * DT; ++j) {
+      const int f = 8 * j + 2 * lg;
+      int at;
+      if (even) {
+        at = f < n_dim ? f : n_dim - 2;
+      } else {
+        const bool full = f + 1 < n_dim, half = f + 1 == n_dim;
+        at = full ? f : (half ? f - 1 : 0);
+      }
+      raw.v[t][j] = *(const nb_d2u*)(row + at);
+    }
+  }
+}
+
+template <int DT, int KL, bool SMALL>
+__device__ __forceinline__ void stream_consume(
+    const double* wl, const double (&cper)[4 * DT], long long n, int n_dim,
+    long long unit, int lane, const StreamRaw<DT>& raw,
+    unsigned char* __restrict__ mask) {
+  const int li = lane & 15, lg = lane >> 4;
+  const bool even = (n_dim & 1) == 0;
+  double d[2][4 * DT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bool ok = (unit * 2 + t) * 16 + li < n;
+#pragma unroll
+    for (int j = 0; j < 2 * DT; ++j) {
+      const int f = 8 * j + 2 * lg;
+      const bool full = f + 1 < n_dim, half = f + 1 == n_dim;
+      const nb_d2u v = raw.v[t][j];
+      const double v0 = (!even && half) ? v.y : v.x;
+      d[t][2 * j] = ((ok && f < n_dim) ? v0 : 0.0) - cper[2 * j];
+      d[t][2 * j + 1] = ((ok && full) ? v.y : 0.0) - cper[2 * j + 1];
+    }
+  }
+  double part[2];
+  stream_quadform<DT, 2, KL, SMALL>(wl, n_dim, lane, d, part);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    double r2 = part[t];
+    r2 += __shfl_xor(r2, 16);
+    r2 += __shfl_xor(r2, 32);
+    const long long pt = (unit * 2 + t) * 16 + li;
+    if (lg == 0 && pt < n) mask[pt] = (r2 < 1.0) ? 1 : 0;
+  }
+}
+
+template <int DT, int KL, bool SMALL>
+__global__ void __launch_bounds__(256, 2)
+nb_ell_stream_pipe_kernel(const double* __restrict__ cvec,
+                          const double* __restrict__ tiles, int n_dim,
+                          const double* __restrict__ x, long long n,
+                          unsigned char* __restrict__ mask) {
+  constexpr int NT = DT * (DT + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double wl[NT * NB_TILE];
+  for (int i = 2 * threadIdx.x; i < NT * NB_TILE; i += 512)
+    *(double2*)(wl + i) = *(const double2*)(tiles + i);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  double cper[4 * DT];
+#pragma unroll
+  for (int j = 0; j < 2 * DT; ++j) {
+    const int f = 8 * j + 2 * lg;
+    cper[2 * j] = cvec[f];              // cvec is zero padded to 16*DT
+    cper[2 * j + 1] = cvec[f + 1];
+  }
+  const long long n_units = (n + 31) / 32, last = n_units - 1;
+  const long long stride = (long long)gridDim.x * 4;
+  long long u = (long long)blockIdx.x * 4 + wave;
+  if (u >= n_units) return;
+  StreamRaw<DT> a, b;
+  stream_issue<DT>(x, n, n_dim, u, li, lg, a);
+  for (; u < n_units; u += 2 * stride) {
+    const long long u1 = u + stride < n_units ? u + stride : last;
+    const long long u2 = u + 2 * stride < n_units ? u + 2 * stride : last;
+    stream_issue<DT>(x, n, n_dim, u1, li, lg, b);
+    stream_consume<DT, KL, SMALL>(wl, cper, n, n_dim, u, lane, a, mask);
+    stream_issue<DT>(x, n, n_dim, u2, li, lg, a);
+    stream_consume<DT, KL, SMALL>(wl, cper, n, n_dim, u1, lane, b, mask);
+  }
+}
+
 template <int DT, int KL, bool SMALL>
 int launch_variant(const double* cvec, const double* tiles, int n_dim,
                    const double* x, long long n, unsigned char* mask,
@@ -207,6 +317,19 @@ int launch_variant(const double* cvec, const double* tiles, int n_dim,
   // 4 tiles per wavefront while the operands fit the register file, one
   // beyond 96 dimensions (two tiles of 28 slots spill 26-42 registers)
   constexpr int TPW = (DT <= 4) ? 4 : (DT <= 6 ? 2 : 1);
+  // (n_dim <= 16: the plain kernel is 3 % ahead; beyond 64 dimensions two
+  // register buffers do not fit)
+  if constexpr (DT >= 2 && DT <= 4) {
+    {
+      const long long n_units = (n + 31) / 32;
+      long long blocks = (n_units + 3) / 4;
+      if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
+      hipLaunchKernelGGL((nb_ell_stream_pipe_kernel<DT, KL, SMALL>),
+                         dim3((unsigned)blocks), dim3(256), 0, stream, cvec,
+                         tiles, n_dim, x, n, mask);
+      return NB_OK;
+    }
+  }
   const long long n_groups = (n + 16 * TPW - 1) / (16 * TPW);
   long long blocks = (n_groups + 3) / 4;
   if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
