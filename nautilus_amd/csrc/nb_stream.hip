@@ -101,6 +101,93 @@ __device__ __forceinline__ void stream_quadform(const double* wl, int n_dim,
   }
 }
 
+// The same with the A operands read AHEAD of their MFMAs: left to the
+// scheduler every LDS read sits directly in front of its first MFMA, and with
+// one or two tiles per wavefront (n_dim > 64) an operand feeds 64-128 cycles
+// of matrix work behind ~120 cycles of exposed LDS latency.  The k-steps go
+// in chunks of four; the reads of a chunk are issued in front of the MFMAs of
+// the chunk before it (256-512 cycles of cover, eight more registers) and
+// pinned there by scheduling barriers.
+template <int DT, int TPW, int KL, bool SMALL>
+__device__ __forceinline__ void stream_quadform_ahead(
+    const double* wl, int lane, const double (&d)[TPW][4 * DT],
+    double (&part)[TPW]) {
+  double a[DT][4 * DT];
+  auto read_chunk = [&](int ht, int c) __attribute__((always_inline)) {
+    const int ks_n = (4 * (ht + 1) < KL) ? 4 * (ht + 1) : KL;
+    // (a last row tile of at most 4 rows: the A operand of the 4x4x4 tile)
+    const int off = (SMALL && ht == DT - 1)
+                        ? (lane >> 4) * 16 + (lane & 3) : lane;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (4 * c + s < ks_n)
+        a[ht][4 * c + s] =
+            wl[((ht * (ht + 1)) / 2 + c) * NB_TILE + s * 64 + off];
+  };
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) part[t] = 0.0;
+  read_chunk(0, 0);
+#pragma unroll
+  for (int ht = 0; ht < DT; ++ht) {
+    const int ks_n = (4 * (ht + 1) < KL) ? 4 * (ht + 1) : KL;
+    const int n_c = (ks_n + 3) / 4;
+    if (SMALL && ht == DT - 1) {
+      // 4x4x4 tiles (16 instead of 64 cycles per k-step); even and odd
+      // k-steps in accumulators of their own: with one or two tiles per
+      // wavefront a single chain waits for its own results
+      double r[TPW][2];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) r[t][0] = r[t][1] = 0.0;
+#pragma unroll
+      for (int c = 0; c < DT; ++c) {
+        if (c < n_c) {
+          if (c + 1 < n_c) read_chunk(ht, c + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            if (4 * c + s < ks_n) {
+#pragma unroll
+              for (int t = 0; t < TPW; ++t)
+                r[t][s & 1] = MFMA4(a[ht][4 * c + s], d[t][4 * c + s],
+                                    r[t][s & 1]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const double y = r[t][0] + r[t][1];
+        part[t] = fma(y, y, part[t]);
+      }
+    } else {
+      nb_d4 acc[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < DT; ++c) {
+        if (c < n_c) {
+          if (c + 1 < n_c) read_chunk(ht, c + 1);
+          else if (ht + 1 < DT) read_chunk(ht + 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            if (4 * c + s < ks_n) {
+#pragma unroll
+              for (int t = 0; t < TPW; ++t)
+                acc[t] = MFMA(a[ht][4 * c + s], d[t][4 * c + s], acc[t]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          part[t] = fma(acc[t][r], acc[t][r], part[t]);
+    }
+  }
+}
+
 template <int DT, int TPW, int KL, bool SMALL>
 __global__ void __launch_bounds__(256, 2)
 nb_ell_stream_kernel(const double* __restrict__ cvec,
@@ -188,7 +275,10 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
     }
 
     double part[TPW];
-    stream_quadform<DT, TPW, KL, SMALL>(wl, n_dim, lane, d, part);
+    if constexpr (DT >= 5)
+      stream_quadform_ahead<DT, TPW, KL, SMALL>(wl, lane, d, part);
+    else
+      stream_quadform<DT, TPW, KL, SMALL>(wl, n_dim, lane, d, part);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       double r2 = part[t];
@@ -348,9 +438,9 @@ int launch(const double* cvec, const double* tiles, int n_dim, const double* x,
   if (kl == 4 * DT)
     return launch_variant<DT, 4 * DT, false>(cvec, tiles, n_dim, x, n, mask,
                                              stream);
-  // (with two tiles per wavefront an operand read feeds only 32 cycles of
-  // 4x4x4 work and the LDS latency shows: slower than the padded tile)
-  if (DT <= 4 && rem >= 1 && rem <= 4)
+  // (beyond 64 dimensions -- one or two tiles per wavefront -- the 4x4x4
+  // tiles pay since the operands are read ahead: stream_quadform_ahead)
+  if (rem >= 1 && rem <= 4)
     return launch_variant<DT, 4 * DT - 2, true>(cvec, tiles, n_dim, x, n, mask,
                                                 stream);
   return launch_variant<DT, 4 * DT - 2, false>(cvec, tiles, n_dim, x, n, mask,

@@ -88,7 +88,36 @@ def test_ellipsoid_stream_large(dev):
         assert torch.equal(b.contains_stream(x[:k]), m1[:k])
 
 
-@pytest.mark.parametrize('d', [1, 3, 5, 7, 33, 49, 63, 65, 127])
+@pytest.mark.parametrize('d', [2, 16, 18, 20, 36, 52, 56, 64, 66, 68, 80, 84,
+                               90, 96, 100, 112, 116, 128])
+def test_ellipsoid_stream_every_variant(dev, d):
+    """Even n_dim through every instantiation of the streaming kernels: the
+    plain kernel (n_dim <= 16), the pipelined one (<= 64), two and one tile
+    per wavefront with the operands read ahead beyond that, each with a full
+    last row tile, a last row tile of at most four rows (4x4x4 matrix
+    instructions: 20, 36, 52, 68, 84, 100, 116) and a trimmed K range --
+    against the oracle (basic.py:340, 360), ragged sizes included."""
+    import torch
+    from oracle import bounds_oracle as bo
+    rng = np.random.default_rng(1000 + d)
+    b_mat = np.tril(rng.normal(size=(d, d)) * 0.05) + np.eye(d) * 0.5
+    ell = bo.OEllipsoid.from_params(np.full(d, 0.5), b_mat)
+    b = upload(ell)
+    n = 40003
+    x = 0.5 + (rng.normal(size=(n, d)) @ b_mat.T) / np.sqrt(d + 2.0)
+    r2 = np.sum(ell.transform(x)**2, axis=-1)
+    want = r2 < 1
+    xt = torch.from_numpy(x).cuda()
+    full = b.contains_stream(xt).cpu().numpy()
+    edge = near_boundary(r2, 1.0, TOL)
+    assert np.array_equal(full[~edge], want[~edge])
+    assert 0.05 < want.mean() < 0.98
+    for k in (1, 17, 32, 33, 64, 65, 4097, 39999):
+        part = b.contains_stream(xt[:k]).cpu().numpy()
+        assert np.array_equal(part, full[:k]), k
+
+
+@pytest.mark.parametrize('d', [1, 3, 5, 7, 33, 49, 63, 65, 67, 99, 115, 127])
 def test_ellipsoid_stream_odd_dims(dev, d):
     """Odd n_dim (rows only 8-byte aligned): 16-byte pair loads from
     8-byte-aligned addresses (n_dim >= 3; the pair with a row's last feature
