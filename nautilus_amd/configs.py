@@ -48,6 +48,17 @@ def baseline_config(name):
             likelihood=GaussianMixtureLikelihood(means, 0.02), n_dim=50,
             n_live=5000, n_networks=4, n_batch=16384, analytic_log_z=0.0,
             means=means, description='50-dim 4-mode Gaussian mixture, n_live=5000')
+    if name.startswith('C4-D'):
+        # the config-4 problem at a dimension the REFERENCE finishes on a CPU
+        # core (tests/golden/make_golden_mixture.py runs it with n_live 2000)
+        d = int(name[4:])
+        means = 0.25 + 0.5 * np.random.default_rng(3).random((4, d))
+        return dict(
+            likelihood=GaussianMixtureLikelihood(means, 0.02), n_dim=d,
+            n_live=2000, n_networks=4, n_batch=100, analytic_log_z=0.0,
+            means=means, description='%d-dim 4-mode Gaussian mixture, '
+                                     'n_live=2000 (config 4 at a dimension '
+                                     'the reference finishes)' % d)
     if name == 'C5':
         return dict(
             likelihood=FunnelLikelihood(100), n_dim=100, n_live=10000,

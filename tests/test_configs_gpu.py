@@ -182,6 +182,52 @@ def test_C4_mixture_explored_and_evidence():
     assert np.all(np.abs(share / share.sum() - 0.25) < 0.06)
 
 
+def _mixture_reference(n_dim):
+    path = os.path.join(GOLDEN, 'e2e_mixture.json')
+    if not os.path.exists(path):
+        return []
+    with open(path) as f:
+        return [r for r in json.load(f)['runs'] if r['n_dim'] == n_dim]
+
+
+@pytest.mark.parametrize('n_dim', [10, 20])
+def test_mixture_against_reference_runs(n_dim):
+    """Configuration 4's problem (four-mode mixture: a Union with several
+    members, several neural bounds per NautilusBound) at the dimensions the
+    REFERENCE finishes, with the settings of its runs in
+    tests/golden/e2e_mixture.json (make_golden_mixture.py: n_live 2000, 4
+    networks, n_batch 100, n_eff 10000, exploration discarded): evidence in
+    the reference's band and within 0.05 of the analytic value 0, likelihood
+    calls, number of bounds, the largest number of neural bounds of a bound and
+    the posterior weight of every mode as the reference has them."""
+    ref = _mixture_reference(n_dim)
+    if len(ref) < 2:
+        pytest.skip('fewer than two reference runs at n_dim %d in '
+                    'tests/golden/e2e_mixture.json' % n_dim)
+    ref_z = np.array([r['log_z'] for r in ref])
+    ref_like = np.mean([r['n_like'] for r in ref])
+    ref_bounds = np.mean([r['n_bounds'] for r in ref])
+    ref_neural = max(r['n_neural_max'] for r in ref)
+    c, s, done = _run('C4-D%d' % n_dim, seed=0)
+    assert done and s.n_eff >= 10000
+    _invariants(c, s)
+    sigma = 0.01                     # of log Z of ONE run at N_eff 10 000
+    assert abs(s.log_z - ref_z.mean()) < 4 * sigma * np.sqrt(1 + 1 / len(ref))
+    assert abs(s.log_z) < 0.05
+    assert abs(s.n_like / ref_like - 1) < 0.15
+    assert abs(len(s.bounds) - ref_bounds) <= 0.15 * ref_bounds + 2
+    ours_neural = max(len(b.neural_bounds) for b in s.bounds[1:])
+    assert ours_neural >= 2 and abs(ours_neural - ref_neural) <= 1
+    pts, log_w, _ = s.posterior()
+    w = np.exp(log_w)
+    means = c['means']
+    mode = np.argmin(((pts[:, None, :] - means[None]) ** 2).sum(-1), axis=1)
+    share = np.array([w[mode == k].sum() for k in range(len(means))])
+    ref_share = np.mean([r['mode_share'] for r in ref], axis=0)
+    # sigma of a mode's weight at N_eff 10 000: sqrt(0.25 * 0.75 / 1e4)
+    assert np.all(np.abs(share / share.sum() - ref_share) < 0.03)
+
+
 def test_C5_funnel_real_size():
     """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
     the device MVEE / mixture fit at 100 dimensions -- 60 s of the run and
