@@ -49,7 +49,8 @@ constexpr int MV_THREADS = 512;
 constexpr int MV_WAVES = MV_THREADS / 64;
 constexpr int MV_MAXB = 16;        // problems per launch
 constexpr int MV_MAXW = 32;        // workgroups (candidate lists) per problem
-constexpr int MV_MAXPPW = 2048;    // points per workgroup
+constexpr int MV_MAXPPW = 8192;    // points per workgroup (their g values live in LDS:
+                                   // launch_sweep refuses what does not fit at the n_dim)
 constexpr int MV_GJ_EPT = 33;      // ceil(129^2 / 512)
 
 struct MvProb {

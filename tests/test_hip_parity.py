@@ -647,12 +647,14 @@ def test_mvee_kernel_shapes(dev):
     """Known answers and ragged sizes: points on a sphere (reference
     tests/test_bounds.py), n barely above n_dim, n not a multiple of 16, odd
     and even dimensions up to the kernels' limit of 128, more points than one
-    workgroup per 128 handles."""
+    workgroup per 128 handles, point sets beyond 65 536 points (up to 8192
+    points per workgroup and candidate list)."""
     from nautilus_amd import geometry
     rng = np.random.default_rng(5)
     for d, n in [(2, 3), (2, 100), (7, 9), (15, 333), (16, 200), (31, 64),
                  (33, 1000), (62, 300), (63, 129), (64, 200), (79, 700),
-                 (100, 1500), (127, 400), (128, 300), (20, 6000)]:
+                 (100, 1500), (127, 400), (128, 300), (20, 6000),
+                 (8, 70000), (50, 66000), (5, 250000)]:
         pts = rng.normal(size=(n, d)) * rng.uniform(0.5, 2.0, size=d) + 0.3
         u = dev.mvee_weights(pts).cpu().numpy()
         u_h = khachiyan_weights_numpy(pts)
