@@ -696,9 +696,13 @@ def main():
         ms = ev0.elapsed_time(ev1) / reps
         gbs = n_pts * (8 * d + 1) / (ms * 1e-3) / 1e9
         out['roofline_contains'] = dict(
-            kernel='nb_ell_stream_kernel', bound='hbm', achieved=gbs,
+            kernel='nb_ell_stream_pipe_kernel', bound='hbm', achieved=gbs,
             peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS,
-            traffic=None, points=n_pts, bytes_per_point=8 * d + 1,
+            traffic=None,
+            traffic_note='committed counter passes of this kernel: '
+                         'profiles/r05/fifth_session/stream_pmc.txt '
+                         '(FETCH_SIZE: 0.98 x the algorithmic bytes)',
+            points=n_pts, bytes_per_point=8 * d + 1,
             avg_launch_ms=ms, inside_fraction=float(mask.double().mean()))
         del x, mask
         # ... and at BASELINE configuration 5's dimension, where D (D + 1)
