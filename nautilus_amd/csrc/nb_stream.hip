@@ -28,6 +28,8 @@
 //  * r^2 is reduced over the 4 lanes of a point with two xor-shuffles.
 #include "nb_common.h"
 
+#include <cstdlib>
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 namespace {
@@ -301,18 +303,18 @@ nb_ell_stream_kernel(const double* __restrict__ cvec,
 // recomputed and stored with the same values -- because the wait counts in
 // front of the MFMA chains must be exact (behind a conditional load the
 // compiler waits for the whole memory queue).
-template <int DT>
-struct StreamRaw { nb_d2u v[2][2 * DT]; };
+template <int DT, int UT>
+struct StreamRaw { nb_d2u v[UT][2 * DT]; };
 
-template <int DT>
+template <int DT, int UT>
 __device__ __forceinline__ void stream_issue(const double* __restrict__ x,
                                              long long n, int n_dim,
                                              long long unit, int li, int lg,
-                                             StreamRaw<DT>& raw) {
+                                             StreamRaw<DT, UT>& raw) {
   const bool even = (n_dim & 1) == 0;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const long long pt = (unit * 2 + t) * 16 + li;
+  for (int t = 0; t < UT; ++t) {
+    const long long pt = (unit * UT + t) * 16 + li;
     const double* row = x + (pt < n ? pt : n - 1) * n_dim;
 #pragma unroll
     for (int j = 0; j < 2 * DT; ++j) {
@@ -329,17 +331,17 @@ __device__ __forceinline__ void stream_issue(const double* __restrict__ x,
   }
 }
 
-template <int DT, int KL, bool SMALL>
+template <int DT, int UT, int KL, bool SMALL>
 __device__ __forceinline__ void stream_consume(
     const double* wl, const double (&cper)[4 * DT], long long n, int n_dim,
-    long long unit, int lane, const StreamRaw<DT>& raw,
+    long long unit, int lane, const StreamRaw<DT, UT>& raw,
     unsigned char* __restrict__ mask) {
   const int li = lane & 15, lg = lane >> 4;
   const bool even = (n_dim & 1) == 0;
-  double d[2][4 * DT];
+  double d[UT][4 * DT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const bool ok = (unit * 2 + t) * 16 + li < n;
+  for (int t = 0; t < UT; ++t) {
+    const bool ok = (unit * UT + t) * 16 + li < n;
 #pragma unroll
     for (int j = 0; j < 2 * DT; ++j) {
       const int f = 8 * j + 2 * lg;
@@ -350,19 +352,23 @@ __device__ __forceinline__ void stream_consume(
       d[t][2 * j + 1] = ((ok && full) ? v.y : 0.0) - cper[2 * j + 1];
     }
   }
-  double part[2];
-  stream_quadform<DT, 2, KL, SMALL>(wl, n_dim, lane, d, part);
+  double part[UT];
+  // (one tile per unit beyond 64 dimensions: operands read ahead)
+  if constexpr (DT >= 5)
+    stream_quadform_ahead<DT, UT, KL, SMALL>(wl, lane, d, part);
+  else
+    stream_quadform<DT, UT, KL, SMALL>(wl, n_dim, lane, d, part);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < UT; ++t) {
     double r2 = part[t];
     r2 += __shfl_xor(r2, 16);
     r2 += __shfl_xor(r2, 32);
-    const long long pt = (unit * 2 + t) * 16 + li;
+    const long long pt = (unit * UT + t) * 16 + li;
     if (lg == 0 && pt < n) mask[pt] = (r2 < 1.0) ? 1 : 0;
   }
 }
 
-template <int DT, int KL, bool SMALL>
+template <int DT, int UT, int KL, bool SMALL>
 __global__ void __launch_bounds__(256, 2)
 nb_ell_stream_pipe_kernel(const double* __restrict__ cvec,
                           const double* __restrict__ tiles, int n_dim,
@@ -384,19 +390,19 @@ nb_ell_stream_pipe_kernel(const double* __restrict__ cvec,
     cper[2 * j] = cvec[f];              // cvec is zero padded to 16*DT
     cper[2 * j + 1] = cvec[f + 1];
   }
-  const long long n_units = (n + 31) / 32, last = n_units - 1;
+  const long long n_units = (n + 16 * UT - 1) / (16 * UT), last = n_units - 1;
   const long long stride = (long long)gridDim.x * 4;
   long long u = (long long)blockIdx.x * 4 + wave;
   if (u >= n_units) return;
-  StreamRaw<DT> a, b;
-  stream_issue<DT>(x, n, n_dim, u, li, lg, a);
+  StreamRaw<DT, UT> a, b;
+  stream_issue<DT, UT>(x, n, n_dim, u, li, lg, a);
   for (; u < n_units; u += 2 * stride) {
     const long long u1 = u + stride < n_units ? u + stride : last;
     const long long u2 = u + 2 * stride < n_units ? u + 2 * stride : last;
-    stream_issue<DT>(x, n, n_dim, u1, li, lg, b);
-    stream_consume<DT, KL, SMALL>(wl, cper, n, n_dim, u, lane, a, mask);
-    stream_issue<DT>(x, n, n_dim, u2, li, lg, a);
-    stream_consume<DT, KL, SMALL>(wl, cper, n, n_dim, u1, lane, b, mask);
+    stream_issue<DT, UT>(x, n, n_dim, u1, li, lg, b);
+    stream_consume<DT, UT, KL, SMALL>(wl, cper, n, n_dim, u, lane, a, mask);
+    stream_issue<DT, UT>(x, n, n_dim, u2, li, lg, a);
+    stream_consume<DT, UT, KL, SMALL>(wl, cper, n, n_dim, u1, lane, b, mask);
   }
 }
 
@@ -414,7 +420,19 @@ int launch_variant(const double* cvec, const double* tiles, int n_dim,
       const long long n_units = (n + 31) / 32;
       long long blocks = (n_units + 3) / 4;
       if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
-      hipLaunchKernelGGL((nb_ell_stream_pipe_kernel<DT, KL, SMALL>),
+      hipLaunchKernelGGL((nb_ell_stream_pipe_kernel<DT, 2, KL, SMALL>),
+                         dim3((unsigned)blocks), dim3(256), 0, stream, cvec,
+                         tiles, n_dim, x, n, mask);
+      return NB_OK;
+    }
+  }
+  if constexpr (DT >= 5 && DT <= 7) {
+    static const bool plain = getenv("NB_STREAM_PLAIN") != nullptr;
+    if (!plain && n_dim >= 3) {
+      const long long n_units = (n + 15) / 16;
+      long long blocks = (n_units + 3) / 4;
+      if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
+      hipLaunchKernelGGL((nb_ell_stream_pipe_kernel<DT, 1, KL, SMALL>),
                          dim3((unsigned)blocks), dim3(256), 0, stream, cvec,
                          tiles, n_dim, x, n, mask);
       return NB_OK;
