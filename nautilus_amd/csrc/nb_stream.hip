@@ -28,8 +28,6 @@
 //  * r^2 is reduced over the 4 lanes of a point with two xor-shuffles.
 #include "nb_common.h"
 
-#include <cstdlib>
-
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 namespace {
@@ -413,8 +411,7 @@ int launch_variant(const double* cvec, const double* tiles, int n_dim,
   // 4 tiles per wavefront while the operands fit the register file, one
   // beyond 96 dimensions (two tiles of 28 slots spill 26-42 registers)
   constexpr int TPW = (DT <= 4) ? 4 : (DT <= 6 ? 2 : 1);
-  // (n_dim <= 16: the plain kernel is 3 % ahead; beyond 64 dimensions two
-  // register buffers do not fit)
+  // (n_dim <= 16: the plain kernel is 3 % ahead)
   if constexpr (DT >= 2 && DT <= 4) {
     {
       const long long n_units = (n + 31) / 32;
@@ -426,9 +423,12 @@ int launch_variant(const double* cvec, const double* tiles, int n_dim,
       return NB_OK;
     }
   }
+  // 65 <= n_dim <= 112: units of ONE tile, operands read ahead (n_dim 96:
+  // 0.99 -> 0.845 ms per 2^22 points against two tiles loaded and multiplied
+  // in turn, 100: 0.955 -> 0.925; profiles/r05/fifth_session/
+  // stream_pipe1_ab.txt); beyond that two register buffers do not fit
   if constexpr (DT >= 5 && DT <= 7) {
-    static const bool plain = getenv("NB_STREAM_PLAIN") != nullptr;
-    if (!plain && n_dim >= 3) {
+    if (n_dim >= 3) {
       const long long n_units = (n + 15) / 16;
       long long blocks = (n_units + 3) / 4;
       if (blocks > 256 * 2 * 2) blocks = 256 * 2 * 2;
