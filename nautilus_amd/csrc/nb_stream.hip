@@ -336,18 +336,22 @@ __device__ __forceinline__ void stream_consume(
     unsigned char* __restrict__ mask) {
   const int li = lane & 15, lg = lane >> 4;
   const bool even = (n_dim & 1) == 0;
+  // No masking of the loaded values: a slot past n_dim holds an element of
+  // the point's own row (the clamped address) and meets exact zeros in the
+  // tiles (nb_api.hip packs B_inv[h][k] = 0 for k >= n_dim), a lane past the
+  // end of the array computes on the last row and stores nothing.  (The
+  // selects were ~4 of the ~6 VALU instructions per loaded pair, on a kernel
+  // whose matrix pipe and memory system are both ~64 % busy.)
   double d[UT][4 * DT];
 #pragma unroll
   for (int t = 0; t < UT; ++t) {
-    const bool ok = (unit * UT + t) * 16 + li < n;
 #pragma unroll
     for (int j = 0; j < 2 * DT; ++j) {
       const int f = 8 * j + 2 * lg;
-      const bool full = f + 1 < n_dim, half = f + 1 == n_dim;
       const nb_d2u v = raw.v[t][j];
-      const double v0 = (!even && half) ? v.y : v.x;
-      d[t][2 * j] = ((ok && f < n_dim) ? v0 : 0.0) - cper[2 * j];
-      d[t][2 * j + 1] = ((ok && full) ? v.y : 0.0) - cper[2 * j + 1];
+      const double v0 = (!even && f + 1 == n_dim) ? v.y : v.x;
+      d[t][2 * j] = v0 - cper[2 * j];
+      d[t][2 * j + 1] = v.y - cper[2 * j + 1];
     }
   }
   double part[UT];
