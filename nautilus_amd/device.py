@@ -5,6 +5,7 @@ path runs in the hand-written HIP kernels of ``libnautilus_hip.so``.
 """
 
 import ctypes as C
+import math
 import os
 import time
 
@@ -16,7 +17,10 @@ from . import _lib
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (the raw handle of torch's current stream: torch.cuda.current_stream()
+    # builds a Stream object, ~10 us, and the hot loop asks ~10 times a step)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(
+        torch._C._cuda_getDevice()))
 
 
 def _ptr(t):
@@ -573,7 +577,7 @@ def _buffer(role, shape, dtype, reuse):
     to hipMalloc -- tens of milliseconds each -- in the middle of a run."""
     if not reuse:
         return torch.empty(shape, dtype=dtype, device='cuda')
-    n_bytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    n_bytes = math.prod(shape) * dtype.itemsize
     buf = _SCRATCH.get(role)
     if buf is None or buf.numel() < n_bytes:
         _SCRATCH[role] = buf = None        # release before growing
@@ -593,7 +597,8 @@ def compact_rows(x, flags, mask=1, want_index=False, reuse=False, flip=0):
     lib = _lib.load()
     n, d = x.shape
     out = _buffer('compact', (n, d), torch.float64, reuse)
-    counts = torch.zeros(2, dtype=torch.int64, device='cuda')
+    # (written by the scan kernel, or zeroed by the launcher for n = 0)
+    counts = torch.empty(2, dtype=torch.int64, device='cuda')
     scratch = _buffer('compact_scratch',
                       (max(16, lib.nb_compact_scratch_bytes(n)),),
                       torch.uint8, reuse)
