@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 5
+#define NB_ABI_VERSION 6
 
 typedef struct nb_bound nb_bound;          /* opaque bound living in HBM     */
 typedef struct nb_boundlist nb_boundlist;  /* device array of bound pointers */
@@ -460,6 +460,12 @@ int nb_gmm_fit(const double* x_dev, int64_t n, int32_t n_dim, int32_t n_init,
                uint64_t seed, double tol, double reg_covar, int32_t max_iter,
                const int32_t* init_labels_dev, double* out_dev,
                double* scratch_dev, void* stream);
+/* The workgroups of a restart wait for each other inside an ordinary launch:
+ * they must all be resident.  The library limits a fit to half of the
+ * device's CUs on its own; a host whose processes SHARE a device (several
+ * ranks on one GPU) sets max_wgs = 1 (one workgroup per restart, nothing
+ * waits); 0 = back to the default (8, or the NB_GMM_MAX_WGS variable).     */
+int nb_gmm_set_max_wgs(int32_t max_wgs);
 
 /* PhaseShift.transform (bounds/periodic.py:50-72), in place on device rows:
  * x[:, periodic[i]] = (x[:, periodic[i]] -/+ (0.5 - centers[i])) mod 1

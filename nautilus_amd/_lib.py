@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('NAUTILUS_HIP_LIB') or os.path.join(
     _HERE, 'lib', 'libnautilus_hip.so')
 
 # NB_ABI_VERSION of include/nautilus_hip.h this binding was written against
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -182,6 +182,7 @@ _SIGNATURES = {
     'nb_gmm_fit': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                              C.c_uint64, C.c_double, C.c_double, C.c_int32,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'nb_gmm_set_max_wgs': (C.c_int, [C.c_int32]),
     'nb_phase_shift': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                  c_int32_p, c_double_p, C.c_int32,
                                  C.c_void_p]),

@@ -571,9 +571,17 @@ class Union(_RejectionSampler):
             return False
         index = int(np.argmax(np.where(~self.block, self.log_v_all, -np.inf)))
         pts = self.points_bounds[index]
-        labels = geometry.two_component_labels(
-            self.bounds[index].transform(pts), self.n_points_min,
-            int(self.rng.integers(2**32 - 1)))
+        try:
+            labels = geometry.two_component_labels(
+                self.bounds[index].transform(pts), self.n_points_min,
+                int(self.rng.integers(2**32 - 1)))
+        except geometry.DegenerateMixture:
+            # every device restart ended with an empty cluster or a singular
+            # covariance (duplicated / collapsed points): these points cannot
+            # be divided -- the outcome of a split that does not shrink the
+            # volume (union.py:204-207), not the end of the run
+            self.block[index] = True
+            return self.split(allow_overlap=allow_overlap)
         cls = type(self.bounds[0])
         halves = cls.compute_many([pts[labels == lab] for lab in (0, 1)],
                                   enlarge_per_dim=self.enlarge_per_dim,

@@ -101,6 +101,7 @@ long long nb_gmm_out_stride_impl(int d);
 long long nb_gmm_scratch_stride_impl(long long n, int d);
 long long nb_gmm_work_doubles_impl(long long n, int d, int n_init);
 long long nb_gmm_logp_offset_impl(long long n, int d);
+int nb_gmm_set_cap_impl(int max_wgs);
 int nb_launch_gmm(const double* x, long long n, int d, int n_init,
                   unsigned long long seed, double tol, double reg, int max_iter,
                   const int* init_labels, double* out, double* scratch,
@@ -1123,6 +1124,7 @@ int64_t nb_gmm_work_doubles(int64_t n, int32_t n_dim, int32_t n_init) {
   return nb_gmm_work_doubles_impl(n, n_dim, n_init);
 }
 
+int nb_gmm_set_max_wgs(int32_t max_wgs) { return nb_gmm_set_cap_impl(max_wgs); }
 int64_t nb_gmm_logp_offset(int32_t n_dim) {
   return nb_gmm_logp_offset_impl(2, n_dim);     // (does not depend on n)
 }

@@ -34,6 +34,7 @@
 // for the seeding).
 #include "nb_sym.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -757,19 +758,37 @@ inline size_t gm_lds_doubles(int dt) {
 }
 // workgroups per restart: a tile row of 256 points or more each, all
 // workgroups of the launch resident at once (they wait for each other)
+static std::atomic<int> g_gmm_cap{0};   // 0 = not set through the C ABI
+
 inline int gm_wgs(long long n, int n_init) {
-  // NB_GMM_MAX_WGS: cap (1 = one workgroup per restart).  The workgroups of
-  // a restart wait for each other, so all of a launch must be resident at
-  // once; processes that SHARE a GPU (several ranks on one device) and fit
-  // at the same time should not count on that -- they set the cap to 1.
-  static const int cap = []() {
+  // The workgroups of a restart wait for each other inside an ordinary
+  // launch, so all of a launch must be resident at once.  Three limits:
+  //  * NB_GMM_MAX_WGS / nb_gmm_set_max_wgs(): processes that SHARE a GPU
+  //    (several ranks on one device) and fit at the same time cannot count
+  //    on residency -- they set the cap to 1 (parallel.py does when it finds
+  //    two ranks on one device);
+  //  * half of the device's CUs for the whole launch (one workgroup per CU
+  //    at this kernel's LDS size; a partitioned device has 32-128 CUs, not
+  //    256) -- the other half stays free for whatever else is in flight;
+  //  * GM_MAXW.
+  static const int env_cap = []() {
     const char* e = getenv("NB_GMM_MAX_WGS");
     const int v = e != nullptr ? atoi(e) : GM_MAXW;
     return v < 1 ? 1 : (v > GM_MAXW ? GM_MAXW : v);
   }();
+  static const int half_cus = []() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                              dev) != hipSuccess || cus <= 0)
+      cus = 64;
+    return cus / 2;
+  }();
+  const int set_cap = g_gmm_cap.load(std::memory_order_relaxed);
+  const int cap = set_cap > 0 && set_cap < env_cap ? set_cap : env_cap;
   long long w = n / 256;
   if (w > cap) w = cap;
-  if (w * n_init > 128) w = 128 / n_init;
+  if (w * n_init > half_cus) w = half_cus / n_init;
   return (int)(w < 1 ? 1 : w);
 }
 
@@ -846,5 +865,10 @@ int nb_launch_gmm(const double* x, long long n, int d, int n_init,
   }
   if (rc != NB_OK) return rc;
   NB_HIP_CHECK(hipGetLastError());
+  return NB_OK;
+}
+
+int nb_gmm_set_cap_impl(int max_wgs) {
+  g_gmm_cap.store(max_wgs < 0 ? 0 : max_wgs, std::memory_order_relaxed);
   return NB_OK;
 }

@@ -16,11 +16,28 @@ from scipy.linalg import solve_triangular
 from . import _lib
 
 
+# (the raw handle of torch's current stream: torch.cuda.current_stream()
+# builds a Stream object, ~10 us, and the hot loop asks ~10 times a step.  The
+# two accessors are private torch API -- resolved once here, with the public
+# route for a torch build that lacks them)
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _cur_device = torch._C._cuda_getDevice
+except AttributeError:                                 # pragma: no cover
+    _raw_stream = None
+
+
 def _stream():
-    # (the raw handle of torch's current stream: torch.cuda.current_stream()
-    # builds a Stream object, ~10 us, and the hot loop asks ~10 times a step)
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(
-        torch._C._cuda_getDevice()))
+    if _raw_stream is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream(_cur_device()))
+
+
+def _itemsize(dtype):
+    try:
+        return dtype.itemsize                          # torch >= 2.1
+    except AttributeError:                             # pragma: no cover
+        return torch.empty((), dtype=dtype).element_size()
 
 
 def _ptr(t):
@@ -577,7 +594,7 @@ def _buffer(role, shape, dtype, reuse):
     to hipMalloc -- tens of milliseconds each -- in the middle of a run."""
     if not reuse:
         return torch.empty(shape, dtype=dtype, device='cuda')
-    n_bytes = math.prod(shape) * dtype.itemsize
+    n_bytes = math.prod(shape) * _itemsize(dtype)
     buf = _SCRATCH.get(role)
     if buf is None or buf.numel() < n_bytes:
         _SCRATCH[role] = buf = None        # release before growing

@@ -95,6 +95,28 @@ class ShardedComm:
         # breakdown
         self.seconds = 0.0
         self.calls = 0
+        self._guard_shared_devices()
+
+    def _guard_shared_devices(self):
+        """Ranks that SHARE a GPU (tests, a CPX partition handed to several
+        processes) cannot count on all workgroups of a mixture fit being
+        resident while another rank's fit runs on the same CUs: one workgroup
+        per restart then (``nb_gmm_set_max_wgs``)."""
+        if not torch.cuda.is_available():
+            return
+        import socket
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = (socket.gethostname(),
+                 str(getattr(props, 'uuid', '')) or 'dev',
+                 getattr(props, 'pci_bus_id', -1),
+                 getattr(props, 'pci_device_id', -1),
+                 getattr(props, 'pci_domain_id', -1))
+        seen = [None] * self.world
+        dist.all_gather_object(seen, ident, group=self.group)
+        self.shared_device = len(set(seen)) < len(seen)
+        if self.shared_device:
+            from . import _lib
+            _lib.check(_lib.load().nb_gmm_set_max_wgs(1))
 
     def describe(self, device='cuda'):
         """What the communicator really spans: backend, ranks counted by an

@@ -621,6 +621,9 @@ class Sampler:
                     b.cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
                     for b in ll[1:]])
                 ll = ll[0]
+            # (whatever the likelihood returns -- float32, a column, a strided
+            # view -- joins the shell's storage as float64 values in a row)
+            ll = ll.reshape(-1).to(torch.float64).contiguous()
             self.n_like += ll.shape[0]
             return (ll.cpu().numpy() if fetch else None), ll, blobs
 
@@ -699,9 +702,23 @@ class Sampler:
             ).reshape(-1, width)[:interleaved_to]
         n = table.shape[0]
         out = np.ascontiguousarray(table).reshape(-1).view(dtype)
-        tail = np.shape(blobs)[1:] if np.ndim(blobs) > 1 and have > 1 else ()
-        if not tail and out.size != n:
-            tail = (out.size // n,)
+        # The shape of one row is agreed on ONCE per run: a rank whose share
+        # has a single row (np.squeeze in _pack_blobs drops the row axis) or
+        # none cannot tell (2, 3) from (6,) -- the widest description any rank
+        # offers wins (ranks with several rows know it) and is kept.
+        if self.__dict__.get('_blob_tail') is None:
+            mine = tuple(np.shape(blobs)[1:]) if np.ndim(blobs) > 1 \
+                and have > 1 else ()
+            code = [float(len(mine))] + [float(v) for v in mine] + \
+                [0.0] * (4 - len(mine))
+            code = [comm.max_float(v, 'cuda') for v in code[:5]]
+            tail = tuple(int(v) for v in code[1:1 + int(code[0])])
+            if not tail and n > 0 and out.size != n:
+                tail = (out.size // n,)
+            if n > 0 and (code[0] > 0 or out.size == n):
+                self._blob_tail = tail
+        else:
+            tail = self._blob_tail
         return out.reshape((n,) + tuple(tail))
 
     def _shell_slice(self, index):
@@ -799,9 +816,12 @@ class Sampler:
         stats = None
         if log_l is None:
             view = self._shell_slice(shell)[0]
-            both = torch.cat([device.shell_stats(view), log_l_dev])
-            both = both.cpu().numpy()
-            stats, log_l = both[:4], both[4:]
+            if view.shape[0] > 0:
+                both = torch.cat([device.shell_stats(view), log_l_dev])
+                both = both.cpu().numpy()
+                stats, log_l = both[:4], both[4:]
+            else:
+                log_l = log_l_dev.cpu().numpy()
         self.log_l[shell] = _grow(self.log_l[shell], log_l)
         if blobs is not None:                      # sampler.py:1137-1141
             if self.blobs is None:

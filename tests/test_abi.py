@@ -25,7 +25,7 @@ def test_library_exports_all_declared_symbols():
     assert sorted(_lib.exported_symbols()) == names
     header = open(os.path.join(ROOT, 'include', 'nautilus_hip.h')).read()
     declared = int(re.search(r'#define NB_ABI_VERSION (\d+)', header).group(1))
-    assert lib.nb_abi_version() == declared == _lib.ABI_VERSION == 5
+    assert lib.nb_abi_version() == declared == _lib.ABI_VERSION == 6
 
 
 def test_missing_library_fails_loudly(monkeypatch):

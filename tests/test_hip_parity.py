@@ -827,18 +827,38 @@ def test_transform_and_standardize(dev, d):
                        rtol=0, atol=1e-11)
 
 
-def test_gmm_degenerate_input_falls_back(dev):
-    """Every device restart fails on a degenerate cloud (all points equal up
-    to a few duplicates); the labels then come from scikit-learn."""
-    import warnings
+def test_gmm_degenerate_input_is_a_rejected_split(dev):
+    """A cloud the mixture cannot divide (every point the same: each device
+    restart ends its Lloyd iterations with an empty cluster) makes
+    ``two_component_labels`` raise ``geometry.DegenerateMixture`` -- no host
+    fit stands behind the device one -- and ``Union.split`` treats that as a
+    split that does not pay (union.py:204-207): the member is blocked, the
+    union stays as it was and the run goes on.  A cloud with a few displaced
+    points still divides."""
     from nautilus_amd import geometry
+    from nautilus_amd.bounds import Union
     x = np.zeros((300, 4)) + 0.5
-    x[:5] += 0.1
     fits = dev.gmm_fit(x, n_init=4, seed=1)
-    assert len(fits) == 4
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        lab = geometry.two_component_labels(x, 5, 3)
+    assert len(fits) == 4 and all(f['failed'] for f in fits)
+    with pytest.raises(geometry.DegenerateMixture):
+        geometry.two_component_labels(x, 5, 3)
+    # the union of a regular cloud whose fit is made to fail: blocked, intact
+    rng = np.random.default_rng(0)
+    pts = 0.5 + 0.05 * rng.normal(size=(400, 4))
+    u = Union.compute(pts, rng=np.random.default_rng(1))
+    real = geometry.two_component_labels
+
+    def failing(*args):
+        raise geometry.DegenerateMixture('provoked')
+    geometry.two_component_labels = failing
+    try:
+        assert u.split() is False
+    finally:
+        geometry.two_component_labels = real
+    assert len(u.bounds) == 1 and bool(u.block[0])
+    y = np.zeros((300, 4)) + 0.5
+    y[:5] += 0.1
+    lab = geometry.two_component_labels(y, 5, 3)
     assert lab.shape == (300,) and set(np.unique(lab)) <= {0, 1}
 
 
