@@ -26,6 +26,8 @@ Extra objects on the JSON line: ``roofline`` (dominant kernel of the timed
 region, HIP-event timed; ``traffic`` is measured only with ``--pmc-traffic``,
 which re-runs this command under ``rocprofv3 --pmc`` in child processes),
 ``roofline_contains`` (the north star's streaming Ellipsoid.contains kernel),
+``roofline_draw`` (the proposal draw: proposals/s, bytes written against HBM,
+fp64 vector operations against the peak),
 ``cpu_baseline`` (the CPU oracle continuing the same sampler state through
 the reference's multiprocess-pool path on all host cores, and on one core,
 for a bounded time).
@@ -735,6 +737,43 @@ def main():
             flop_per_point=d2 * (d2 + 1), bytes_per_point=8 * d2 + 1,
             avg_launch_ms=ms, inside_fraction=float(mask.double().mean()))
         del x, mask
+        # ... and the proposal draw (Ellipsoid.sample, basic.py:362-381), the
+        # second kernel of the timed step: VALU work (Philox, Box-Muller
+        # polynomials, the triangular product x = c + B z), 8 D bytes written
+        # per proposal.  Priced against both roofs it could meet; the issue
+        # counters behind the statement of what binds it are committed
+        # (profiles/r06/draw_pmc.txt: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES)
+        n3 = 1 << 22
+        draw_dev = ell.device_bound()
+        draw_dev.propose(7, 0, n3)
+        ev0.record()
+        for _ in range(reps):
+            xs = draw_dev.propose(7, 0, n3)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        # fp64 operations per proposal as the kernel issues them: the
+        # triangular product D (D + 1), |z|^2 and the rescaling 3 D, and per
+        # Box-Muller pair the polynomial log (47), sincos (49), the square
+        # root (~12) and four multiplications -- nb_draw.h, counted by hand
+        flop_draw = d * (d + 1.0) + 3.0 * d + 0.5 * d * 112.0
+        wr = n3 * 8.0 * d / (ms * 1e-3) / 1e9
+        tf = n3 * flop_draw / (ms * 1e-3) / 1e12
+        out['roofline_draw'] = dict(
+            kernel='nb_draw_kernel', bound='valu', proposals=n3,
+            avg_launch_ms=ms, proposals_per_s=n3 / (ms * 1e-3),
+            bytes_written_per_proposal=8 * d, hbm_write_gbs=wr,
+            hbm_frac=wr / HBM_PEAK_GBS,
+            fp64_flop_per_proposal=flop_draw, achieved=tf,
+            peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s (fp64 vector; the vector '
+            'and the matrix peak of this part are the same 78.6)',
+            frac=tf / FP64_MFMA_PEAK_TF,
+            integer_work='Philox4x32-10: D / 4 calls of 10 rounds, four '
+                         'quarter-rate 32-bit multiplies each -- ~16 issue '
+                         'cycles per round next to ~8 fp64 operations per '
+                         'output byte; not in the flop count',
+            counters='profiles/r06/draw_pmc.txt')
+        del xs
         # ... and the two-stage bound evaluation (geometric stage + candidate
         # lists + one batched emulator launch) of a bound with four outer
         # members and four neural bounds at the same dimension: median of

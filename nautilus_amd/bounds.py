@@ -405,6 +405,31 @@ class UnitCubeEllipsoidMixture(_DeviceBoundBase):
 # rejection sampling shared by Union and NautilusBound
 # ---------------------------------------------------------------------------
 
+class _PrefetchSlots:
+    """Output buffers of refills that are in flight (``prefetch``): a refill
+    in flight keeps its compacted rows in a scratch buffer of its own until
+    they land in the bound's queue.  At most N_SLOTS are outstanding in a
+    process; asking for another lands the oldest (long finished) first."""
+
+    N_SLOTS = 4
+    free = list(range(N_SLOTS))
+    owners = []                # (bound, slot), oldest first
+
+    @classmethod
+    def acquire(cls, bound):
+        if not cls.free:
+            oldest = cls.owners[0][0]
+            oldest._land_pending()
+        slot = cls.free.pop()
+        cls.owners.append((bound, slot))
+        return slot
+
+    @classmethod
+    def release(cls, slot):
+        cls.owners = [(b, s) for b, s in cls.owners if s != slot]
+        cls.free.append(slot)
+
+
 class _RejectionSampler(_DeviceBoundBase):
     """FIFO + Monte-Carlo volume counters around ``DeviceBound.sample_launch``
     (the chunked loops of bounds/union.py:305-327 and bounds/nautilus.py:
@@ -418,10 +443,62 @@ class _RejectionSampler(_DeviceBoundBase):
         self.n_sample = 0
         self.n_reject = 0
 
-    def _queue(self):
+    def _queue(self, land=True):
+        """The FIFO; a refill launched ahead of time (``prefetch``) lands in
+        it first -- whoever looks at the queue sees every accepted point."""
+        if land and self.__dict__.get('_pending') is not None:
+            self._land_pending()
         if self._fifo is None:
             self._fifo = _Fifo(self.n_dim)
         return self._fifo
+
+    def _land_pending(self):
+        """Counters and rows of the launch ``prefetch`` issued: its counts
+        come to the host now (no wait if the launch has finished meanwhile),
+        the rows move into the queue, the slot is free again."""
+        rows, counts, n_draw, slot = self._pending
+        self._pending = None
+        _PrefetchSlots.release(slot)
+        self._collect(rows, counts.cpu().numpy(), n_draw)
+
+    def prefetch(self, n_points):
+        """Launch the refill that ``sample_device(n_points)`` would need --
+        WITHOUT waiting for it: draw, accept and compact are queued behind
+        whatever the stream holds, the counts stay on the device until the
+        queue is looked at next (``_queue``).  The sampler calls this for the
+        shell it expects to sample next, behind the last launch of the
+        current batch: the GPU works on the refill while the host does the
+        batch's bookkeeping (reference: the refill of nautilus.py:212-244
+        starts when ``sample`` is called, with the host idle meanwhile).  The
+        proposals are those the synchronous refill would have drawn -- the
+        same Philox stream, consumed in order -- so the points a bound hands
+        out do not depend on when its refills were launched."""
+        if self.__dict__.get('_pending') is not None:
+            return False
+        need = n_points - len(self._queue(land=False))
+        if need <= 0:
+            return False
+        n_draw = self._launch(need)
+        seed, off = self._stream.take(n_draw)
+        slot = _PrefetchSlots.acquire(self)
+        rows, counts = self.device_bound().sample_launch(
+            seed, off, n_draw, reuse=True, out_role='prefetch%d' % slot)
+        self._pending = (rows, counts, n_draw, slot)
+        return True
+
+    def drop_pending(self):
+        """Forget a prefetched launch (its proposals were drawn and are simply
+        not looked at: i.i.d. draws, independent of everything kept)."""
+        if self.__dict__.get('_pending') is not None:
+            _PrefetchSlots.release(self._pending[3])
+            self._pending = None
+
+    def __getstate__(self):
+        if self.__dict__.get('_pending') is not None:
+            self._land_pending()
+        state = super().__getstate__()
+        state.pop('_pending', None)
+        return state
 
     @property
     def points(self):
@@ -503,6 +580,7 @@ class _RejectionSampler(_DeviceBoundBase):
         return self._queue().pop(n_points)
 
     def _reset_sampling(self, rng=None):
+        self.drop_pending()
         self._queue().clear()
         self.n_sample = 0
         self.n_reject = 0

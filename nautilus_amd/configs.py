@@ -21,7 +21,7 @@ def baseline_config(name):
     ``n_update`` makes every shell thicker, and the volume an emulator cuts off
     wrongly grows with it (30-D: log Z = -138.34 / -138.23 / -138.31 / -138.72
     at n_batch 100 / 256 / 1024 / 8192, reference at its default 100: -138.22,
-    exact -137.49)."""
+    exact -137.49; docs/history/round2.md)."""
     if name == 'C1':
         # README example of the reference: 3-D Gaussian
         return dict(
@@ -72,7 +72,7 @@ def baseline_config(name):
         # mass below), where the iso-likelihood region has shrunk by ~7.8 nats
         # per dimension; at ~0.7 nats per bound that is ~100 bounds at D = 10,
         # ~170 at D = 20, ~250 at D = 30 and ~830 at D = 100 (measured: 8.0-8.4
-        # bounds per dimension)
+        # bounds per dimension; docs/history/round4.md)
         d = int(name[4:])
         return dict(
             likelihood=FunnelLikelihood(d), n_dim=d, n_live=10000,

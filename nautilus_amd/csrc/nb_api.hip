@@ -24,7 +24,7 @@ int nb_launch_eval_fast(const double* blob_dev, int n_dim, bool sample, int m,
                         unsigned char* out_u8, double* out_f64,
                         unsigned long long seed, unsigned long long offset,
                         hipStream_t stream);
-int nb_launch_cand(int dt, const double* const* blobs_dev,
+int nb_launch_cand(int dt, int n_dim, const double* const* blobs_dev,
                    const int* group_base_dev, int nb, int n_groups, int b_off,
                    int g_off, int accumulate, int mode, const double* x,
                    long long n, unsigned char* st, int* first, int* work,
@@ -758,7 +758,7 @@ int nb_list_eval(const nb_boundlist* l, int32_t mode, const double* x,
     const int g0 = l->group_base[b0], ng = l->group_base[b1] - g0;
     int *dense = nullptr, *totals = nullptr;
     long long n_pad = 0;
-    int rc = nb_launch_cand(l->dt, l->ptrs_dev + b0, l->group_base_dev + b0,
+    int rc = nb_launch_cand(l->dt, l->n_dim, l->ptrs_dev + b0, l->group_base_dev + b0,
                             b1 - b0, ng, b0, g0, b0 > 0 ? 1 : 0, mode, x, n,
                             st, first, (int*)work, 0, 0, &dense, &totals,
                             &n_pad, as_stream(stream));
@@ -825,7 +825,7 @@ int nb_accept_staged(const nb_bound* b, uint64_t seed, uint64_t offset,
     hu[0] = now_us();
     (void)hipEventRecord(e[0], as_stream(stream));
   }
-  int rc = nb_launch_cand(b->dt, b->self_list_dev, b->group_base_dev, 1,
+  int rc = nb_launch_cand(b->dt, b->n_dim, b->self_list_dev, b->group_base_dev, 1,
                           b->n_groups, 0, 0, 0, 2, x, n, flags, nullptr,
                           (int*)work, seed, offset, &dense, &totals, &n_pad,
                           as_stream(stream));

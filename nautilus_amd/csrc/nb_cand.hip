@@ -68,15 +68,23 @@ struct CandArgs {
   unsigned long long* counters; // optional, as in nb_eval.hip
 };
 
-// the k-steps of a lower-triangular ellipsoid transform in execution order
-template <int DT>
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+
+// the k-steps of a lower-triangular ellipsoid transform in execution order.
+// SMALL: the last row tile holds at most four real rows (n_dim mod 16 in
+// 1..4: n_dim 50 has two, n_dim 100 four) -- its last two k-steps then hold
+// zero padding only (the K permutation pairs k-steps: 2 j, 2 j + 1 cover the
+// features 8 j .. 8 j + 7) and are left out, and the tile itself runs on
+// v_mfma_f64_4x4x4_4b (cand_inside).
+template <int DT, bool SMALL>
 struct StepTable {
-  static constexpr int N = 2 * DT * (DT + 1);
+  static constexpr int N = 2 * DT * (DT + 1) - (SMALL ? 2 : 0);
   unsigned char ht[N], ks[N];
   constexpr StepTable() : ht(), ks() {
     int i = 0;
     for (int h = 0; h < DT; ++h)
-      for (int k = 0; k < 4 * (h + 1); ++k) {
+      for (int k = 0; k < 4 * (h + 1) - ((SMALL && h == DT - 1) ? 2 : 0);
+           ++k) {
         ht[i] = (unsigned char)h;
         ks[i] = (unsigned char)k;
         ++i;
@@ -88,14 +96,22 @@ struct StepTable {
 // its ellipsoid.  X(t, ks) = coordinate slot ks of tile t (lane layout of
 // nb_tile.h).  Operands (A tile rows, centre) come from global memory PD
 // k-steps ahead; same summation order as ell_eval / ell_eval_centre, so r2
-// is bit-identical to the other kernels'.
-template <int DT, int T, int PD, class XF>
+// is bit-identical to the other kernels'.  SMALL (see StepTable): the last
+// row tile as 4 rows x 16 points on v_mfma_f64_4x4x4_4b -- 16 instead of 64
+// cycles per k-step; the A operand (lane i + 4 b + 16 k: row i, replicated
+// over the four blocks b) is gathered from the same tile storage, the B
+// operand is the 16x16x4 one, and the result (lane p + 16 i) is bit for bit
+// register 0 of the 16x16x4 accumulator: same k order per row, and the
+// squares land in the lane groups where the full tile had them (rows 4..15 of
+// that tile are zero padding and added +0.0).
+template <int DT, int T, int PD, bool SMALL, class XF>
 __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
                                             bool has_box, XF&& X, int lane,
                                             int lg, bool (&inside)[T]) {
   constexpr int DP = 16 * DT;
-  constexpr StepTable<DT> TAB{};
-  constexpr int N = StepTable<DT>::N;
+  constexpr StepTable<DT, SMALL> TAB{};
+  constexpr int N = StepTable<DT, SMALL>::N;
+  const int lane4 = (lane >> 4) * 16 + (lane & 3);
   const nb_gd* lo = blk + 2;
   const nb_gd* hi = lo + DP;
   const nb_gd* c = hi + DP;
@@ -123,21 +139,27 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
     double a[PD], cv[PD];
     auto fetch = [&](int i, int slot) __attribute__((always_inline)) {
       const int ht = TAB.ht[i], ks = TAB.ks[i];
-      a[slot] = tiles[((ks >> 2) * DT + ht) * NB_TILE + (ks & 3) * 64 + lane];
+      a[slot] = tiles[((ks >> 2) * DT + ht) * NB_TILE + (ks & 3) * 64 +
+                      ((SMALL && ht == DT - 1) ? lane4 : lane)];
       cv[slot] = c[4 * ks + lg];
     };
 #pragma unroll
     for (int i = 0; i < PD && i < N; ++i) fetch(i, i);
     nb_d4 acc[T];
+    double r4[T];
     // (the order is pinned: left alone, the scheduler hoists the loads of all
     // k-steps to the top and spills)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int ht = TAB.ht[i], ks = TAB.ks[i];
+      const bool small = SMALL && ht == DT - 1;
       if (ks == 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < T; ++t) {
+          acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
+          r4[t] = 0.0;
+        }
       }
       const double av = a[i % PD];
       double cc = cv[i % PD];
@@ -148,10 +170,18 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
       __builtin_amdgcn_sched_barrier(0);
       if (i + PD < N) fetch(i + PD, i % PD);
       __builtin_amdgcn_sched_barrier(0);
+      if (small) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = MFMA(av, X(t, ks) - cc, acc[t]);
+        for (int t = 0; t < T; ++t) r4[t] = MFMA4(av, X(t, ks) - cc, r4[t]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = MFMA(av, X(t, ks) - cc, acc[t]);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if (ks == 4 * (ht + 1) - 1) {
+      if (small && ks == 4 * (ht + 1) - 3) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) part[t] += r4[t] * r4[t];
+      } else if (!small && ks == 4 * (ht + 1) - 1) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -169,7 +199,7 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
 // wavefront per SIMD; two per SIMD run without spills up to n_dim = 64 and
 // were faster than three with spills: 2.81 against 3.10 ms per 2^20 proposals
 // at n_dim = 50, K = M = 4)
-template <int DT, int T, int OCC, bool SAMPLE>
+template <int DT, int T, int OCC, bool SAMPLE, bool SMALL>
 __global__ void __launch_bounds__(64 * CD_WPB)
 __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   constexpr int DP = 16 * DT;
@@ -351,7 +381,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
           const bool has_ell = ((const NB_G long long*)blk)[0] > 0;
           const bool has_box = ((const NB_G long long*)blk)[1] != 0;
           bool ins[T];
-          cand_inside<DT, T, PD>(blk, has_ell, has_box, X, lane, lgb, ins);
+          cand_inside<DT, T, PD, SMALL>(blk, has_ell, has_box, X, lane, lgb, ins);
 #pragma unroll
           for (int t = 0; t < T; ++t) k_cnt[t] += ins[t] ? 1 : 0;
         }
@@ -397,7 +427,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         if (!__any(any_want)) break;
         const nb_gd* nb_m = nblk0 + m * neural_stride;
         bool ins[T];
-        cand_inside<DT, T, PD>(nb_m, true, false, X, lane, lgb, ins);
+        cand_inside<DT, T, PD, SMALL>(nb_m, true, false, X, lane, lgb, ins);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const bool test = want[t] && !decided[t];
@@ -486,19 +516,27 @@ nb_cand_compact_kernel(const int* __restrict__ counts,
   }
 }
 
-template <int DT, int T, int OCC, bool SAMPLE>
+template <int DT, int T, int OCC, bool SAMPLE, bool SMALL>
 void launch_cand_m(const CandArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)a.n_groups * CD_WPB * sizeof(int);
   const int blocks = (a.n_waves + CD_WPB - 1) / CD_WPB;
-  hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, SAMPLE>),
+  hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, SAMPLE, SMALL>),
                      dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream, a);
 }
 
-// T_S / T_L: tiles per wavefront for proposals / lists (cand_tiles)
+// T_S / T_L: tiles per wavefront for proposals / lists (cand_tiles); `small`:
+// the last row tile has at most four real rows (StepTable)
 template <int DT, int T_S, int T_L, int OCC>
-int launch_cand_t(const CandArgs& a, hipStream_t stream) {
-  if (a.mode == CM_SAMPLE) launch_cand_m<DT, T_S, OCC, true>(a, stream);
-  else launch_cand_m<DT, T_L, OCC, false>(a, stream);
+int launch_cand_t(const CandArgs& a, bool small, hipStream_t stream) {
+  if (DT > 1 && small) {
+    if (a.mode == CM_SAMPLE)
+      launch_cand_m<DT, T_S, OCC, true, (DT > 1)>(a, stream);
+    else
+      launch_cand_m<DT, T_L, OCC, false, (DT > 1)>(a, stream);
+  } else {
+    if (a.mode == CM_SAMPLE) launch_cand_m<DT, T_S, OCC, true, false>(a, stream);
+    else launch_cand_m<DT, T_L, OCC, false, false>(a, stream);
+  }
   return NB_OK;
 }
 
@@ -550,7 +588,7 @@ long long nb_cand_work_bytes(int dt, int mode, long long n, int n_groups) {
 
 // candidates + compaction.  On return (in stream order) totals[g] and
 // dense[g * n_pad ...] describe the second stage's work.
-int nb_launch_cand(int dt, const double* const* blobs_dev,
+int nb_launch_cand(int dt, int n_dim, const double* const* blobs_dev,
                    const int* group_base_dev, int nb, int n_groups, int b_off,
                    int g_off, int accumulate, int mode, const double* x, long long n, unsigned char* st, int* first,
                    int* work, unsigned long long seed,
@@ -580,15 +618,17 @@ int nb_launch_cand(int dt, const double* const* blobs_dev,
   a.counts = dense + gp;
   int* totals = a.counts + (long long)n_groups * a.n_waves;
   int rc = NB_OK;
+  const int live = n_dim - 16 * (dt - 1);        // real rows of the last tile
+  const bool small = live >= 1 && live <= 4;
   switch (dt) {
-    case 1: rc = launch_cand_t<1, 2, 2, 4>(a, stream); break;
-    case 2: rc = launch_cand_t<2, 2, 2, 3>(a, stream); break;
-    case 3: rc = launch_cand_t<3, 2, 2, 2>(a, stream); break;
-    case 4: rc = launch_cand_t<4, 2, 2, 2>(a, stream); break;
-    case 5: rc = launch_cand_t<5, 2, 2, 2>(a, stream); break;
-    case 6: rc = launch_cand_t<6, 2, 1, 2>(a, stream); break;
-    case 7: rc = launch_cand_t<7, 2, 1, 2>(a, stream); break;
-    case 8: rc = launch_cand_t<8, 2, 1, 2>(a, stream); break;
+    case 1: rc = launch_cand_t<1, 2, 2, 4>(a, small, stream); break;
+    case 2: rc = launch_cand_t<2, 2, 2, 3>(a, small, stream); break;
+    case 3: rc = launch_cand_t<3, 2, 2, 2>(a, small, stream); break;
+    case 4: rc = launch_cand_t<4, 2, 2, 2>(a, small, stream); break;
+    case 5: rc = launch_cand_t<5, 2, 2, 2>(a, small, stream); break;
+    case 6: rc = launch_cand_t<6, 2, 1, 2>(a, small, stream); break;
+    case 7: rc = launch_cand_t<7, 2, 1, 2>(a, small, stream); break;
+    case 8: rc = launch_cand_t<8, 2, 1, 2>(a, small, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;

@@ -271,16 +271,20 @@ class DeviceBound:
             self.dense_need = float(totals.sum()) / max(1, n)
         return flags
 
-    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False):
+    def sample_launch(self, seed, offset, n_draw, mask=2, reuse=False,
+                      out_role='compact'):
         """One launch of the device ``sample`` pipeline: draw, accept,
         compact.  Returns (points, counters) with counters = int64 tensor
         [n kept by the outer union, n kept in total] still on the device.
         ``reuse=True`` (the bounds' refill loops): the launch works in the
         process-wide scratch buffers and the returned rows are only valid
-        until the next such launch."""
+        until the next such launch (the next launch with the same
+        ``out_role``: a refill in flight keeps its rows in a role of its
+        own)."""
         x = self.propose(seed, offset, n_draw, reuse)
         flags = self.accept(seed, offset, x, reuse)
-        out, counts, _ = compact_rows(x, flags, mask, reuse=reuse)
+        out, counts, _ = compact_rows(x, flags, mask, reuse=reuse,
+                                      out_role=out_role)
         return out, counts
 
 
@@ -604,7 +608,8 @@ def _buffer(role, shape, dtype, reuse):
     return buf[:n_bytes].view(dtype).view(shape)
 
 
-def compact_rows(x, flags, mask=1, want_index=False, reuse=False, flip=0):
+def compact_rows(x, flags, mask=1, want_index=False, reuse=False, flip=0,
+                 out_role='compact'):
     """Stable compaction of the rows of ``x`` with ((flags ^ flip) & mask)
     != 0.
 
@@ -613,7 +618,7 @@ def compact_rows(x, flags, mask=1, want_index=False, reuse=False, flip=0):
     [rows with bit0, rows kept]."""
     lib = _lib.load()
     n, d = x.shape
-    out = _buffer('compact', (n, d), torch.float64, reuse)
+    out = _buffer(out_role, (n, d), torch.float64, reuse)
     # (written by the scan kernel, or zeroed by the launcher for n = 0)
     counts = torch.empty(2, dtype=torch.int64, device='cuda')
     scratch = _buffer('compact_scratch',

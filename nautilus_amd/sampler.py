@@ -388,6 +388,7 @@ class Sampler:
             discard_exploration=False, timeout=np.inf, verbose=False):
         """sampler.py:373-505."""
         t0 = time()
+        self._n_shell_min = n_shell
         if verbose:
             print('Starting the nautilus_amd sampler (MI355X hot path)...')
             self.print_status(header=True)
@@ -533,12 +534,7 @@ class Sampler:
             if transfer or later is None:
                 n_req = need             # every drawn point is in the shell
             else:
-                # in-shell fraction seen so far (exploration points count
-                # even when they are discarded from the estimate)
-                n_s = self.shell_n_sample[s_idx]
-                frac = (len(self.log_l[s_idx]) + 1.0) / (n_s + 2.0) \
-                    if n_s > 0 else 0.5
-                n_req = int(min(4 * device_block(), need / frac * 1.15 + 256))
+                n_req = self._shell_request(s_idx, need)
             x = bound.sample_device(n_req)
             if later is not None:
                 # sampler.py:796-799 on the device: flag the points inside a
@@ -577,6 +573,59 @@ class Sampler:
         if shell_t is None:
             return pts, n_bound
         return pts, n_bound, idx_t
+
+    def _shell_request(self, s_idx, need):
+        """Points to ask the bound of shell ``s_idx`` for when ``need`` of
+        them must lie outside all later bounds: the in-shell fraction seen so
+        far (exploration points count even when they are discarded from the
+        estimate) with 15 % on top."""
+        if s_idx == len(self.bounds) - 1:
+            return need
+        n_s = self.shell_n_sample[s_idx]
+        frac = (len(self.log_l[s_idx]) + 1.0) / (n_s + 2.0) \
+            if n_s > 0 else 0.5
+        return int(min(4 * device_block(), need / frac * 1.15 + 256))
+
+    def _predict_next_shell(self, shell, n_new):
+        """The shell the loop of ``run`` will most likely sample after the
+        batch of ``n_new`` points that was just drawn for ``shell`` -- BEFORE
+        that batch's likelihoods are known: rule of sampler.py:482-491 with
+        the shell's count grown by the batch and its mean likelihood and
+        N_eff / N taken as unchanged.  Only a guess (``prefetch`` acts on it:
+        a wrong guess costs nothing but the order of the work)."""
+        s = shell % len(self.bounds)
+        if not self.explored:
+            return len(self.bounds) - 1
+        n = np.array(self.shell_n, dtype=float)
+        n_eff = np.array(self.shell_n_eff, dtype=float)
+        known = n[s] > 0
+        n[s] += n_new
+        n_min = getattr(self, '_n_shell_min', 1)
+        if np.any(n < n_min):
+            return int(np.flatnonzero(n < n_min)[0])
+        if not known or not np.all(n_eff > 0):
+            return None
+        n_eff[s] *= n[s] / (n[s] - n_new)
+        with np.errstate(all='ignore'):
+            gain = (self.shell_log_l + self.shell_log_v - 0.5 * np.log(n) -
+                    0.5 * np.log(n_eff))
+        if not np.any(np.isfinite(gain)):
+            return None
+        return int(np.nanargmax(gain))
+
+    def _prefetch_next(self, shell, n_new):
+        """Queue the refill of the bound the next batch will most likely ask
+        (``_RejectionSampler.prefetch``) behind the launches of the current
+        batch, so that the GPU draws and filters proposals while the host
+        waits for this batch's numbers and does its bookkeeping."""
+        if not PREFETCH or self.comm is not None:
+            return
+        nxt = self._predict_next_shell(shell, n_new)
+        if nxt is None:
+            return
+        bound = self.bounds[nxt]
+        if hasattr(bound, 'prefetch'):
+            bound.prefetch(self._shell_request(nxt, self.n_batch))
 
     def _pair_with_candidates(self, x, shell_t, idx_t):
         """Pair fresh points of the newest shell with stored candidates of
@@ -797,6 +846,11 @@ class Sampler:
             else:
                 # (a device likelihood's values come to the host further
                 # down, in one transfer with the shell statistics)
+                if not self._device_likelihood and (
+                        self.explored or len(self.shell_t) == 0):
+                    # a host likelihood: the GPU refills the next batch's
+                    # queue while the CPU evaluates this one
+                    self._prefetch_next(shell, pts.shape[0])
                 log_l, log_l_dev, blobs = self.evaluate_likelihood(
                     pts, fetch=self.comm is not None or not DEFER_FETCH)
         t2 = time()
@@ -818,6 +872,9 @@ class Sampler:
             view = self._shell_slice(shell)[0]
             if view.shape[0] > 0:
                 both = torch.cat([device.shell_stats(view), log_l_dev])
+                if self.explored:
+                    # behind this batch's last launch, in front of the wait
+                    self._prefetch_next(shell, log_l_dev.shape[0])
                 both = both.cpu().numpy()
                 stats, log_l = both[:4], both[4:]
             else:
@@ -1220,6 +1277,9 @@ class Sampler:
 # statistics (one wait per batch instead of two; profiles/tools/step_ab.py
 # measures both)
 DEFER_FETCH = True
+# refills launched ahead of the batch that will ask for them (``prefetch``);
+# NB_PREFETCH=0 restores the launch-when-asked order (profiles/r06 A/B)
+PREFETCH = os.environ.get('NB_PREFETCH', '1') not in ('0', '')
 
 
 def _grow(cur, new):

@@ -6,7 +6,7 @@ and the reference's own runs of the same problem (tests/golden/e2e_C1.json,
 e2e_C2.json, e2e_C3.json, written by make_golden.py / make_golden_c3.py).  C4
 runs its whole exploration and a sampling phase to a reduced N_eff against the
 analytic evidence.  C5 does not finish at its full dimension anywhere (~830
-bounds with training sets beyond 10^6 rows; the
+bounds with training sets beyond 10^6 rows, docs/history/round4.md; the
 reference's FAQ stops at ~60 dimensions), so it runs for
 a bounded wall time and the test asserts what must hold at any point of a run
 -- every bound built on the device, volumes shrinking, evidence finite and
@@ -232,7 +232,7 @@ def test_C5_funnel_real_size():
     """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
     the device MVEE / mixture fit at 100 dimensions -- 60 s of the run and
     the invariants of a run in progress.  The run itself does not end inside
-    any budget this project has (the exploration front
+    any budget this project has (docs/history/round4.md: the exploration front
     has to walk down the funnel to x_0 ~ 0.27, ~830 bounds at the measured
     8.3 bounds per dimension, with training sets beyond 10^6 rows from bound
     50 on; a GPU lease lasts one hour and a checkpoint of ~10 GB cannot

@@ -360,7 +360,10 @@ def test_pipelined_accept_and_score(dev, d, e, k_outer):
             assert 0 < want.mean() < 1
 
 
-@pytest.mark.parametrize('d,k,m', [(20, 3, 2), (50, 2, 3)])
+# (n_dim mod 16 in 1..4 -- 20, 33, 50, 67, 100: the last row tile of every
+# ellipsoid test runs on the 4-row matrix instruction, nb_cand.hip StepTable)
+@pytest.mark.parametrize('d,k,m', [(20, 3, 2), (50, 2, 3), (33, 2, 2),
+                                   (67, 2, 2), (100, 2, 2), (53, 2, 2)])
 def test_two_stage_large_launch(dev, d, k, m):
     """Bounds with several outer members and several neural bounds go through
     the two device-side stages (nb_cand.hip: geometric tests + candidate

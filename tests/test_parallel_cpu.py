@@ -65,9 +65,11 @@ def _worker(rank, world, port, out_dir):
     # likelihood of a batch every rank holds
     from types import SimpleNamespace
     from nautilus_amd.sampler import Sampler
-    me = SimpleNamespace(comm=comm)
-    for dtype in (np.float32, [('a', '|S10'), ('b', np.int16)], (np.int64, 3)):
+    for dtype in (np.float32, [('a', '|S10'), ('b', np.int16)], (np.int64, 3),
+                  (np.float64, (2, 3))):
         dt = np.dtype(dtype)
+        # (one sampler has one blob layout: the row shape is agreed on once)
+        me = SimpleNamespace(comm=comm)
 
         def blob_of(i):
             if dt.names:
@@ -88,6 +90,16 @@ def _worker(rank, world, port, out_dir):
                                     interleaved_to=n)
         want = np.array([blob_of(i) for i in range(n)], dtype=base)
         assert got.dtype == want.dtype and np.array_equal(got, want)
+        # a share of ONE row (squeezed: its row axis is gone) on the last
+        # rank, several on the others: every rank ends with the same shape
+        n = world + 1
+        per = -(-n // world)
+        local = np.array([blob_of(i) for i in range(rank, n, world)],
+                         dtype=base)
+        got = Sampler._gather_blobs(SimpleNamespace(comm=comm),
+                                    np.squeeze(local), per, interleaved_to=n)
+        want = np.array([blob_of(i) for i in range(n)], dtype=base)
+        assert got.shape == want.shape and np.array_equal(got, want)
     # collective stop decision: true everywhere if true anywhere
     assert comm.any_flag(rank == 1) is True
     assert comm.any_flag(False) is False
