@@ -664,6 +664,9 @@ def main():
         n_bounds=len(sampler.bounds), setup_s=setup_s, shell_fill_s=fill_s,
         points_per_s=(n_like1 - n_like0) / dt,
         device_mallocs_in_timed_region=int(mallocs),
+        # refills launched ahead of the batch that needs them (sampler.py
+        # _prefetch_next): launches issued, guesses that were right / wrong
+        prefetch=dict(getattr(sampler, 'prefetch_stats', {})),
         proposals_per_s=(prop1 - prop0) / dt,
         full_run=dict(wall_s=setup_s + fill_s + dt,
                       ess_per_s=n_eff1 / (setup_s + fill_s + dt)),
@@ -768,10 +771,12 @@ def main():
             peak=FP64_MFMA_PEAK_TF, unit='TFLOP/s (fp64 vector; the vector '
             'and the matrix peak of this part are the same 78.6)',
             frac=tf / FP64_MFMA_PEAK_TF,
-            integer_work='Philox4x32-10: D / 4 calls of 10 rounds, four '
-                         'quarter-rate 32-bit multiplies each -- ~16 issue '
-                         'cycles per round next to ~8 fp64 operations per '
-                         'output byte; not in the flop count',
+            integer_work='Philox4x32-10: D / 4 calls of 10 rounds (four '
+                         '32-bit multiplies + six logic operations each) per '
+                         'proposal -- about as many vector instructions as '
+                         'the fp64 work, not in the flop count',
+            valu_busy='0.77 of the kernel cycles issue a VALU instruction '
+                      'on every SIMD (SQ_ACTIVE_INST_VALU, committed pass)',
             counters='profiles/r06/draw_pmc.txt')
         del xs
         # ... and the two-stage bound evaluation (geometric stage + candidate

@@ -104,10 +104,21 @@ struct StepTable {
 // register 0 of the 16x16x4 accumulator: same k order per row, and the
 // squares land in the lane groups where the full tile had them (rows 4..15 of
 // that tile are zero padding and added +0.0).
-template <int DT, int T, int PD, bool SMALL, class XF>
+//
+// The centre goes through a wavefront-private strip of LDS (`cw`, DP doubles):
+// read from the blob once per block (one or two loads per lane) and from
+// there per k-step.  Straight from the blob it was a second vector-memory
+// instruction per k-step next to the A operand -- and the CU's texture path
+// takes ~16-20 cycles per 64-lane load whatever its addresses are: with eight
+// wavefronts per CU that path, not the matrix pipe, set the pace (n_dim 50:
+// 4 x 76 loads per 3.6 k cycles of matrix work and SIMD).
+// (STRIP = false: two tiles at n_dim > 112 have no register left for it and
+// read the centre from the blob as before.)
+template <int DT, int T, int PD, bool SMALL, bool STRIP, class XF>
 __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
                                             bool has_box, XF&& X, int lane,
-                                            int lg, bool (&inside)[T]) {
+                                            int lg, double* cw,
+                                            bool (&inside)[T]) {
   constexpr int DP = 16 * DT;
   constexpr StepTable<DT, SMALL> TAB{};
   constexpr int N = StepTable<DT, SMALL>::N;
@@ -137,11 +148,18 @@ __device__ __forceinline__ void cand_inside(const nb_gd* blk, bool has_ell,
   for (int t = 0; t < T; ++t) part[t] = 0.0;
   if (has_ell) {
     double a[PD], cv[PD];
+    // (the strip is the wavefront's own: its LDS operations execute in
+    // order, no barrier)
+    if (STRIP) {
+#pragma unroll
+      for (int j = 0; j < DP; j += 64)
+        if (j + 64 <= DP || lane < DP - j) cw[j + lane] = c[j + lane];
+    }
     auto fetch = [&](int i, int slot) __attribute__((always_inline)) {
       const int ht = TAB.ht[i], ks = TAB.ks[i];
       a[slot] = tiles[((ks >> 2) * DT + ht) * NB_TILE + (ks & 3) * 64 +
                       ((SMALL && ht == DT - 1) ? lane4 : lane)];
-      cv[slot] = c[4 * ks + lg];
+      cv[slot] = STRIP ? cw[4 * ks + lg] : c[4 * ks + lg];
     };
 #pragma unroll
     for (int i = 0; i < PD && i < N; ++i) fetch(i, i);
@@ -211,6 +229,8 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   // operands; profiles/r05/cand_prefetch_depth_and_three_tiles.txt)
   constexpr int PD = OCC >= 4 ? 6 : ((DT == 8 && T == 2) ? 6 : 10);
   extern __shared__ int cur[];           // [n_groups][CD_WPB] fill counts
+  constexpr bool STRIP = !(DT == 8 && T == 2);
+  __shared__ double centre_strip[STRIP ? CD_WPB : 1][DP];   // cand_inside: `cw`
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lg = lane >> 4;
@@ -381,7 +401,8 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
           const bool has_ell = ((const NB_G long long*)blk)[0] > 0;
           const bool has_box = ((const NB_G long long*)blk)[1] != 0;
           bool ins[T];
-          cand_inside<DT, T, PD, SMALL>(blk, has_ell, has_box, X, lane, lgb, ins);
+          cand_inside<DT, T, PD, SMALL, STRIP>(blk, has_ell, has_box, X, lane, lgb,
+                                       centre_strip[STRIP ? wave : 0], ins);
 #pragma unroll
           for (int t = 0; t < T; ++t) k_cnt[t] += ins[t] ? 1 : 0;
         }
@@ -427,7 +448,8 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         if (!__any(any_want)) break;
         const nb_gd* nb_m = nblk0 + m * neural_stride;
         bool ins[T];
-        cand_inside<DT, T, PD, SMALL>(nb_m, true, false, X, lane, lgb, ins);
+        cand_inside<DT, T, PD, SMALL, STRIP>(nb_m, true, false, X, lane, lgb,
+                                       centre_strip[STRIP ? wave : 0], ins);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const bool test = want[t] && !decided[t];

@@ -625,7 +625,13 @@ class Sampler:
             return
         bound = self.bounds[nxt]
         if hasattr(bound, 'prefetch'):
-            bound.prefetch(self._shell_request(nxt, self.n_batch))
+            stats = self.__dict__.setdefault(
+                'prefetch_stats', dict(issued=0, enough=0, right=0, wrong=0))
+            if bound.prefetch(self._shell_request(nxt, self.n_batch)):
+                stats['issued'] += 1
+            else:
+                stats['enough'] += 1
+            self._predicted = nxt
 
     def _pair_with_candidates(self, x, shell_t, idx_t):
         """Pair fresh points of the newest shell with stored candidates of
@@ -816,6 +822,10 @@ class Sampler:
         t0 = time()
         log_l = None
         blobs = None
+        if self.__dict__.get('_predicted') is not None:
+            hit = self._predicted == shell % len(self.bounds)
+            self.prefetch_stats['right' if hit else 'wrong'] += 1
+            self._predicted = None
         if shell == -1 and len(self.shell_t) > 0:
             if self.comm is not None:
                 pts, n_bound, idx_t = self._sharded_transfer_batch()

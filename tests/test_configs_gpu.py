@@ -171,15 +171,19 @@ def test_C4_mixture_explored_and_evidence():
     assert done and s.explored
     assert max(len(b.neural_bounds) for b in s.bounds[1:]) >= 3
     assert max(b.n_ell for b in s.bounds[1:]) >= 2
-    # N_eff = 2000: sigma(log Z) ~ 1 / sqrt(N_eff) = 0.022
-    assert abs(s.log_z - c['analytic_log_z']) < (0.05 if FULL else 0.08)
+    # The target is nominal: with batches of 16384 the first batch of every
+    # shell (sampler.py:482-486) already brings N_eff to ~70 000 (committed
+    # run: 71 081, log Z +0.004), sigma(log Z) ~ 1 / sqrt(N_eff) = 0.004 and
+    # sigma of a mode's weight = sqrt(0.25 * 0.75 / N_eff) = 0.002.
+    assert s.n_eff > 20000
+    assert abs(s.log_z - c['analytic_log_z']) < 0.03
     # posterior mass splits evenly over the four modes
     pts, log_w, _ = s.posterior()
     w = np.exp(log_w)
     means = c['means']
     mode = np.argmin(((pts[:, None, :] - means[None]) ** 2).sum(-1), axis=1)
     share = np.array([w[mode == k].sum() for k in range(len(means))])
-    assert np.all(np.abs(share / share.sum() - 0.25) < 0.06)
+    assert np.all(np.abs(share / share.sum() - 0.25) < 0.025)
 
 
 def _mixture_reference(n_dim):
@@ -245,6 +249,80 @@ def test_C5_funnel_real_size():
     if FULL:
         assert done and s.n_eff >= 10000
         assert abs(s.log_z - c['analytic_log_z']) < 0.1
+
+
+def _prefix_reference():
+    path = os.path.join(GOLDEN, 'e2e_C5_prefix.json')
+    if not os.path.exists(path):
+        return []
+    with open(path) as f:
+        return json.load(f)['runs']
+
+
+def test_C5_prefix_against_the_reference():
+    """Configuration 5 at its REAL dimension, like for like with the
+    reference: the 100-D funnel at the reduced settings (n_live 2000, 4
+    networks, n_batch 100) stopped by ``run(n_like_max=N)``
+    (/root/reference/nautilus/sampler.py:373-374, 433) -- the reference's
+    state at that N is in tests/golden/e2e_C5_prefix.json
+    (make_golden_c5_prefix.py: one rung per 20 000 likelihood calls, two
+    seeds, as far as the CPU budget of the round carried them).  Held at the
+    last rung both reference runs reached: number of bounds, log volume of
+    the newest bound, likelihood calls per bound, rows of the newest
+    emulator's training set, shell occupation and the live-set volume.  (The
+    evidence so far is the sum of a few shells with f_live ~ 1: it moves by
+    nats from rung to rung in the reference as well and is only required to
+    be finite.)"""
+    import torch
+    from nautilus_amd.emulator import NeuralNetworkEmulator
+    ref = _prefix_reference()
+    assert len(ref) >= 2, 'tests/golden/e2e_C5_prefix.json: two runs needed'
+    n_rungs = min(len(r['rungs']) for r in ref)
+    assert n_rungs >= 3
+    rungs = [r['rungs'][n_rungs - 1] for r in ref]
+    n_max = rungs[0]['n_like_max']
+    assert all(r['n_like_max'] == n_max for r in rungs)
+    rows = []
+    inner = NeuralNetworkEmulator.train_many.__func__
+
+    def counting(cls, data, *a, **k):
+        rows.extend(int(x.shape[0]) for x, _ in data)
+        return inner(cls, data, *a, **k)
+    NeuralNetworkEmulator.train_many = classmethod(counting)
+    try:
+        from nautilus_amd import Sampler, unit_prior
+        from nautilus_amd.configs import baseline_config
+        c = baseline_config('C5')
+        s = Sampler(unit_prior, c['likelihood'], n_dim=100, n_live=2000,
+                    n_networks=4, n_batch=100, vectorized=True, seed=0)
+        done = s.run(n_like_max=n_max, discard_exploration=True)
+        torch.cuda.synchronize()
+    finally:
+        NeuralNetworkEmulator.train_many = classmethod(inner)
+    assert not done and not s.explored
+    _invariants(c, s)
+    # stopped where the reference stops: at the first batch boundary at or
+    # past N
+    assert s.n_like == rungs[0]['n_like'] == n_max
+    ref_bounds = np.mean([r['n_bounds'] for r in rungs])
+    assert abs(len(s.bounds) - ref_bounds) <= 0.1 * ref_bounds + 1
+    ref_log_v = np.mean([r['log_v'][-1] for r in rungs])
+    assert abs(s.bounds[-1].log_v - ref_log_v) < 1.0
+    # ... and bound by bound: the volumes shrink at the reference's rate
+    k = int(min(len(s.bounds), min(r['n_bounds'] for r in rungs)))
+    ours = np.array([b.log_v for b in s.bounds[:k]])
+    theirs = np.mean([r['log_v'][:k] for r in rungs], axis=0)
+    assert np.max(np.abs(ours - theirs)) < 1.0
+    ref_rows = np.mean([r['train_rows'][-1] for r in rungs])
+    assert abs(rows[-1] / ref_rows - 1) < 0.15
+    ref_built = np.mean([len(r['train_rows']) for r in rungs])
+    assert abs(len(rows) - ref_built) <= 0.1 * ref_built + 1
+    # shell occupation: every finished shell holds what the reference's does
+    ref_shell = np.mean([r['shell_n'][:k - 1] for r in rungs], axis=0)
+    assert np.all(np.abs(s.shell_n[:k - 1] / ref_shell - 1) < 0.25)
+    ref_live = np.mean([r['log_v_live'] for r in rungs])
+    assert abs(s.log_v_live - ref_live) < 1.0
+    assert np.isfinite(s.log_z)
 
 
 def _x0_moments(s):

