@@ -227,7 +227,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   // 0.875 / 2.19, 14: 0.900 / 2.25, 20: 0.93 / 2.85; three tiles per
   // wavefront at n_dim 50: 0.927 -- the stage is not waiting for its
   // operands; profiles/r05/cand_prefetch_depth_and_three_tiles.txt)
-  constexpr int PD = OCC >= 4 ? 6 : ((DT == 8 && T == 2) ? 6 : 10);
+  constexpr int PD = OCC >= 4 ? 6 : (OCC == 3 && DT == 4 ? (SMALL ? 6 : 4) : ((DT == 8 && T == 2) ? 6 : 10));
   extern __shared__ int cur[];           // [n_groups][CD_WPB] fill counts
   constexpr bool STRIP = !(DT == 8 && T == 2);
   __shared__ double centre_strip[STRIP ? CD_WPB : 1][DP];   // cand_inside: `cw`
@@ -548,16 +548,20 @@ void launch_cand_m(const CandArgs& a, hipStream_t stream) {
 
 // T_S / T_L: tiles per wavefront for proposals / lists (cand_tiles); `small`:
 // the last row tile has at most four real rows (StepTable)
-template <int DT, int T_S, int T_L, int OCC>
+// OCC_S / OCC_L: wavefronts per SIMD (the register budget) for proposals /
+// lists -- cand_occ() below is the host's copy of the table
+template <int DT, int T_S, int T_L, int OCC_S, int OCC_L>
 int launch_cand_t(const CandArgs& a, bool small, hipStream_t stream) {
   if (DT > 1 && small) {
     if (a.mode == CM_SAMPLE)
-      launch_cand_m<DT, T_S, OCC, true, (DT > 1)>(a, stream);
+      launch_cand_m<DT, T_S, OCC_S, true, (DT > 1)>(a, stream);
     else
-      launch_cand_m<DT, T_L, OCC, false, (DT > 1)>(a, stream);
+      launch_cand_m<DT, T_L, OCC_L, false, (DT > 1)>(a, stream);
   } else {
-    if (a.mode == CM_SAMPLE) launch_cand_m<DT, T_S, OCC, true, false>(a, stream);
-    else launch_cand_m<DT, T_L, OCC, false, false>(a, stream);
+    if (a.mode == CM_SAMPLE)
+      launch_cand_m<DT, T_S, OCC_S, true, false>(a, stream);
+    else
+      launch_cand_m<DT, T_L, OCC_L, false, false>(a, stream);
   }
   return NB_OK;
 }
@@ -581,13 +585,24 @@ static int cand_tiles(int dt, int mode) {
 
 // Geometry of the candidate lists for n points: points per wavefront, number
 // of wavefronts, padded list length (all multiples the kernels rely on).
+// wavefronts per SIMD the kernel's registers allow (the OCC template argument
+// of the launch below): proposals at 49..64 dimensions run three per SIMD (165
+// registers with six k-steps of operands in flight; 2.41 -> 2.39 ms per 2^20
+// proposals at n_dim 50, K = M = 4), lists keep two (three would spill)
+static int cand_occ(int dt, int mode) {
+  if (dt == 1) return 4;
+  if (dt == 2) return 3;
+  return (dt == 4 && mode == CM_SAMPLE) ? 3 : 2;
+}
+
 void nb_cand_shape(int dt, int mode, long long n, int* chunk, int* n_waves,
                    long long* n_pad) {
   const int tile = 16 * cand_tiles(dt, mode);
   // wavefronts of the grid: what the chip holds at once at the kernel's
-  // register budget (two per SIMD from n_dim 33 on: 2048), twice that for the
-  // small kernels
-  const int max_waves = dt >= 3 ? CD_MAX_WAVES / 2 : CD_MAX_WAVES;
+  // register budget (two per SIMD from n_dim 33 on: 2048; three: 3072), all
+  // of CD_MAX_WAVES for the small kernels
+  const int occ = cand_occ(dt, mode);
+  const int max_waves = occ >= 3 && dt <= 2 ? CD_MAX_WAVES : 1024 * occ;
   const long long passes = (n + tile - 1) / tile;
   const long long per_wave = (passes + max_waves - 1) / max_waves;
   *chunk = (int)((per_wave < 1 ? 1 : per_wave) * tile);
@@ -643,14 +658,14 @@ int nb_launch_cand(int dt, int n_dim, const double* const* blobs_dev,
   const int live = n_dim - 16 * (dt - 1);        // real rows of the last tile
   const bool small = live >= 1 && live <= 4;
   switch (dt) {
-    case 1: rc = launch_cand_t<1, 2, 2, 4>(a, small, stream); break;
-    case 2: rc = launch_cand_t<2, 2, 2, 3>(a, small, stream); break;
-    case 3: rc = launch_cand_t<3, 2, 2, 2>(a, small, stream); break;
-    case 4: rc = launch_cand_t<4, 2, 2, 2>(a, small, stream); break;
-    case 5: rc = launch_cand_t<5, 2, 2, 2>(a, small, stream); break;
-    case 6: rc = launch_cand_t<6, 2, 1, 2>(a, small, stream); break;
-    case 7: rc = launch_cand_t<7, 2, 1, 2>(a, small, stream); break;
-    case 8: rc = launch_cand_t<8, 2, 1, 2>(a, small, stream); break;
+    case 1: rc = launch_cand_t<1, 2, 2, 4, 4>(a, small, stream); break;
+    case 2: rc = launch_cand_t<2, 2, 2, 3, 3>(a, small, stream); break;
+    case 3: rc = launch_cand_t<3, 2, 2, 2, 2>(a, small, stream); break;
+    case 4: rc = launch_cand_t<4, 2, 2, 3, 2>(a, small, stream); break;
+    case 5: rc = launch_cand_t<5, 2, 2, 2, 2>(a, small, stream); break;
+    case 6: rc = launch_cand_t<6, 2, 1, 2, 2>(a, small, stream); break;
+    case 7: rc = launch_cand_t<7, 2, 1, 2, 2>(a, small, stream); break;
+    case 8: rc = launch_cand_t<8, 2, 1, 2, 2>(a, small, stream); break;
     default:
       nb_set_error("n_dim > 128 is not supported by the device kernels");
       return NB_ERR_UNSUPPORTED;

@@ -224,6 +224,8 @@ class Sampler:
         state['_live'] = None
         state['comm'] = None
         state['_in_flight'] = []
+        state.pop('_pinned', None)
+        state.pop('_predicted', None)
         state['_pts_t'] = self._pts_t.cpu().numpy()
         return state
 
@@ -495,8 +497,13 @@ class Sampler:
         if n_max is None:
             n_max = len(self.bounds)
         x = device.as_device_points(points, self.n_dim)
-        lst = device.DeviceBoundList(
-            [b.device_bound() for b in self.bounds[:n_max][::-1]])
+        # (the list of a given length is built once: the pairing of
+        # sample_shell asks for the same one several times per batch)
+        key = ('association', n_max, len(self.bounds))
+        lst = self._later.get(key)
+        if lst is None:
+            lst = self._later[key] = device.DeviceBoundList(
+                [b.device_bound() for b in self.bounds[:n_max][::-1]])
         first = lst.first_containing(x).cpu().numpy().astype(int)
         shell = np.where(first >= 0, n_max - 1 - first, -1)
         return shell
@@ -638,9 +645,17 @@ class Sampler:
         the same earlier shell (sampler.py:803-819): the candidates move into
         the new shell, the paired fresh points are dropped.  Host RNG; in a
         sharded run every rank does this on the same gathered points."""
+        waiting = shell_t[shell_t >= 0]
+        if waiting.size == 0:
+            return x, idx_t              # every candidate has moved already
         shell_p = self.shell_association(x, n_max=len(self.bounds) - 1)
         swap = np.zeros(x.shape[0], dtype=bool)
-        for s in range(len(self.bounds) - 1):
+        # the reference walks ALL shells in ascending order and draws from its
+        # generator for those that have both candidates and fresh points; the
+        # same shells in the same order, found without n_bounds passes over
+        # the two arrays (a funnel run has hundreds of bounds and tens of
+        # thousands of these rounds)
+        for s in np.intersect1d(waiting, shell_p):
             cand = np.flatnonzero(shell_t == s)
             fresh = np.flatnonzero(shell_p == s)
             m = min(len(cand), len(fresh))
@@ -649,9 +664,28 @@ class Sampler:
                     cand, size=m, replace=False))
                 shell_t[idx_t] = -1
                 swap[self.rng.choice(fresh, size=m, replace=False)] = True
+        if not swap.any():
+            return x, idx_t
         return x[torch.from_numpy(~swap).cuda()], idx_t
 
-    def evaluate_likelihood(self, points, fetch=True):
+    def _fetch_async(self, t):
+        """Start the transfer of the 1-D float64 cuda tensor ``t`` into
+        pinned host memory; returns (host view, event).  What is launched
+        between this call and ``event.synchronize()`` runs BEHIND the transfer
+        in the stream -- ``t.cpu()`` issued after such launches would wait
+        for them."""
+        n = int(t.shape[0])
+        buf = self.__dict__.get('_pinned')
+        if buf is None or buf.shape[0] < n:
+            buf = self._pinned = torch.empty(
+                max(2 * n, 4096), dtype=torch.float64).pin_memory()
+        view = buf[:n]
+        view.copy_(t, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return view, event
+
+    def evaluate_likelihood(self, points, fetch=True, after_fetch=None):
         """sampler.py:832-908.  ``points`` is a cuda tensor (n, n_dim);
         returns (log_l numpy, log_l cuda tensor, blobs or None).  ``fetch =
         False``: a device likelihood's values stay on the device (None in
@@ -688,7 +722,16 @@ class Sampler:
             transform = self.prior.unit_to_dictionary
         else:
             transform = self.prior.unit_to_physical
-        host = points.cpu().numpy()
+        if after_fetch is None:
+            host = points.cpu().numpy()
+        else:
+            # the points start their way to the host, THEN the next batch's
+            # refill is queued (``after_fetch``): the GPU draws and filters
+            # proposals while the CPU evaluates this batch
+            view, event = self._fetch_async(points.reshape(-1))
+            after_fetch()
+            event.synchronize()
+            host = view.numpy().reshape(points.shape).copy()
         if not self.vectorized:
             args = list(map(transform, np.copy(host)))
         else:
@@ -856,13 +899,15 @@ class Sampler:
             else:
                 # (a device likelihood's values come to the host further
                 # down, in one transfer with the shell statistics)
-                if not self._device_likelihood and (
+                ahead = None
+                if not self._device_likelihood and self.comm is None and (
                         self.explored or len(self.shell_t) == 0):
                     # a host likelihood: the GPU refills the next batch's
                     # queue while the CPU evaluates this one
-                    self._prefetch_next(shell, pts.shape[0])
+                    ahead = partial(self._prefetch_next, shell, pts.shape[0])
                 log_l, log_l_dev, blobs = self.evaluate_likelihood(
-                    pts, fetch=self.comm is not None or not DEFER_FETCH)
+                    pts, fetch=self.comm is not None or not DEFER_FETCH,
+                    after_fetch=ahead)
         t2 = time()
         if isinstance(pts, _RowsInFlight):
             # sharded sampling phase: the rows are on their way to this rank
@@ -882,10 +927,15 @@ class Sampler:
             view = self._shell_slice(shell)[0]
             if view.shape[0] > 0:
                 both = torch.cat([device.shell_stats(view), log_l_dev])
-                if self.explored:
-                    # behind this batch's last launch, in front of the wait
+                if self.explored and PREFETCH and self.comm is None:
+                    # the numbers start their way to the host, the next
+                    # batch's refill is queued behind them, then the wait
+                    host, event = self._fetch_async(both)
                     self._prefetch_next(shell, log_l_dev.shape[0])
-                both = both.cpu().numpy()
+                    event.synchronize()
+                    both = host.numpy().copy()
+                else:
+                    both = both.cpu().numpy()
                 stats, log_l = both[:4], both[4:]
             else:
                 log_l = log_l_dev.cpu().numpy()

@@ -56,7 +56,19 @@ def funnel(u):
             0.5 * np.sum(zi * zi, axis=1) - (d - 1) * (log_s + 0.5 * LOG_2PI))
 
 
+def identity(u):
+    return u
+
+
+CKPT = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'gpurun_out',
+                    'refjobs')
+
+
 def run(seed, cpu_budget_s):
+    """Climb the ladder; the sampler and the ladder so far are pickled after
+    every rung, so that a job that is killed resumes at its last rung (the
+    committed part file is only ever replaced by a longer ladder)."""
+    import pickle
     import nautilus
     from nautilus.bounds import neural as ref_neural
 
@@ -67,15 +79,25 @@ def run(seed, cpu_budget_s):
         train_rows.append(int(len(x)))
         return inner(cls, x, y, **kwargs)
 
-    ref_neural.NeuralNetworkEmulator.train = classmethod(counting_train)
-
     path = os.path.join(PARTS, 'D%d_seed%d.json' % (N_DIM, seed))
     os.makedirs(PARTS, exist_ok=True)
-    s = nautilus.Sampler(lambda u: u, funnel, n_dim=N_DIM, vectorized=True,
-                         seed=seed, pool=None, **SETTINGS)
-    rungs = []
-    t0 = time.process_time()
-    n_max = 0
+    os.makedirs(CKPT, exist_ok=True)
+    ckpt = os.path.join(CKPT, 'c5_prefix_seed%d.pkl' % seed)
+    have = 0
+    if os.path.exists(path):
+        with open(path) as f:
+            have = len(json.load(f)['rungs'])
+    if os.path.exists(ckpt):
+        with open(ckpt, 'rb') as f:
+            s, rungs, rows_so_far, spent = pickle.load(f)
+        train_rows.extend(rows_so_far)
+    else:
+        s = nautilus.Sampler(identity, funnel, n_dim=N_DIM, vectorized=True,
+                             seed=seed, pool=None, **SETTINGS)
+        rungs, spent = [], 0.0
+    ref_neural.NeuralNetworkEmulator.train = classmethod(counting_train)
+    t0 = time.process_time() - spent
+    n_max = rungs[-1]['n_like_max'] if rungs else 0
     while time.process_time() - t0 < cpu_budget_s and not s.explored:
         n_max += STEP
         s.run(n_like_max=n_max, discard_exploration=True, verbose=False)
@@ -93,11 +115,18 @@ def run(seed, cpu_budget_s):
             n_outer_last=len(getattr(getattr(last, 'outer_bound', None),
                                      'bounds', [])),
             cpu_s=time.process_time() - t0))
-        out = dict(n_dim=N_DIM, seed=seed, step=STEP, rungs=rungs,
-                   **SETTINGS)
-        with open(path + '.tmp', 'w') as f:
-            json.dump(out, f)
-        os.replace(path + '.tmp', path)
+        ref_neural.NeuralNetworkEmulator.train = classmethod(inner)
+        with open(ckpt + '.tmp', 'wb') as f:
+            pickle.dump((s, rungs, list(train_rows),
+                         time.process_time() - t0), f, protocol=4)
+        os.replace(ckpt + '.tmp', ckpt)
+        ref_neural.NeuralNetworkEmulator.train = classmethod(counting_train)
+        if len(rungs) > have:
+            out = dict(n_dim=N_DIM, seed=seed, step=STEP, rungs=rungs,
+                       **SETTINGS)
+            with open(path + '.tmp', 'w') as f:
+                json.dump(out, f)
+            os.replace(path + '.tmp', path)
     return path
 
 

@@ -67,16 +67,43 @@ def tag(job):
     return '%s_D%d_seed%d%s' % (setting, d, seed, '' if discard else '_keep')
 
 
+def identity(u):
+    return u
+
+
+CKPT = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'gpurun_out',
+                    'refjobs')
+
+
 def run_job(job):
+    """One reference run.  The run advances in slices of 15 minutes
+    (``run(timeout=...)``: every piece of loop state lives on the sampler,
+    so the slices are the uninterrupted run) and the sampler is pickled
+    between them -- a job that is killed resumes from its last slice."""
+    import pickle
     import nautilus
     setting, d, seed, discard = job
     path = os.path.join(PARTS, tag(job) + '.json')
     if os.path.exists(path):
         return path
-    t0 = time.time()
-    s = nautilus.Sampler(lambda u: u, funnel, n_dim=d, vectorized=True,
-                         seed=seed, pool=None, **SETTINGS[setting])
-    s.run(discard_exploration=discard, verbose=False)
+    os.makedirs(CKPT, exist_ok=True)
+    ckpt = os.path.join(CKPT, 'funnel_' + tag(job) + '.pkl')
+    if os.path.exists(ckpt):
+        with open(ckpt, 'rb') as f:
+            s, spent = pickle.load(f)
+    else:
+        s = nautilus.Sampler(identity, funnel, n_dim=d, vectorized=True,
+                             seed=seed, pool=None, **SETTINGS[setting])
+        spent = 0.0
+    done = False
+    while not done:
+        t0 = time.time()
+        done = s.run(discard_exploration=discard, verbose=False,
+                     timeout=900.0)
+        spent += time.time() - t0
+        with open(ckpt + '.tmp', 'wb') as f:
+            pickle.dump((s, spent), f, protocol=4)
+        os.replace(ckpt + '.tmp', ckpt)
     pts, log_w, log_l = s.posterior()
     w = np.exp(log_w - np.max(log_w))
     w /= w.sum()
@@ -85,7 +112,7 @@ def run_job(job):
     out = dict(setting=setting, n_dim=d, seed=seed, discard_exploration=discard,
                log_z=float(s.log_z), n_eff=float(s.n_eff),
                n_like=int(s.n_like), n_bounds=len(s.bounds),
-               eta=float(s.eta), wall_s=time.time() - t0,
+               eta=float(s.eta), wall_s=spent,
                mean_x0=float(mean[0]), var_x0=float(var[0]),
                mean_x1=float(mean[1]), var_x1=float(var[1]),
                mean_log_l=float(log_l @ w), **SETTINGS[setting])

@@ -52,24 +52,57 @@ def tag(job):
     return 'D%d_seed%d' % job
 
 
+def identity(u):
+    return u
+
+
+class Mixture:
+    """The likelihood as a picklable object (the run is checkpointed)."""
+
+    def __init__(self, d):
+        self.means = means_of(d)
+        self.log_norm = (-d * np.log(SIGMA * np.sqrt(2 * np.pi)) -
+                         np.log(len(self.means)))
+
+    def __call__(self, u):
+        u = np.atleast_2d(u)
+        r2 = np.sum((u[:, None, :] - self.means[None])**2, axis=2)
+        return logsumexp(-0.5 * r2 / SIGMA**2, axis=1) + self.log_norm
+
+
+CKPT = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'gpurun_out',
+                    'refjobs')
+
+
 def run_job(job):
+    """One reference run, advanced in slices of 15 minutes
+    (``run(timeout=...)``: all loop state lives on the sampler, the slices
+    are the uninterrupted run) with the sampler pickled between them, so
+    that a job that is killed resumes from its last slice."""
+    import pickle
     import nautilus
     d, seed = job
     path = os.path.join(PARTS, tag(job) + '.json')
     if os.path.exists(path):
         return path
     means = means_of(d)
-    log_norm = -d * np.log(SIGMA * np.sqrt(2 * np.pi)) - np.log(len(means))
-
-    def mixture(u):
-        u = np.atleast_2d(u)
-        r2 = np.sum((u[:, None, :] - means[None])**2, axis=2)
-        return logsumexp(-0.5 * r2 / SIGMA**2, axis=1) + log_norm
-
-    t0 = time.time()
-    s = nautilus.Sampler(lambda u: u, mixture, n_dim=d, vectorized=True,
-                         seed=seed, pool=None, **SETTINGS)
-    s.run(discard_exploration=True, verbose=False)
+    os.makedirs(CKPT, exist_ok=True)
+    ckpt = os.path.join(CKPT, 'mixture_' + tag(job) + '.pkl')
+    if os.path.exists(ckpt):
+        with open(ckpt, 'rb') as f:
+            s, spent = pickle.load(f)
+    else:
+        s = nautilus.Sampler(identity, Mixture(d), n_dim=d, vectorized=True,
+                             seed=seed, pool=None, **SETTINGS)
+        spent = 0.0
+    done = False
+    while not done:
+        t0 = time.time()
+        done = s.run(discard_exploration=True, verbose=False, timeout=900.0)
+        spent += time.time() - t0
+        with open(ckpt + '.tmp', 'wb') as f:
+            pickle.dump((s, spent), f, protocol=4)
+        os.replace(ckpt + '.tmp', ckpt)
     pts, log_w, log_l = s.posterior()
     w = np.exp(log_w - np.max(log_w))
     w /= w.sum()
@@ -83,7 +116,7 @@ def run_job(job):
                n_neural_last=len(getattr(last, 'neural_bounds', [])),
                n_neural_max=max(len(getattr(b, 'neural_bounds', []))
                                 for b in s.bounds),
-               mode_share=share, wall_s=time.time() - t0, **SETTINGS)
+               mode_share=share, wall_s=spent, **SETTINGS)
     os.makedirs(PARTS, exist_ok=True)
     with open(path + '.tmp', 'w') as f:
         json.dump(out, f, indent=1)
