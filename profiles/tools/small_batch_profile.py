@@ -19,13 +19,14 @@ from nautilus_amd import Sampler, unit_prior             # noqa: E402
 from nautilus_amd.configs import baseline_config         # noqa: E402
 
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+limit = float(sys.argv[2]) if len(sys.argv) > 2 else float('inf')
 c = baseline_config('C5-D%d' % d)
 s = Sampler(unit_prior, c['likelihood'], n_dim=d, n_live=2000, n_networks=4,
             n_batch=100, vectorized=True, seed=0)
 t0 = time.time()
 pr = cProfile.Profile()
 pr.enable()
-s.run(n_eff=0, n_shell=0, discard_exploration=True)
+s.run(n_eff=0, n_shell=0, discard_exploration=True, timeout=limit)
 torch.cuda.synchronize()
 pr.disable()
 t1 = time.time()
@@ -41,7 +42,7 @@ n0 = s.n_like
 tim0 = dict(s.timing)
 pr = cProfile.Profile()
 pr.enable()
-s.run(n_eff=10000, discard_exploration=True)
+s.run(n_eff=10000, discard_exploration=True, timeout=limit)
 torch.cuda.synchronize()
 pr.disable()
 t2 = time.time()

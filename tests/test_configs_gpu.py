@@ -194,7 +194,7 @@ def _mixture_reference(n_dim):
         return [r for r in json.load(f)['runs'] if r['n_dim'] == n_dim]
 
 
-@pytest.mark.parametrize('n_dim', [10, 20])
+@pytest.mark.parametrize('n_dim', [10, 20, 30])
 def test_mixture_against_reference_runs(n_dim):
     """Configuration 4's problem (four-mode mixture: a Union with several
     members, several neural bounds per NautilusBound) at the dimensions the
@@ -234,16 +234,18 @@ def test_mixture_against_reference_runs(n_dim):
 
 def test_C5_funnel_real_size():
     """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
-    the device MVEE / mixture fit at 100 dimensions -- 60 s of the run and
+    the device MVEE / mixture fit at 100 dimensions -- 35 s of the run and
     the invariants of a run in progress.  The run itself does not end inside
     any budget this project has (docs/history/round4.md: the exploration front
     has to walk down the funnel to x_0 ~ 0.27, ~830 bounds at the measured
     8.3 bounds per dimension, with training sets beyond 10^6 rows from bound
     50 on; a GPU lease lasts one hour and a checkpoint of ~10 GB cannot
     travel between leases).  What CAN be verified end to end is verified in
-    ``test_C5_family_finishes``: the same problem at the dimensions whose
-    runs finish."""
-    c, s, done = _run('C5', timeout=np.inf if FULL else 60.0)
+    ``test_C5_family_finishes`` and ``test_funnel_*_against_reference_runs``:
+    the same problem at the dimensions whose runs finish, and like for like
+    with the reference at this dimension in
+    ``test_C5_prefix_against_the_reference``."""
+    c, s, done = _run('C5', timeout=np.inf if FULL else 35.0)
     _invariants(c, s)
     assert len(s.bounds) >= 2
     if FULL:
@@ -407,8 +409,50 @@ def test_funnel_exploration_kept_shares_the_reference_bias():
     assert abs(s.n_like / np.mean([r['n_like'] for r in ref]) - 1) < 0.06
 
 
-@pytest.mark.parametrize('name,discard', [('C5-D10', False), ('C5-D30', True)]
-                         + ([('C5-D20', False)] if FULL else []))
+def test_funnel_D50_against_reference_runs():
+    """Configuration 5's problem at FIFTY dimensions -- the dimension of the
+    headline metric -- against the reference's own runs at the settings the
+    reference finishes (tests/golden/e2e_funnel.json, ``reduced``: n_live
+    2000, 4 networks, n_batch 100, n_eff 10000, exploration discarded; 4-5
+    hours per run on a CPU core, ~2 minutes here).  At this dimension BOTH
+    samplers miss the quadrature evidence by more than the north star's
+    0.01 and put E[x_0] ~0.015 above the quadrature value: the bounds lose
+    mass at the narrow end of the funnel.  What is
+    held: this build's evidence, likelihood calls, number of bounds and the
+    posterior of x_0 against the REFERENCE'S, and the reference's own
+    assertion |log Z - log Z_true| < 0.1 (tests/test_sampler.py:326) with
+    the margin the reference's runs themselves need."""
+    from nautilus_amd.configs import funnel_log_z
+    ref = _funnel_reference(50, True)
+    assert len(ref) >= 2, 'two reference runs at n_dim 50 needed'
+    ref_z = np.array([r['log_z'] for r in ref])
+    ref_like = np.mean([r['n_like'] for r in ref])
+    ref_bounds = np.mean([r['n_bounds'] for r in ref])
+    ref_mean = np.mean([r['mean_x0'] for r in ref])
+    ref_var = np.mean([r['var_x0'] for r in ref])
+    c, s, done = _run('C5-D50', seed=0, n_batch=100, n_live=2000,
+                      n_networks=4)
+    assert done and s.n_eff >= 10000
+    _invariants(c, s)
+    # sigma(log Z) of ONE run at this dimension: 0.017 over this build's
+    # seeds (profiles/r06/anchors_here.jsonl), the reference's two runs
+    # differ by as much
+    sigma = 0.017
+    assert abs(s.log_z - ref_z.mean()) < 4 * sigma * np.sqrt(1 + 1 / len(ref))
+    worst_ref = np.max(np.abs(ref_z - funnel_log_z(50)))
+    assert abs(s.log_z - funnel_log_z(50)) < max(0.1, worst_ref + 2 * sigma)
+    assert abs(s.n_like / ref_like - 1) < 0.08
+    assert abs(len(s.bounds) - ref_bounds) <= 0.05 * ref_bounds + 4
+    mean, var = _x0_moments(s)
+    se = np.sqrt(ref_var / 10000)
+    assert abs(mean[0] - ref_mean) < 5 * se * np.sqrt(1 + 1 / len(ref))
+    assert abs(var / ref_var - 1) < 0.15
+    assert np.all(np.abs(mean[1:] - 0.5) < 0.01)
+
+
+@pytest.mark.parametrize('name,discard', [('C5-D10', False)]
+                         + ([('C5-D30', True), ('C5-D20', False)]
+                            if FULL else []))
 def test_C5_family_finishes(name, discard):
     """Configuration 5's own settings (n_live 10000, 8 networks) at the
     dimensions where a run ends.  10 (and 20) dimensions with the
