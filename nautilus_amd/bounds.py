@@ -416,9 +416,12 @@ class _PrefetchSlots:
     owners = []                # (bound, slot), oldest first
 
     @classmethod
-    def acquire(cls, bound):
+    def acquire(cls, bound, keep=0):
+        """A free slot for ``bound`` (which holds ``keep`` slots of the
+        refill it is issuing); with none free the oldest other refill in
+        flight lands first."""
         if not cls.free:
-            oldest = cls.owners[0][0]
+            oldest = next(b for b, _ in cls.owners if b is not bound)
             oldest._land_pending()
         slot = cls.free.pop()
         cls.owners.append((bound, slot))
@@ -456,10 +459,10 @@ class _RejectionSampler(_DeviceBoundBase):
         """Counters and rows of the launch ``prefetch`` issued: its counts
         come to the host now (no wait if the launch has finished meanwhile),
         the rows move into the queue, the slot is free again."""
-        rows, counts, n_draw, slot = self._pending
-        self._pending = None
-        _PrefetchSlots.release(slot)
-        self._collect(rows, counts.cpu().numpy(), n_draw)
+        pending, self._pending = self._pending, None
+        for rows, counts, n_draw, slot in pending:
+            _PrefetchSlots.release(slot)
+            self._collect(rows, counts.cpu().numpy(), n_draw)
 
     def prefetch(self, n_points):
         """Launch the refill that ``sample_device(n_points)`` would need --
@@ -478,19 +481,28 @@ class _RejectionSampler(_DeviceBoundBase):
         need = n_points - len(self._queue(land=False))
         if need <= 0:
             return False
-        n_draw = self._launch(need)
-        seed, off = self._stream.take(n_draw)
-        slot = _PrefetchSlots.acquire(self)
-        rows, counts = self.device_bound().sample_launch(
-            seed, off, n_draw, reuse=True, out_role='prefetch%d' % slot)
-        self._pending = (rows, counts, n_draw, slot)
+        # A launch is limited to MAX_DRAW proposals; where that is expected to
+        # fall short of ``need`` a second launch follows at once (the refill
+        # loop would issue it after a wait for the first one's count).
+        pending = []
+        acc = max(self._acceptance(), 1e-7)
+        while need > 0 and len(pending) < 2:
+            n_draw = self._launch(need)
+            seed, off = self._stream.take(n_draw)
+            slot = _PrefetchSlots.acquire(self, keep=len(pending))
+            rows, counts = self.device_bound().sample_launch(
+                seed, off, n_draw, reuse=True, out_role='prefetch%d' % slot)
+            pending.append((rows, counts, n_draw, slot))
+            need -= int(n_draw * acc / 1.05)
+            self._pending = pending
         return True
 
     def drop_pending(self):
         """Forget a prefetched launch (its proposals were drawn and are simply
         not looked at: i.i.d. draws, independent of everything kept)."""
         if self.__dict__.get('_pending') is not None:
-            _PrefetchSlots.release(self._pending[3])
+            for entry in self._pending:
+                _PrefetchSlots.release(entry[3])
             self._pending = None
 
     def __getstate__(self):

@@ -66,6 +66,11 @@ struct CandArgs {
   int chunk, n_waves;
   unsigned long long seed, offset;
   unsigned long long* counters; // optional, as in nb_eval.hip
+  // long lists over few rows: blockIdx.y owns the bounds [y * b_chunk,
+  // (y + 1) * b_chunk) of the slice (0: one block row walks them all).  The
+  // blocks of a row range then share its status bytes / first-bound words:
+  // the launcher has initialised them, the kernel only ever ORs / MINs
+  int b_chunk;
 };
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
@@ -244,6 +249,11 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   const NB_G int* group_base = (const NB_G int*)a.group_base;
   const int n_dim = (int)nb_hdr((const double*)blobs[0], NB_H_NDIM);
   const long long w = (long long)blockIdx.x * CD_WPB + wave;
+  // the bounds of this block row (see CandArgs::b_chunk)
+  const bool chunked = !m_sample && a.b_chunk > 0;
+  const int b_lo = chunked ? (int)blockIdx.y * a.b_chunk : 0;
+  const int b_hi = chunked && b_lo + a.b_chunk < a.nb ? b_lo + a.b_chunk
+                                                      : a.nb;
   const long long p_begin = w * a.chunk;
   const long long p_end = p_begin + a.chunk < a.n ? p_begin + a.chunk : a.n;
   unsigned long long cnt_outer = 0, cnt_ell = 0;
@@ -266,7 +276,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
   for (long long p0 = p_begin; p0 < p_end; p0 += 16 * T) {
     long long row[T];
     bool valid[T], active[T];
-    unsigned char st[T];
+    unsigned char st[T], st_in[T];
     int first[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -274,9 +284,10 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
       valid[t] = row[t] < p_end;
       active[t] = valid[t];
       st[t] = 0;
+      st_in[t] = 0;
       first[t] = INT_MAX;
       if (a.accumulate && valid[t]) {
-        st[t] = a.st[row[t]];
+        st[t] = st_in[t] = a.st[row[t]];
         if (a.mode == CM_FIRST) first[t] = a.first[row[t]];
         active[t] = !(st[t] & CS_INSIDE);
       }
@@ -285,7 +296,7 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
     load_points<DT, T>(a.x, row, valid, n_dim, a.n, lane, xin);
 
     bool reload = false;
-    for (int b = 0; b < a.nb; ++b) {
+    for (int b = b_lo; b < b_hi; ++b) {
       // lane group, opaque per bound: what is indexed by 4 ks + lg below
       // (offsets of the centre / limit / shift slots, padding predicates of
       // the cube clip) would otherwise be hoisted out of both loops and held
@@ -468,16 +479,39 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         }
       if (m_sample) break;                 // a single bound
     }
+    if (chunked) {
+      // other block rows work on the same rows: set bits / lower the first
+      // bound, never overwrite (the byte's 32-bit word takes the OR)
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (valid[t] && lg == 0) {
-        a.st[row[t]] = st[t];
-        if (a.mode == CM_FIRST) a.first[row[t]] = first[t];
-      }
+      for (int t = 0; t < T; ++t)
+        if (valid[t] && lg == 0) {
+          const unsigned char fresh = st[t] & (unsigned char)~st_in[t];
+          if (fresh != 0) {
+            // (the slab of rows may start at any byte of its allocation)
+            const unsigned long long at =
+                (unsigned long long)(a.st + row[t]);
+            atomicOr((unsigned*)(at & ~3ull),
+                     (unsigned)fresh << (8 * (int)(at & 3ull)));
+          }
+          if (a.mode == CM_FIRST && first[t] != INT_MAX)
+            atomicMin(a.first + row[t], first[t]);
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (valid[t] && lg == 0) {
+          a.st[row[t]] = st[t];
+          if (a.mode == CM_FIRST) a.first[row[t]] = first[t];
+        }
+    }
   }
   __syncthreads();
+  // fill counts of the groups this block row owns (all of them unless the
+  // bounds are dealt out over block rows)
+  const int g_lo = chunked ? group_base[b_lo] - a.g_off : 0;
+  const int g_hi = chunked ? group_base[b_hi] - a.g_off : a.n_groups;
   if (w < a.n_waves)
-    for (int g = lane; g < a.n_groups; g += 64)
+    for (int g = g_lo + lane; g < g_hi; g += 64)
       a.counts[(long long)g * a.n_waves + w] = cur[g * CD_WPB + wave];
   if (a.counters != nullptr && lane == 0) {
     atomicAdd(&a.counters[0], cnt_outer);
@@ -542,8 +576,11 @@ template <int DT, int T, int OCC, bool SAMPLE, bool SMALL>
 void launch_cand_m(const CandArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)a.n_groups * CD_WPB * sizeof(int);
   const int blocks = (a.n_waves + CD_WPB - 1) / CD_WPB;
+  const int rows_y =
+      !SAMPLE && a.b_chunk > 0 ? (a.nb + a.b_chunk - 1) / a.b_chunk : 1;
   hipLaunchKernelGGL((nb_cand_kernel<DT, T, OCC, SAMPLE, SMALL>),
-                     dim3((unsigned)blocks), dim3(64 * CD_WPB), lds, stream, a);
+                     dim3((unsigned)blocks, (unsigned)rows_y),
+                     dim3(64 * CD_WPB), lds, stream, a);
 }
 
 // T_S / T_L: tiles per wavefront for proposals / lists (cand_tiles); `small`:
@@ -649,6 +686,32 @@ int nb_launch_cand(int dt, int n_dim, const double* const* blobs_dev,
   a.st = st; a.first = first; a.seed = seed; a.offset = offset;
   a.counters = nb_eval_counters();
   nb_cand_shape(dt, mode, n, &a.chunk, &a.n_waves, &a.n_pad);
+  // A long list over few rows (the shell association and exclusion of a run
+  // at the reference's batch size of 100: hundreds of nested bounds, a few
+  // hundred rows) is a handful of wavefronts each walking the whole list --
+  // ~1.5 us of dependent loads and a full ellipsoid test per bound, 0.5 ms
+  // per call, 48 % of the kernel time of a 50-dimensional funnel run
+  // (profiles/r06/funnel50_kernel_stats_before.csv).  The bounds are dealt
+  // out over block rows until the grid fills the chip: every block row takes
+  // b_chunk bounds for all rows, results meet in the status bytes (OR) and
+  // first-bound words (MIN) -- order independent, so the answer is the
+  // sequential walk's.
+  a.b_chunk = 0;
+  if (mode != CM_SAMPLE && nb >= 8 && a.n_waves <= 512) {
+    int rows_y = 2048 / a.n_waves;
+    if (rows_y > nb / 2) rows_y = nb / 2;
+    if (rows_y > 1) {
+      a.b_chunk = (nb + rows_y - 1) / rows_y;
+      if (!accumulate) {
+        // (the kernel ORs / MINs into what it finds)
+        NB_HIP_CHECK(hipMemsetAsync(st, 0, (size_t)n, stream));
+        if (first != nullptr)
+          NB_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7fffffff,
+                                         (size_t)n, stream));
+        a.accumulate = 1;
+      }
+    }
+  }
   const long long gp = (long long)n_groups * a.n_pad;
   a.seg = work;
   int* dense = work + gp;

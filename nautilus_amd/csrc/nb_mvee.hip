@@ -541,31 +541,11 @@ nb_mvee_sweep_kernel(MvBatch batch, int d, int n_batch, int call, int n_calls,
   __syncthreads();
   MV_STAMP(10);
 
-  // ---- B2 + B3 in one level where every point has a thread of its own -------
-  // (the usual case: 128 points per workgroup up to n = 4096): thread i ranks
-  // g_i among all values of the workgroup -- the same total order (g, index)
-  // as the two levels below, so the candidates are the same, bit for bit, for
-  // ~0.5 k cycles instead of ~8 k (two barriers, two rounds of lock-step
-  // bisections; stamps of profiles/r06/mvee_phases_start.txt)
-  if (cnt <= MV_THREADS) {
-    double* og = pb.cand_g + ((size_t)cur * W + wg) * NSC;
-    int* oi = pb.cand_i + ((size_t)cur * W + wg) * (NSC + 1);
-    if (tid < cnt) {
-      const double xg = gwg[tid];
-      int rank = 0;
-      for (int j = 0; j < cnt; j += 4) {
-        const nb_d4 v = *(const nb_d4*)(gwg + j);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          rank += (j + q < cnt && mv_before(v[q], j + q, xg, tid)) ? 1 : 0;
-      }
-      if (rank < K) { og[rank] = xg; oi[rank] = base + tid; }
-    }
-    if (tid == 0) oi[NSC] = cnt < K ? cnt : K;
-    MV_STAMP(11);
-    MV_STAMP(12);
-    return;
-  }
+  // (One level for workgroups whose points have a thread each -- thread i
+  // ranking g_i among all of the workgroup's values -- was measured: 3.26
+  // against 3.18-3.26 ms per fit at n = 2000, n_dim 50; the loop over the
+  // values waits for LDS as long as the two levels do.  profiles/r06/
+  // mvee_phases_start.txt has the stamps of the two-level form.)
   // ---- B2: first level, wave w ranks its slice of the g values --------------
   {
     const int slice = ((cnt + MV_WAVES - 1) / MV_WAVES + 3) & ~3;

@@ -513,6 +513,100 @@ def test_list_eval_against_the_oracle(dev):
             del os.environ['NB_LIST_SLICE_GROUPS']
 
 
+@pytest.mark.parametrize('d,n_bounds', [(20, 70), (50, 9)])
+def test_long_list_over_few_and_many_rows(dev, d, n_bounds):
+    """A long list over FEW rows (the shell association / exclusion of a run
+    at the reference's batch size: hundreds of bounds, a few hundred rows)
+    deals its bounds out over block rows of the candidate kernel, whose
+    results meet in the status bytes (OR) and first-bound words (MIN); over
+    many rows one block row walks the list.  Both against the oracle's
+    ``contains`` of every bound (sampler.py:797-798, 1213-1219), on bounds
+    scattered over the cube (most (row, bound) pairs end at the bounding
+    sphere), every fifth with periodic dimensions recentred, two without
+    neural bounds (decided in the first stage: the first-bound MIN must beat
+    later bounds' emulators); odd slab offsets (the byte-wise OR) and the
+    group-slice path too."""
+    from nautilus_amd import device
+    from oracle import bounds_oracle as bo
+    from oracle import mlp_oracle as mo
+    rng = np.random.default_rng(17 * d + n_bounds)
+    obs, probes = [], []
+    for j in range(n_bounds):
+        centre = rng.uniform(0.15, 0.85, size=d)
+        b_mat = np.tril(rng.normal(size=(d, d)) * 0.004) + np.eye(d) * 0.09
+        shift = None
+        if j % 5 == 2:
+            shift = bo.OPhaseShift.from_params(
+                np.array([0, d - 1]), rng.uniform(0.0, 1.0, size=2))
+        ell = bo.OEllipsoid.from_params(centre, b_mat)
+        outer = bo.OUnion.from_members(
+            [bo.OEllipsoid.from_params(centre, 1.05 * b_mat)], unit=True)
+        neural = []
+        if j not in (3, n_bounds - 2):
+            nb = bo.ONeural()
+            nb.outer_bound, nb.n_dim = ell, d
+            nb.emulator = mo.Emulator.from_weights(
+                rng.normal(size=d) * 0.1, rng.uniform(0.5, 1.5, d),
+                [mo.glorot_init(d, 2 * j + i)[:2] for i in range(2)])
+            probe = centre + (rng.normal(size=(500, d)) @ b_mat.T) * (
+                0.7 / np.sqrt(d))
+            nb.score_predict_min = float(np.quantile(
+                nb.emulator.predict(ell.transform(probe)), 0.3))
+            neural.append(nb)
+        ob = bo.ONautilus.from_parts(outer, neural, shift=shift)
+        obs.append(ob)
+        # points around the bound, in the frame the sampler sees
+        pts = centre + (rng.normal(size=(600, d)) @ b_mat.T) * (
+            0.8 / np.sqrt(d))
+        if shift is not None:
+            pts = shift.transform(pts % 1.0, inverse=True)
+        probes.append(pts)
+    x = np.vstack(probes + [rng.random((3000, d))])
+    x = x[rng.permutation(len(x))]
+    xd = torch.as_tensor(x, device='cuda')
+    inside = np.array([ob.contains(x) for ob in obs])
+    edge = np.zeros(len(x), dtype=bool)
+    for ob in obs:
+        xs = x if ob.shift is None else ob.shift.transform(x)
+        for n_b in ob.neural_bounds:
+            y = n_b.outer_bound.transform(xs)
+            edge |= near_boundary(np.sum(y**2, axis=1), 1.0, 1e-12)
+            edge |= near_boundary(n_b.emulator.predict(y),
+                                  n_b.score_predict_min, 1e-9)
+        for m in ob.outer_bound.bounds:
+            edge |= near_boundary(np.sum(m.transform(xs)**2, axis=1), 1.0,
+                                  1e-12)
+    assert edge.mean() < 1e-3
+    assert 0.1 < inside.any(axis=0).mean() < 0.9
+    assert inside.sum(axis=0).max() <= 3          # scattered, not nested
+    lst = device.DeviceBoundList([upload(ob) for ob in obs])
+    want_any = inside.any(axis=0)
+    want_first = np.where(want_any, np.argmax(inside, axis=0), -1)
+
+    def check():
+        # all rows (one block row per row range), 701 rows from an odd offset
+        # (block rows over the bounds), 33 rows
+        for lo, hi in ((0, len(x)), (1203, 1904), (5, 38)):
+            part = xd[lo:hi].contiguous()
+            keep = ~edge[lo:hi]
+            got_any = lst.contains_any(part).cpu().numpy()
+            got_first = lst.first_containing(part).cpu().numpy()
+            assert np.array_equal(got_any[keep], want_any[lo:hi][keep])
+            assert np.array_equal(got_first[keep], want_first[lo:hi][keep])
+    check()
+    old = device.WORK_BYTES
+    device.WORK_BYTES = 1 << 18
+    try:
+        check()
+    finally:
+        device.WORK_BYTES = old
+    os.environ['NB_LIST_SLICE_GROUPS'] = '5'
+    try:
+        check()
+    finally:
+        del os.environ['NB_LIST_SLICE_GROUPS']
+
+
 def test_list_eval_matches_the_one_kernel_form(dev):
     """nb_list_eval (candidate lists + one batched emulator launch; exclusion
     = any bound, association = first bound) against the one-kernel form that
