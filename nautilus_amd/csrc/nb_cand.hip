@@ -290,6 +290,13 @@ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) nb_cand_kernel(CandArgs a) {
         st[t] = st_in[t] = a.st[row[t]];
         if (a.mode == CM_FIRST) first[t] = a.first[row[t]];
         active[t] = !(st[t] & CS_INSIDE);
+        // Block rows over the bounds run side by side: "inside" may have
+        // been set a moment ago by the block row of LATER bounds, and the
+        // association wants the FIRST bound of the list -- only a bound in
+        // front of this block row's (earlier slices included) settles a row.
+        // (Exclusion asks for any bound: whoever was first is enough.)
+        if (chunked && a.mode == CM_FIRST)
+          active[t] = !(first[t] < a.b_off + b_lo);
       }
     }
     double xin[T][4 * DT];

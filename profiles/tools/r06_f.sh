@@ -1,6 +1,6 @@
 # round 6, sixth call: long lists through the sphere mask
 O=gpurun_out/r06f; mkdir -p $O
-python -m pytest tests/test_hip_parity.py -x -q -k "long_list or two_stage or list_eval or accept_routes or nested or periodic or exclusion or shell" > $O/tests_parity.txt 2>&1; tail -3 $O/tests_parity.txt
+python -m pytest tests/test_hip_parity.py -x -q -k "long_list or two_stage or sampler or gaussian or list_eval or accept_routes or nested or periodic or exclusion or shell" > $O/tests_parity.txt 2>&1; tail -3 $O/tests_parity.txt
 python -m pytest tests/test_sampler_gpu.py tests/test_sampler_behaviour_gpu.py tests/test_fuzz_gpu.py -x -q > $O/tests_sampler.txt 2>&1; tail -2 $O/tests_sampler.txt
 rm -f gpurun_out/r06_anchors.jsonl
 python profiles/tools/r06_anchor_runs.py funnel 20 0 2>&1 | tail -1 | cut -c1-300
