@@ -1204,10 +1204,10 @@ __global__ void nb_train_epoch_kernel(TrainArgs a, long long t_adam) {
 // get into each other's way: 3 us per step), 6 for up to four (half a
 // microsecond less barrier latency per step)
 #ifndef NB_POLL_SLEEP
-#define NB_POLL_SLEEP 16
+#define NB_POLL_SLEEP 2
 #endif
 #ifndef NB_POLL_SLEEP_FEW
-#define NB_POLL_SLEEP_FEW 6
+#define NB_POLL_SLEEP_FEW 1
 #endif
 constexpr int XCD_COUNT = 8;
 constexpr int XCD_SLOTS = 32;            // workgroups per network: one per CU
