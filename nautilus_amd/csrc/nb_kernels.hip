@@ -282,31 +282,44 @@ nb_scatter_kernel(const double* __restrict__ x,
                   unsigned char flip, long long n, int n_dim,
                   const long long* __restrict__ chunk_counts,
                   double* __restrict__ out, long long* __restrict__ src_idx) {
+  // Per round of 256 flags: the survivors' rows (chunk-relative) are listed
+  // in LDS in order, then ALL threads copy the elements of those rows --
+  // thread t the elements t, t + 256, ... of the contiguous destination
+  // block, every load independent of the others.  (One row at a time per
+  // wavefront -- a dependent load / store pair per survivor -- took 171 us
+  // for the 65 536 survivors of a shell-exclusion batch at n_dim 50: 150 GB/s.)
   __shared__ int wcount[4];
+  __shared__ int srcs[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)blockIdx.x * CHUNK;
   long long dst = chunk_counts[2 * blockIdx.x + 1];
+  const int r0 = (int)threadIdx.x / n_dim, c0 = (int)threadIdx.x - r0 * n_dim;
+  const int dr = 256 / n_dim, dc = 256 - dr * n_dim;
   for (int k = 0; k < CHUNK / 256; ++k) {
     const long long i = base + k * 256 + threadIdx.x;
     const bool keep = (i < n) && (((flags[i] ^ flip) & mask) != 0);
     const unsigned long long b = __ballot(keep);
     if (lane == 0) wcount[wave] = __popcll(b);
     __syncthreads();
-    long long wdst = dst;
-    for (int w = 0; w < wave; ++w) wdst += wcount[w];
-    const long long total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    // copy the wave's survivors row by row, all lanes cooperating
-    unsigned long long rem = b;
-    long long o = wdst;
-    const long long wbase = base + k * 256 + wave * 64;
-    while (rem) {
-      const int src_lane = __ffsll((long long)rem) - 1;
-      rem &= rem - 1;
-      const double* srow = x + (wbase + src_lane) * n_dim;
-      double* drow = out + o * n_dim;
-      for (int cidx = lane; cidx < n_dim; cidx += 64) drow[cidx] = srow[cidx];
-      if (src_idx != nullptr && lane == 0) src_idx[o] = wbase + src_lane;
-      ++o;
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wcount[w];
+    const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (keep) {
+      const int at = woff + __popcll(b & ((1ull << lane) - 1ull));
+      srcs[at] = k * 256 + (int)threadIdx.x;
+      if (src_idx != nullptr) src_idx[dst + at] = i;
+    }
+    __syncthreads();
+    const double* src = x + base * n_dim;
+    double* drow = out + dst * n_dim;
+    int r = r0, c = c0;
+    const int n_el = total * n_dim;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < n_el; e += 256) {
+      drow[e] = src[(long long)srcs[r] * n_dim + c];
+      r += dr;
+      c += dc;
+      if (c >= n_dim) { c -= n_dim; ++r; }
     }
     __syncthreads();
     dst += total;

@@ -620,25 +620,35 @@ class Sampler:
             return None
         return int(np.nanargmax(gain))
 
-    def _prefetch_next(self, shell, n_new):
+    def _prefetch_plan(self, shell, n_new):
+        """(bound, points to ask it for) of the refill ``_prefetch_next`` will
+        queue, or None -- the host arithmetic of the guess, done while the GPU
+        still works on the batch."""
+        if not PREFETCH or self.comm is not None:
+            return None
+        nxt = self._predict_next_shell(shell, n_new)
+        if nxt is None or not hasattr(self.bounds[nxt], 'prefetch'):
+            return None
+        return nxt, self._shell_request(nxt, self.n_batch)
+
+    def _prefetch_next(self, shell, n_new, plan=False):
         """Queue the refill of the bound the next batch will most likely ask
         (``_RejectionSampler.prefetch``) behind the launches of the current
         batch, so that the GPU draws and filters proposals while the host
-        waits for this batch's numbers and does its bookkeeping."""
-        if not PREFETCH or self.comm is not None:
+        waits for this batch's numbers and does its bookkeeping.  ``plan``:
+        what ``_prefetch_plan`` returned earlier for the same batch."""
+        if plan is False:
+            plan = self._prefetch_plan(shell, n_new)
+        if plan is None:
             return
-        nxt = self._predict_next_shell(shell, n_new)
-        if nxt is None:
-            return
-        bound = self.bounds[nxt]
-        if hasattr(bound, 'prefetch'):
-            stats = self.__dict__.setdefault(
-                'prefetch_stats', dict(issued=0, enough=0, right=0, wrong=0))
-            if bound.prefetch(self._shell_request(nxt, self.n_batch)):
-                stats['issued'] += 1
-            else:
-                stats['enough'] += 1
-            self._predicted = nxt
+        nxt, n_ask = plan
+        stats = self.__dict__.setdefault(
+            'prefetch_stats', dict(issued=0, enough=0, right=0, wrong=0))
+        if self.bounds[nxt].prefetch(n_ask):
+            stats['issued'] += 1
+        else:
+            stats['enough'] += 1
+        self._predicted = nxt
 
     def _pair_with_candidates(self, x, shell_t, idx_t):
         """Pair fresh points of the newest shell with stored candidates of
@@ -909,6 +919,11 @@ class Sampler:
                     pts, fetch=self.comm is not None or not DEFER_FETCH,
                     after_fetch=ahead)
         t2 = time()
+        # (the guess of the next batch's shell, while the likelihood kernel
+        # runs: the refill itself is queued further down)
+        plan = self._prefetch_plan(shell, pts.shape[0]) \
+            if self.explored and log_l is None and \
+            not isinstance(pts, _RowsInFlight) else None
         if isinstance(pts, _RowsInFlight):
             # sharded sampling phase: the rows are on their way to this rank
             first = self._pts[shell].reserve(pts.total)
@@ -931,7 +946,7 @@ class Sampler:
                     # the numbers start their way to the host, the next
                     # batch's refill is queued behind them, then the wait
                     host, event = self._fetch_async(both)
-                    self._prefetch_next(shell, log_l_dev.shape[0])
+                    self._prefetch_next(shell, log_l_dev.shape[0], plan)
                     event.synchronize()
                     both = host.numpy().copy()
                 else:
