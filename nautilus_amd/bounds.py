@@ -34,7 +34,8 @@ import os as _os
 # set of the first emulator whose whole ensemble died (tests/tools/collapse_check.py)
 _FILL_TRACE = bool(_os.environ.get('NB_FILL_TRACE'))
 MIN_DRAW = 1 << 14          # proposals per launch, lower limit
-MAX_DRAW = 1 << 22          # upper limit (bounds the scratch memory)
+MAX_DRAW = 1 << int(_os.environ.get('NB_MAX_DRAW_LOG2', '22'))   # upper limit
+#                             (bounds the scratch memory)
 DEAD_MARGIN = 5e-3          # loss within this of the constant predictor's
 MAX_BARREN = 256            # launches of MAX_DRAW without one accepted point
 # measured guard of the pre-fill: after GUARD_LAUNCHES launches of MAX_DRAW

@@ -92,9 +92,35 @@ __device__ __forceinline__ void ell_eval_centre(
   double part[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) part[t] = 0.0;
+  // A last row tile of at most four real rows (n_dim mod 16 in 1..4: two at
+  // n_dim 50, four at 100) runs on v_mfma_f64_4x4x4_4b -- 16 instead of 64
+  // cycles per k-step -- without its last two k-steps (zero padding only),
+  // exactly as in nb_cand.hip's cand_inside: bit for bit register 0 of the
+  // full tile, the other three are the zero rows.
+  const int live = n_dim - 16 * (DT - 1);
+  const bool small = DT > 1 && live >= 1 && live <= 4;
+  const int lane4 = (lane >> 4) * 16 + (lane & 3);
 #pragma unroll
   for (int ht = 0; ht < DT; ++ht) {
-    if (16 * ht < n_dim) {
+    if (ht == DT - 1 && small) {
+      double r4[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) r4[t] = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < 4 * (ht + 1) - 2; ++ks) {
+        const int kt = ks >> 2, s = ks & 3;
+        const double a =
+            tiles[(ht * (ht + 1) / 2 + kt) * NB_TILE + s * 64 + lane4];
+#pragma unroll
+        for (int t = 0; t < T; ++t) r4[t] = NB_MFMA4(a, d[t][ks], r4[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        y[t][4 * ht] = r4[t];
+        y[t][4 * ht + 1] = y[t][4 * ht + 2] = y[t][4 * ht + 3] = 0.0;
+        part[t] += r4[t] * r4[t];
+      }
+    } else if (16 * ht < n_dim) {
       nb_d4 acc[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) acc[t] = nb_d4{0.0, 0.0, 0.0, 0.0};
