@@ -45,7 +45,8 @@ JOBS = ([('reduced', 10, s, True) for s in range(3)] +
          ('reduced', 30, 2, True), ('reduced', 50, 1, True)] +
         # (more seeds where a run is cheap: sigma(log Z) ~ 0.01 per run)
         [('reduced', 20, s, True) for s in range(4, 10)] +
-        [('reduced', 10, s, True) for s in range(4, 10)])
+        [('reduced', 10, s, True) for s in range(4, 10)] +
+        [('reduced', 50, 2, True)])
 SETTINGS = dict(reduced=dict(n_live=2000, n_networks=4),
                 full=dict(n_live=10000, n_networks=8))
 
