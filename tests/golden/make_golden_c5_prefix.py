@@ -98,9 +98,23 @@ def run(seed, cpu_budget_s):
     ref_neural.NeuralNetworkEmulator.train = classmethod(counting_train)
     t0 = time.process_time() - spent
     n_max = rungs[-1]['n_like_max'] if rungs else 0
+    if s.n_like > n_max:             # resumed inside a rung
+        n_max = (s.n_like - 1) // STEP * STEP
     while time.process_time() - t0 < cpu_budget_s and not s.explored:
         n_max += STEP
-        s.run(n_like_max=n_max, discard_exploration=True, verbose=False)
+        # (in slices of 15 minutes with a checkpoint after each: a rung takes
+        # more than an hour from the eighth on, and a killed job should not
+        # lose it -- the slices are the uninterrupted run, see the docstring)
+        while s.n_like < n_max and not s.explored:
+            s.run(n_like_max=n_max, discard_exploration=True, verbose=False,
+                  timeout=900.0)
+            ref_neural.NeuralNetworkEmulator.train = classmethod(inner)
+            with open(ckpt + '.tmp', 'wb') as f:
+                pickle.dump((s, rungs, list(train_rows),
+                             time.process_time() - t0), f, protocol=4)
+            os.replace(ckpt + '.tmp', ckpt)
+            ref_neural.NeuralNetworkEmulator.train = \
+                classmethod(counting_train)
         last = s.bounds[-1]
         rungs.append(dict(
             n_like_max=n_max, n_like=int(s.n_like), n_bounds=len(s.bounds),
