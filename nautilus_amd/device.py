@@ -714,6 +714,34 @@ class LivePool:
                 raise OverflowError('live pool capacity exceeded')
         return float(self._host[0]), int(self._host[1]), int(self._host[2])
 
+    def select_with_stats(self, shells):
+        """``select`` and ``shell_stats(shells)`` with ONE wait: the selection
+        kernel leaves the new threshold on the device, the per-shell
+        reductions read it there, and everything comes to the host in one
+        copy.  Returns ((threshold, #above, #equal), rows)."""
+        if not self.dirty:
+            return self.select(), self.shell_stats(shells)
+        nxt = 1 - self.cur
+        _lib.check(self._lib.nb_live_select(
+            _ptr(self.bufs[self.cur]), _ptr(self.counts[self.cur:]),
+            self.cap, self.k, _ptr(self.bufs[nxt]),
+            _ptr(self.counts[nxt:]), _ptr(self.thr), _ptr(self.stats),
+            _stream()))
+        self.cur = nxt
+        self.dirty = False
+        out = torch.zeros((max(1, len(shells)), 4), dtype=torch.float64,
+                          device='cuda')
+        for row, ll in zip(out, shells):
+            _lib.check(self._lib.nb_live_stats(
+                _ptr(ll), ll.shape[0], _ptr(self.thr), _ptr(row), _stream()))
+        host = torch.cat([self.stats[:3], self.counts[2:].double(),
+                          out[:len(shells), :3].reshape(-1)]).cpu().numpy()
+        self._host = host[:4]
+        if self._host[3] != 0:
+            raise OverflowError('live pool capacity exceeded')
+        return ((float(host[0]), int(host[1]), int(host[2])),
+                host[4:].reshape(len(shells), 3))
+
     def smallest_above(self):
         """Smallest pooled value strictly above the threshold (the likelihood
         plateau rule of add_bound, sampler.py:1012-1020); call after

@@ -334,11 +334,32 @@ class Sampler:
         selection and the per-shell sums on the device.  Ties at the
         threshold (likelihood plateaus) share the remaining places equally --
         the reference takes an arbitrary subset of them."""
-        thr, n_gt, n_eq = self._live_threshold()
-        pool = self._live
-        shells = [s for s in range(len(self._ll_dev))
-                  if self._ll_dev[s].n > 0 and self._shell_max[s] >= thr]
-        rows = pool.shell_stats([self._ll_dev[s].view() for s in shells])
+        pool = self._live_pool()
+        rows = None
+        if pool.dirty:
+            # one wait for the selection AND the per-shell sums: the shells
+            # that reached the PREVIOUS threshold are a superset of those that
+            # reach the new one (it only rises while the pool lives)
+            thr_prev = float(pool._host[0])
+            shells = [s for s in range(len(self._ll_dev))
+                      if self._ll_dev[s].n > 0 and
+                      self._shell_max[s] >= thr_prev]
+            try:
+                (thr, n_gt, n_eq), rows = pool.select_with_stats(
+                    [self._ll_dev[s].view() for s in shells])
+                keep = [i for i, s in enumerate(shells)
+                        if self._shell_max[s] >= thr]
+                shells = [shells[i] for i in keep]
+                rows = rows[keep]
+            except OverflowError:           # many batches without a selection
+                self._live = None
+                rows = None
+        if rows is None:
+            thr, n_gt, n_eq = self._live_threshold()
+            pool = self._live
+            shells = [s for s in range(len(self._ll_dev))
+                      if self._ll_dev[s].n > 0 and self._shell_max[s] >= thr]
+            rows = pool.shell_stats([self._ll_dev[s].view() for s in shells])
         frac = min(1.0, max(0.0, (self.n_live - n_gt) / n_eq)) if n_eq > 0 \
             else 0.0
         log_w, log_v = [-np.inf], [-np.inf]
