@@ -1784,7 +1784,14 @@ void g_plan(int kt1, std::vector<int>& jobs, std::vector<int>& sched) {
   const int n_free = XCD_SLOTS - G_ROWT;
   GPlan best;
   const int shapes[5][2] = {{2, 1}, {1, 2}, {3, 1}, {2, 2}, {1, 1}};
+  // (experiment switches: force the number of late-only workgroups / the
+  // block shape of the late jobs instead of taking the cost model's choice)
+  const char* e_lo = getenv("NB_TRAIN_LATE_ONLY");
+  const char* e_sh = getenv("NB_TRAIN_LATE_SHAPE");
+  const int f_lo = e_lo != nullptr ? atoi(e_lo) : -1;
+  const int f_sh = e_sh != nullptr ? atoi(e_sh) : -1;
   for (int late_only = 0; late_only <= 3; ++late_only) {
+    if (f_lo >= 0 && late_only != f_lo) continue;
     const std::vector<GRec> early = g_early(late_only);
     if ((int)early.size() + late_only != n_free) continue;
     // when the workgroups are free for a late job
@@ -1805,7 +1812,9 @@ void g_plan(int kt1, std::vector<int>& jobs, std::vector<int>& sched) {
                         const std::pair<double, int>& y) {
                        return x.first < y.first;
                      });
-    for (const auto& sh : shapes) {
+    for (int si = 0; si < 5; ++si) {
+      if (f_sh >= 0 && si != f_sh) continue;
+      const int* sh = shapes[si];
       std::vector<GRec> late;
       g_blocks(late, 0, kt1, NB_HT1, sh[0], sh[1]);
       while ((int)late.size() <= XCD_SLOTS) {
