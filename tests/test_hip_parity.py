@@ -1050,6 +1050,73 @@ def test_periodic_nautilus_bound(dev):
     assert abs(full.log_v - float(g['log_v'])) < 0.1
 
 
+def _product_bound(g, seed):
+    """The golden NautilusBound as a nautilus_amd.bounds.NautilusBound with
+    its Philox stream at a known place."""
+    from nautilus_amd import bounds as nb
+    from nautilus_amd.emulator import NeuralNetworkEmulator, Network
+    ob = nautilus_from_golden(g)
+    outer = nb.Union.from_members(
+        [nb.UnitCubeEllipsoidMixture.from_params(
+            m.dim_cube, None if m.ellipsoid is None else
+            nb.Ellipsoid.from_params(m.ellipsoid.c, m.ellipsoid.B,
+                                     m.ellipsoid.B_inv, m.ellipsoid.A))
+         for m in ob.outer_bound.bounds], unit=True)
+    outer.log_v_all = ob.outer_bound.log_v_all
+    neural = []
+    for o in ob.neural_bounds:
+        emu = NeuralNetworkEmulator.from_weights(
+            o.emulator.mean, o.emulator.scale,
+            [Network(n_.coefs, n_.intercepts) for n_ in o.emulator.networks])
+        neural.append(nb.NeuralBound.from_parts(
+            nb.Ellipsoid.from_params(o.outer_bound.c, o.outer_bound.B,
+                                     o.outer_bound.B_inv, o.outer_bound.A),
+            emu, o.score_predict_min))
+    full = nb.NautilusBound.from_parts(outer, neural,
+                                       rng=np.random.default_rng(1))
+    full._stream.seed, full._stream.offset = seed, 0
+    return full
+
+
+def test_refill_ahead_hands_out_the_same_points(dev):
+    """``prefetch`` (the refill of the next batch's bound, launched before
+    the host waits for the current batch; sampler.py ``_prefetch_next``)
+    draws what the refill-when-asked loop would have drawn -- the bound's
+    Philox stream, consumed in order -- so the points a bound hands out do
+    not depend on when its refills were launched, a refill in flight lands
+    before anything looks at the queue, and the Monte-Carlo volume counters
+    count every proposal that was examined."""
+    g = load_golden('nautilusbound_D4')
+    plain, ahead = _product_bound(g, 123), _product_bound(g, 123)
+    asks = (3000, 500, 7000, 1, 2500)
+    want = [plain.sample_device(n).clone() for n in asks]
+    got = []
+    for i, n in enumerate(asks):
+        ahead.prefetch(n)                      # in flight ...
+        assert ahead.__dict__.get('_pending') is not None or i > 0
+        if i == 2:
+            assert len(ahead.points) >= 0      # ... lands when looked at
+            assert ahead.__dict__.get('_pending') is None
+        got.append(ahead.sample_device(n).clone())
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    # a refill in flight when the bound is pickled lands first
+    import pickle
+    ahead.prefetch(10**5)
+    state = pickle.loads(pickle.dumps(ahead))
+    assert state.__dict__.get('_pending') is None
+    assert ahead.__dict__.get('_pending') is None
+    assert ahead.n_sample >= plain.n_sample and ahead.n_sample > 0
+    assert abs(ahead.log_v - plain.log_v) < 0.05
+    # ... and one that is dropped (reset) leaves no slot behind
+    from nautilus_amd.bounds import _PrefetchSlots
+    free = len(_PrefetchSlots.free)
+    assert ahead.prefetch(10**6)
+    assert len(_PrefetchSlots.free) == free - 1
+    ahead.reset(np.random.default_rng(2))
+    assert len(_PrefetchSlots.free) == free
+
+
 def test_shell_exclusion_and_association(dev, nautilus_d4, neural_d4):
     """sampler.py:797-798 and 1213-1219 over a list of nested bounds."""
     import torch
