@@ -625,7 +625,11 @@ def main():
             ((prop1 - prop0) / world + 2.0 * (n_like1 - n_like0) / world)
             * (8 * d + 1) / max(1, ev['launches'])),
         point_evals=work, dominant_by_time=dominant,
-        time_share={k: v['ms'] for k, v in kernels.items()})
+        time_share={k: v['ms'] for k, v in kernels.items()},
+        # committed counter passes of the same steps (one counter per
+        # rocprofv3 pass): SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / kernel cycles
+        matrix_pipe_busy='0.80 of the kernel cycles (profiles/r06/'
+                         'fast_pmc.txt; not measured in this run)')
 
     # emulator networks per bound (M x E) against the ranks they are dealt out
     # over (network g trains on rank g mod world, reference neural.py:93-96)
