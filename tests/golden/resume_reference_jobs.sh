@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Run WITHOUT a pipe behind it: the jobs inherit stdout.)
 # (Re)start the long reference jobs of round 6; every one resumes from its
 # checkpoint under gpurun_out/refjobs/ and skips itself when its result exists.
 cd "$(dirname "$0")/../.."
@@ -19,4 +20,4 @@ runs = json.load(open('tests/golden/e2e_C3.json'))['runs']
 sys.exit(0 if any(r.get('seed') == 1 for r in runs) else 1)
 PY
 sleep 3
-ps aux | grep make_golden | grep -v grep | awk '{print $12, $13, $14}'
+ps aux | grep make_golden | grep -v grep | wc -l
