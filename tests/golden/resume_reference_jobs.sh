@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/refjobs
 export OMP_NUM_THREADS=1 OPENBLAS_NUM_THREADS=1 MKL_NUM_THREADS=1
 running() { ps aux | grep -v grep | grep -q "$1"; }
-for t in reduced_D50_seed0 reduced_D50_seed1 reduced_D50_seed2; do
+for t in reduced_D50_seed0 reduced_D50_seed1; do
   [ -f tests/golden/funnel_parts/$t.json ] || running "make_golden_funnel.py $t" || \
     nohup setsid python tests/golden/make_golden_funnel.py $t >> gpurun_out/refjobs/$t.log 2>&1 &
 done
@@ -14,10 +14,7 @@ for s in 0 1; do
   running "make_golden_c5_prefix.py $s " || \
     nohup setsid python tests/golden/make_golden_c5_prefix.py $s 36000 >> gpurun_out/refjobs/c5prefix_$s.log 2>&1 &
 done
-python - <<'PY' || { running "make_golden_c3.py 1 single" || nohup setsid python tests/golden/make_golden_c3.py 1 single >> gpurun_out/refjobs/c3_seed1.log 2>&1 & }
-import json, sys
-runs = json.load(open('tests/golden/e2e_C3.json'))['runs']
-sys.exit(0 if any(r.get('seed') == 1 for r in runs) else 1)
-PY
+# (a second C3 run on one core was started in round 6 and stopped 1.7 h in:
+# 36 of ~185 bounds -- it needs ~9 h; `make_golden_c3.py 1 single` resumes)
 sleep 3
 ps aux | grep make_golden | grep -v grep | wc -l
