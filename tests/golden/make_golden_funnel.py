@@ -124,6 +124,32 @@ def run_job(job):
     return path
 
 
+def snapshot(job):
+    """State of a run in progress, read from its checkpoint: what
+    ``run(n_like_max=<its n_like>)`` of the reference leaves behind (the
+    slices end between batches, so the state is the one the reference has
+    when it stops at that number of calls).  Written to
+    tests/golden/funnel_parts/<tag>_snapshot.json -- a like-for-like anchor
+    for runs that do not finish inside a round."""
+    import pickle
+    ckpt = os.path.join(CKPT, 'funnel_' + tag(job) + '.pkl')
+    with open(ckpt, 'rb') as f:
+        s, spent = pickle.load(f)
+    out = dict(setting=job[0], n_dim=job[1], seed=job[2],
+               n_like=int(s.n_like), n_bounds=len(s.bounds),
+               explored=bool(s.explored),
+               log_v=[float(b.log_v) for b in s.bounds],
+               shell_n=[int(n) for n in s.shell_n],
+               shell_log_l_min=[float(x) for x in s.shell_log_l_min],
+               f_live=None if s.explored else float(s.f_live),
+               log_z=float(s.log_z), cpu_s=float(spent),
+               **SETTINGS[job[0]])
+    path = os.path.join(PARTS, tag(job) + '_snapshot.json')
+    with open(path, 'w') as f:
+        json.dump(out, f)
+    return path
+
+
 def merge():
     runs = []
     for job in JOBS:
@@ -145,6 +171,9 @@ def merge():
 if __name__ == '__main__':
     if sys.argv[1] == 'merge':
         merge()
+    elif sys.argv[1] == 'snapshot':
+        one = [j for j in JOBS if tag(j) == sys.argv[2]]
+        print(snapshot(one[0]))
     elif sys.argv[1] == 'run':
         import multiprocessing as mp
         workers = int(sys.argv[2]) if len(sys.argv) > 2 else 6
