@@ -418,10 +418,10 @@ class _PrefetchSlots:
     owners = []                # (bound, slot), oldest first
 
     @classmethod
-    def acquire(cls, bound, keep=0):
-        """A free slot for ``bound`` (which holds ``keep`` slots of the
-        refill it is issuing); with none free the oldest other refill in
-        flight lands first."""
+    def acquire(cls, bound):
+        """A free slot for ``bound`` (which may hold slots of the refill it
+        is issuing); with none free the oldest other refill in flight lands
+        first."""
         if not cls.free:
             oldest = next(b for b, _ in cls.owners if b is not bound)
             oldest._land_pending()
@@ -494,7 +494,7 @@ class _RejectionSampler(_DeviceBoundBase):
         while need > 0 and len(pending) < PREFETCH_LAUNCHES:
             n_draw = self._launch(need)
             seed, off = self._stream.take(n_draw)
-            slot = _PrefetchSlots.acquire(self, keep=len(pending))
+            slot = _PrefetchSlots.acquire(self)
             rows, counts = self.device_bound().sample_launch(
                 seed, off, n_draw, reuse=True, out_role='prefetch%d' % slot)
             pending.append((rows, counts, n_draw, slot))
