@@ -41,7 +41,7 @@ SETTINGS = dict(n_live=2000, n_networks=4)
 
 # (n_dim, seed), in the order they are started
 JOBS = [(10, 0), (10, 1), (10, 2), (20, 0), (20, 1), (10, 3), (20, 2),
-        (30, 0), (30, 1)]
+        (30, 0), (30, 1), (30, 2)]
 
 
 def means_of(d):
