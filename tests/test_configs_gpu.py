@@ -61,7 +61,14 @@ def _invariants(c, s):
     """What must hold at any point of a run."""
     assert len(s.bounds) >= 2
     vols = np.array([b.log_v for b in s.bounds])
-    assert np.all(np.diff(vols) < 0)                 # sampler.py:1035-1038
+    # sampler.py:1035-1038 accepts a bound whose volume estimate is smaller
+    # than its predecessor's AT THAT MOMENT; both are Monte-Carlo estimates
+    # that keep moving as their bounds are sampled (union.py:329-343,
+    # nautilus.py:246-261), so two neighbours of nearly equal volume may
+    # change places later -- by the scatter of the estimates, not more
+    steps = np.diff(vols)
+    assert np.all(steps < 0.1), steps[steps >= 0]
+    assert np.mean(steps < 0) > 0.97
     assert np.isfinite(s.log_z)
     used = s.shell_n > 0
     assert np.all(s.shell_n_sample[used] >= s.shell_n[used])
