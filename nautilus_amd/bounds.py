@@ -46,15 +46,22 @@ MAX_BARREN = 256            # launches of MAX_DRAW without one accepted point
 
 
 
-def _MARGIN(need):
+def _MARGIN(need, accepted=0):
     """Proposals drawn per accepted point needed, over the inverse of the
-    acceptance measured so far: four standard deviations of the count on top,
-    at least 2 % (a flat 20 % until round 6 -- 0.2 ms of surplus proposals per
-    65 536-point step of the headline run; NB_DRAW_MARGIN=loose restores it).
-    A launch that falls short is followed by another, as before."""
+    acceptance measured so far: four standard deviations on top -- of the
+    count of this launch and of the acceptance estimate itself, which rests on
+    the ``accepted`` points the bound has handed out so far -- between 2 % and
+    the flat 20 % of the rounds before 6 (0.2 ms of surplus proposals per
+    65 536-point step of the headline run; a young bound of configuration 4,
+    whose acceptance is known from a few hundred points, keeps the 20 %: with
+    2 % its refills fell short every other time and the run took 187 s instead
+    of 170).  NB_DRAW_MARGIN=loose restores the flat 20 %.  A launch that falls
+    short is followed by another, as before."""
     if _os.environ.get('NB_DRAW_MARGIN') == 'loose':
         return 1.2
-    return 1.0 + max(0.02, 4.0 / np.sqrt(max(need, 1.0)))
+    rel = 4.0 * max(1.0 / np.sqrt(max(need, 1.0)),
+                    1.0 / np.sqrt(max(accepted, 1.0)))
+    return 1.0 + min(0.2, max(0.02, rel))
 
 
 PREFETCH_LAUNCHES = 1       # launches of one refill issued ahead (prefetch)
@@ -547,7 +554,8 @@ class _RejectionSampler(_DeviceBoundBase):
         """Number of proposals of one refill launch for ``need`` more
         points."""
         acc = max(self._acceptance(), 1e-7)
-        n_draw = int(min(MAX_DRAW, max(MIN_DRAW, _MARGIN(need) * need / acc)))
+        margin = _MARGIN(need, self.n_sample - self.n_reject)
+        n_draw = int(min(MAX_DRAW, max(MIN_DRAW, margin * need / acc)))
         n_draw = (n_draw + 63) // 64 * 64
         return n_draw
 
